@@ -1,0 +1,96 @@
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+    python -m oracle.make_golden            # writes tests/golden/<case>.npz
+
+The reference ships no golden vectors, so these fixtures are
+outputs of the reference's own ``GlocalTextPathNavCMT`` (imported from
+/root/reference through ``oracle/ref_harness.py``), fp32 CPU, eval mode, on
+seeded synthetic inputs (``planner_oracle.make_batch`` seed 1234) with seeded
+weights (``planner_oracle.init_params`` seed 0).  Full gradients are 563 MB per
+case, so each parameter gradient is stored as a fingerprint (sum, abs-max, L2)
+plus 48 values at fixed strided indices; small outputs are stored whole.
+TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import planner_oracle as po  # noqa: E402
+
+N_SAMPLE = 48
+
+# name -> (config factory kwargs, batch kwargs)
+CASES = {
+    # BASELINE.json configs[0]: single episode, 12 pano + 5 cand views, 20 tokens
+    "c1_single_episode": (dict(kind="r2r"), dict(B=1, L=20, V=17, G=9, ragged=False)),
+    # ragged lengths, ignore_index label, tiny
+    "ragged_small": (dict(kind="r2r"), dict(B=3, L=12, V=14, G=7, ragged=True)),
+    # per-sample shape of configs[1] (36 views x 768-d, 80 tokens, 16 nodes)
+    "c2_shape_b2": (dict(kind="r2r", image_feat_size=768), dict(B=2, L=80, V=36, G=16, ragged=False)),
+    # configs[4]: 64 graph nodes (G > V)
+    "c5_g64_b2": (dict(kind="r2r"), dict(B=2, L=24, V=36, G=64, ragged=True)),
+    # configs[3]: XLM-R vocabulary / eps 1e-5 (short text to keep the fixture cheap)
+    "c4_rxr_b1": (dict(kind="rxr"), dict(B=1, L=48, V=14, G=6, ragged=False)),
+}
+
+
+def make_cfg(kind="r2r", **kw):
+    return po.PlannerConfig.rxr(**kw) if kind == "rxr" else po.PlannerConfig.r2r(**kw)
+
+
+def sample_idx(n: int) -> np.ndarray:
+    if n <= N_SAMPLE:
+        return np.arange(n)
+    return np.unique(np.linspace(0, n - 1, N_SAMPLE).astype(np.int64))
+
+
+def fingerprint(t: torch.Tensor):
+    f = t.detach().double().reshape(-1)
+    fp = np.array([float(f.sum()), float(f.abs().max()), float(f.norm())], dtype=np.float64)
+    idx = sample_idx(f.numel())
+    return fp, f[torch.from_numpy(idx)].float().numpy()
+
+
+def pack(outs, grads):
+    d = {}
+    for k in ("txt_embeds", "pano_embeds", "gmap_embeds", "global_logits", "loss", "gmap_img_fts"):
+        d[f"out.{k}"] = outs[k].float().numpy()
+    d["out.pano_masks"] = outs["pano_masks"].numpy()
+    for k, g in grads.items():
+        fp, smp = fingerprint(g)
+        d[f"gfp.{k}"] = fp
+        d[f"gsm.{k}"] = smp
+    return d
+
+
+def main():
+    from oracle import ref_harness as rh
+    assert rh.reference_available(), "needs /root/reference"
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    only = sys.argv[1:]
+    for name, (ckw, bkw) in CASES.items():
+        if only and name not in only:
+            continue
+        cfg = make_cfg(**ckw)
+        P = po.init_params(cfg, seed=0)
+        model = rh.build_reference_model(cfg, P)
+        batch = po.make_batch(cfg, seed=1234, **bkw)
+        outs, grads = rh.reference_step(model, batch)
+        d = pack(outs, grads)
+        d["meta.cfg"] = np.array(repr(ckw))
+        d["meta.batch"] = np.array(repr(bkw))
+        path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+        np.savez_compressed(path, **d)
+        print(name, "loss", float(outs["loss"]), os.path.getsize(path) // 1024, "KiB")
+        del model
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,476 @@
+"""CPU oracle for the ETPNav cross-modal planner hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a *restatement* of the reference algorithm in plain torch tensor
+math (fp32 or fp64, CPU).  It is not shipped, never imported by the product
+package ``etpnav_amd`` and never used as a fallback: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  Gradients come from torch autograd over this restatement, which is how the
+reference itself obtains them (it has no hand-written backward).
+
+Parity pinning: the reference ships no tests / golden vectors, so
+this oracle is pinned against outputs of the *reference itself* imported in the
+build container (``oracle/ref_harness.py``); ``oracle/make_golden.py`` commits
+those outputs as fixtures under ``tests/golden/`` and
+``tests/test_oracle_golden.py`` re-checks the oracle against them everywhere
+(the reference does not travel to the GPU box).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  Parameter names are the reference state-dict names
+(SURVEY.md Appendix B).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Optional
+
+import torch
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class PlannerConfig:
+    """Hyper-parameters fixed by vlnce_baselines/models/etp/vlnbert_init.py:32-59
+    plus bert_config/*/config.json."""
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    num_l_layers: int = 9
+    num_pano_layers: int = 2
+    num_x_layers: int = 4
+    vocab_size: int = 30522
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    image_feat_size: int = 512
+    depth_feat_size: int = 128
+    angle_feat_size: int = 4
+    max_action_steps: int = 100
+    use_depth_embedding: bool = True
+    graph_sprels: bool = True
+    layer_norm_eps: float = 1e-12
+
+    @staticmethod
+    def r2r(**kw) -> "PlannerConfig":
+        return PlannerConfig(**kw)
+
+    @staticmethod
+    def rxr(**kw) -> "PlannerConfig":
+        # bert_config/xlm-roberta-base/config.json + vlnbert_init.py:38-39
+        d = dict(vocab_size=250002, max_position_embeddings=514, type_vocab_size=2,
+                 layer_norm_eps=1e-5)
+        d.update(kw)
+        return PlannerConfig(**d)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+# --------------------------------------------------------------------------
+# parameter tree
+# --------------------------------------------------------------------------
+def param_shapes(cfg: PlannerConfig) -> Dict[str, tuple]:
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    s: Dict[str, tuple] = {}
+    s["embeddings.word_embeddings.weight"] = (cfg.vocab_size, H)
+    s["embeddings.position_embeddings.weight"] = (cfg.max_position_embeddings, H)
+    s["embeddings.token_type_embeddings.weight"] = (cfg.type_vocab_size, H)
+    s["embeddings.LayerNorm.weight"] = (H,)
+    s["embeddings.LayerNorm.bias"] = (H,)
+
+    def bert_attention(p):  # BertAttention: vilmodel_cmt.py:156-166
+        for n in ("query", "key", "value"):
+            s[f"{p}.self.{n}.weight"] = (H, H)
+            s[f"{p}.self.{n}.bias"] = (H,)
+        s[f"{p}.output.dense.weight"] = (H, H)
+        s[f"{p}.output.dense.bias"] = (H,)
+        s[f"{p}.output.LayerNorm.weight"] = (H,)
+        s[f"{p}.output.LayerNorm.bias"] = (H,)
+
+    def ffn(pi, po):
+        s[f"{pi}.dense.weight"] = (I, H)
+        s[f"{pi}.dense.bias"] = (I,)
+        s[f"{po}.dense.weight"] = (H, I)
+        s[f"{po}.dense.bias"] = (H,)
+        s[f"{po}.LayerNorm.weight"] = (H,)
+        s[f"{po}.LayerNorm.bias"] = (H,)
+
+    for l in range(cfg.num_l_layers):
+        p = f"lang_encoder.layer.{l}"
+        bert_attention(f"{p}.attention")
+        ffn(f"{p}.intermediate", f"{p}.output")
+
+    e = "img_embeddings"
+    s[f"{e}.img_linear.weight"] = (H, cfg.image_feat_size)
+    s[f"{e}.img_linear.bias"] = (H,)
+    s[f"{e}.img_layer_norm.weight"] = (H,)
+    s[f"{e}.img_layer_norm.bias"] = (H,)
+    s[f"{e}.loc_linear.weight"] = (H, cfg.angle_feat_size)
+    s[f"{e}.loc_linear.bias"] = (H,)
+    s[f"{e}.loc_layer_norm.weight"] = (H,)
+    s[f"{e}.loc_layer_norm.bias"] = (H,)
+    if cfg.use_depth_embedding:
+        s[f"{e}.dep_linear.weight"] = (H, cfg.depth_feat_size)
+        s[f"{e}.dep_linear.bias"] = (H,)
+        s[f"{e}.dep_layer_norm.weight"] = (H,)
+        s[f"{e}.dep_layer_norm.bias"] = (H,)
+    s[f"{e}.nav_type_embedding.weight"] = (2, H)
+    s[f"{e}.layer_norm.weight"] = (H,)
+    s[f"{e}.layer_norm.bias"] = (H,)
+    for l in range(cfg.num_pano_layers):
+        p = f"{e}.pano_encoder.layers.{l}"
+        s[f"{p}.self_attn.in_proj_weight"] = (3 * H, H)
+        s[f"{p}.self_attn.in_proj_bias"] = (3 * H,)
+        s[f"{p}.self_attn.out_proj.weight"] = (H, H)
+        s[f"{p}.self_attn.out_proj.bias"] = (H,)
+        s[f"{p}.linear1.weight"] = (I, H)
+        s[f"{p}.linear1.bias"] = (I,)
+        s[f"{p}.linear2.weight"] = (H, I)
+        s[f"{p}.linear2.bias"] = (H,)
+        s[f"{p}.norm1.weight"] = (H,)
+        s[f"{p}.norm1.bias"] = (H,)
+        s[f"{p}.norm2.weight"] = (H,)
+        s[f"{p}.norm2.bias"] = (H,)
+    if cfg.num_pano_layers > 0:
+        s[f"{e}.pano_encoder.norm.weight"] = (H,)
+        s[f"{e}.pano_encoder.norm.bias"] = (H,)
+
+    g = "global_encoder"
+    s[f"{g}.gmap_pos_embeddings.0.weight"] = (H, cfg.angle_feat_size + 3)
+    s[f"{g}.gmap_pos_embeddings.0.bias"] = (H,)
+    s[f"{g}.gmap_pos_embeddings.1.weight"] = (H,)
+    s[f"{g}.gmap_pos_embeddings.1.bias"] = (H,)
+    s[f"{g}.gmap_step_embeddings.weight"] = (cfg.max_action_steps, H)
+    for l in range(cfg.num_x_layers):
+        p = f"{g}.encoder.x_layers.{l}"
+        bert_attention(f"{p}.visn_self_att")
+        ffn(f"{p}.visn_inter", f"{p}.visn_output")
+        for n in ("query", "key", "value"):
+            s[f"{p}.visual_attention.att.{n}.weight"] = (H, H)
+            s[f"{p}.visual_attention.att.{n}.bias"] = (H,)
+        s[f"{p}.visual_attention.output.dense.weight"] = (H, H)
+        s[f"{p}.visual_attention.output.dense.bias"] = (H,)
+        s[f"{p}.visual_attention.output.LayerNorm.weight"] = (H,)
+        s[f"{p}.visual_attention.output.LayerNorm.bias"] = (H,)
+    if cfg.graph_sprels:
+        s[f"{g}.sprel_linear.weight"] = (1, 1)
+        s[f"{g}.sprel_linear.bias"] = (1,)
+    s["global_sap_head.net.0.weight"] = (H, H)
+    s["global_sap_head.net.0.bias"] = (H,)
+    s["global_sap_head.net.2.weight"] = (H,)
+    s["global_sap_head.net.2.bias"] = (H,)
+    s["global_sap_head.net.4.weight"] = (1, H)
+    s["global_sap_head.net.4.bias"] = (1,)
+    return s
+
+
+def init_params(cfg: PlannerConfig, seed: int = 0, dtype=torch.float32,
+                perturb: bool = True) -> Dict[str, Tensor]:
+    """BERT-style init (normal(0, .02) weights, zero bias, LN=(1,0)) — the
+    transformers-4.12 ``init_weights`` the reference ctor calls
+    (vilmodel_cmt.py:673).  With ``perturb`` biases / LN affine / sprel get small
+    random values too so that parity tests exercise every term."""
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, Tensor] = {}
+    for name, shape in param_shapes(cfg).items():
+        is_ln = ("LayerNorm" in name or "layer_norm" in name or ".norm" in name
+                 or name.endswith("gmap_pos_embeddings.1.weight")
+                 or name.endswith("gmap_pos_embeddings.1.bias")
+                 or "global_sap_head.net.2" in name)
+        if name.endswith("weight") and len(shape) == 2 and not is_ln:
+            t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
+            if "sprel_linear" in name:
+                t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.5 if perturb else t
+        elif is_ln and name.endswith("weight"):
+            t = torch.ones(shape)
+            if perturb:
+                t = t + 0.1 * torch.randn(shape, generator=g)
+        else:  # biases, LN bias, in_proj_weight handled above (2-D)
+            if name.endswith("in_proj_weight"):
+                t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
+            else:
+                t = torch.zeros(shape)
+                if perturb:
+                    t = 0.02 * torch.randn(shape, generator=g)
+        out[name] = t.to(dtype)
+    return out
+
+
+# --------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    """torch.nn.LayerNorm: biased variance over the last dim."""
+    mu = x.mean(-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdim=True)
+    return xc / torch.sqrt(var + eps) * w + b
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    y = x @ w.transpose(-1, -2)
+    return y if b is None else y + b
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """vilmodel_cmt.py:31-37 (exact erf form; F.gelu default is the same)."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def extend_neg_masks(masks: Tensor, dtype) -> Tensor:
+    """common/ops.py:25-34: (N,L) bool -> (N,1,1,L) additive -10000 mask."""
+    return (1.0 - masks[:, None, None, :].to(dtype)) * -10000.0
+
+
+def gen_seq_masks(seq_lens: Tensor, max_len: Optional[int] = None) -> Tensor:
+    """common/ops.py:36-44."""
+    if max_len is None:
+        max_len = int(seq_lens.max())
+    return torch.arange(max_len)[None, :] < seq_lens[:, None]
+
+
+def _split_heads(x: Tensor, nh: int) -> Tensor:
+    n, t, h = x.shape
+    return x.view(n, t, nh, h // nh).permute(0, 2, 1, 3)
+
+
+def _merge_heads(x: Tensor) -> Tensor:
+    n, nh, t, d = x.shape
+    return x.permute(0, 2, 1, 3).reshape(n, t, nh * d)
+
+
+def bert_attention_core(q: Tensor, k: Tensor, v: Tensor, add_mask: Tensor, nh: int) -> Tensor:
+    """vilmodel_cmt.py:112-137 / :330-351: softmax(QK^T/sqrt(d) + mask) V."""
+    qh, kh, vh = _split_heads(q, nh), _split_heads(k, nh), _split_heads(v, nh)
+    scores = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
+    scores = scores + add_mask
+    probs = torch.softmax(scores, dim=-1)
+    return _merge_heads(probs @ vh)
+
+
+def bert_self_attention_block(P, p: str, x: Tensor, add_mask: Tensor, cfg: PlannerConfig) -> Tensor:
+    """BertAttention (vilmodel_cmt.py:156-166) = BertSelfAttention :103-141 +
+    BertSelfOutput :150-154 (post-LN)."""
+    q = linear(x, P[f"{p}.self.query.weight"], P[f"{p}.self.query.bias"])
+    k = linear(x, P[f"{p}.self.key.weight"], P[f"{p}.self.key.bias"])
+    v = linear(x, P[f"{p}.self.value.weight"], P[f"{p}.self.value.bias"])
+    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads)
+    o = linear(ctx, P[f"{p}.output.dense.weight"], P[f"{p}.output.dense.bias"])
+    return layer_norm(o + x, P[f"{p}.output.LayerNorm.weight"], P[f"{p}.output.LayerNorm.bias"],
+                      cfg.layer_norm_eps)
+
+
+def bert_ffn_block(P, pi: str, po: str, x: Tensor, cfg: PlannerConfig) -> Tensor:
+    """BertIntermediate :177-180 + BertOutput :189-193."""
+    h = gelu_erf(linear(x, P[f"{pi}.dense.weight"], P[f"{pi}.dense.bias"]))
+    o = linear(h, P[f"{po}.dense.weight"], P[f"{po}.dense.bias"])
+    return layer_norm(o + x, P[f"{po}.LayerNorm.weight"], P[f"{po}.LayerNorm.bias"],
+                      cfg.layer_norm_eps)
+
+
+def cross_attention_block(P, p: str, x: Tensor, ctx_in: Tensor, add_mask: Tensor,
+                          cfg: PlannerConfig) -> Tensor:
+    """BertXAttention :360-363 = BertOutAttention :325-352 + BertSelfOutput."""
+    q = linear(x, P[f"{p}.att.query.weight"], P[f"{p}.att.query.bias"])
+    k = linear(ctx_in, P[f"{p}.att.key.weight"], P[f"{p}.att.key.bias"])
+    v = linear(ctx_in, P[f"{p}.att.value.weight"], P[f"{p}.att.value.bias"])
+    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads)
+    o = linear(ctx, P[f"{p}.output.dense.weight"], P[f"{p}.output.dense.bias"])
+    return layer_norm(o + x, P[f"{p}.output.LayerNorm.weight"], P[f"{p}.output.LayerNorm.bias"],
+                      cfg.layer_norm_eps)
+
+
+# --------------------------------------------------------------------------
+# the three planner entry points
+# --------------------------------------------------------------------------
+def forward_txt(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor) -> Tensor:
+    """GlocalTextPathNavCMT.forward_txt vilmodel_cmt.py:684-688 =
+    BertEmbeddings :62-77 (eval: dropout off) + LanguageEncoder :426-433."""
+    dt = P["embeddings.LayerNorm.weight"].dtype
+    L = txt_ids.shape[1]
+    e = (P["embeddings.word_embeddings.weight"][txt_ids]
+         + P["embeddings.position_embeddings.weight"][:L][None]
+         + P["embeddings.token_type_embeddings.weight"][0][None, None])
+    x = layer_norm(e, P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"],
+                   cfg.layer_norm_eps)
+    m = extend_neg_masks(txt_masks, dt)
+    for l in range(cfg.num_l_layers):
+        p = f"lang_encoder.layer.{l}"
+        x = bert_self_attention_block(P, f"{p}.attention", x, m, cfg)
+        x = bert_ffn_block(P, f"{p}.intermediate", f"{p}.output", x, cfg)
+    return x
+
+
+def pano_encoder_layer(P, p: str, x: Tensor, key_valid: Tensor, cfg: PlannerConfig) -> Tensor:
+    """TransformerEncoderLayer.forward_pre common/transformer.py:170-182 with
+    nn.MultiheadAttention math spelt out: packed in_proj [3H,H], q scaled by
+    1/sqrt(d), padded keys -> -inf.  norm1/norm2 use eps=1e-5 (:144-145).
+    Batch-first here; the reference's seq-first transposes (:76-77,86-87) are
+    layout only."""
+    H, nh = cfg.hidden_size, cfg.num_attention_heads
+    a = layer_norm(x, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], 1e-5)
+    qkv = linear(a, P[f"{p}.self_attn.in_proj_weight"], P[f"{p}.self_attn.in_proj_bias"])
+    q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
+    qh, kh, vh = _split_heads(q, nh), _split_heads(k, nh), _split_heads(v, nh)
+    scores = (qh / math.sqrt(H // nh)) @ kh.transpose(-1, -2)
+    scores = scores.masked_fill(~key_valid[:, None, None, :], float("-inf"))
+    ctx = _merge_heads(torch.softmax(scores, -1) @ vh)
+    x = x + linear(ctx, P[f"{p}.self_attn.out_proj.weight"], P[f"{p}.self_attn.out_proj.bias"])
+    f = layer_norm(x, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"], 1e-5)
+    h = gelu_erf(linear(f, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"]))
+    return x + linear(h, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"])
+
+
+def forward_panorama(P, cfg: PlannerConfig, rgb_fts: Tensor, dep_fts: Tensor, loc_fts: Tensor,
+                     nav_types: Tensor, view_lens: Tensor):
+    """GlocalTextPathNavCMT.forward_panorama vilmodel_cmt.py:690-719."""
+    e = "img_embeddings"
+    x = layer_norm(linear(rgb_fts, P[f"{e}.img_linear.weight"], P[f"{e}.img_linear.bias"]),
+                   P[f"{e}.img_layer_norm.weight"], P[f"{e}.img_layer_norm.bias"], 1e-12)
+    if cfg.use_depth_embedding:
+        x = x + layer_norm(linear(dep_fts, P[f"{e}.dep_linear.weight"], P[f"{e}.dep_linear.bias"]),
+                           P[f"{e}.dep_layer_norm.weight"], P[f"{e}.dep_layer_norm.bias"], 1e-12)
+    x = (x
+         + layer_norm(linear(loc_fts, P[f"{e}.loc_linear.weight"], P[f"{e}.loc_linear.bias"]),
+                      P[f"{e}.loc_layer_norm.weight"], P[f"{e}.loc_layer_norm.bias"], 1e-12)
+         + P[f"{e}.nav_type_embedding.weight"][nav_types]
+         + P["embeddings.token_type_embeddings.weight"][1][None, None])
+    x = layer_norm(x, P[f"{e}.layer_norm.weight"], P[f"{e}.layer_norm.bias"], 1e-12)
+    masks = gen_seq_masks(view_lens, rgb_fts.shape[1])
+    for l in range(cfg.num_pano_layers):
+        x = pano_encoder_layer(P, f"{e}.pano_encoder.layers.{l}", x, masks, cfg)
+    if cfg.num_pano_layers > 0:
+        x = layer_norm(x, P[f"{e}.pano_encoder.norm.weight"], P[f"{e}.pano_encoder.norm.bias"], 1e-12)
+    return x, masks
+
+
+def forward_navigation(P, cfg: PlannerConfig, txt_embeds: Tensor, txt_masks: Tensor,
+                       gmap_step_ids: Tensor, gmap_img_fts: Tensor, gmap_pos_fts: Tensor,
+                       gmap_masks: Tensor, gmap_visited_masks: Tensor, gmap_pair_dists: Tensor):
+    """GlocalTextPathNavCMT.forward_navigation vilmodel_cmt.py:721-750
+    (gmap_vpids is ignored by the reference and omitted here)."""
+    g = "global_encoder"
+    dt = txt_embeds.dtype
+    x = (gmap_img_fts
+         + P[f"{g}.gmap_step_embeddings.weight"][gmap_step_ids]
+         + layer_norm(linear(gmap_pos_fts, P[f"{g}.gmap_pos_embeddings.0.weight"],
+                             P[f"{g}.gmap_pos_embeddings.0.bias"]),
+                      P[f"{g}.gmap_pos_embeddings.1.weight"], P[f"{g}.gmap_pos_embeddings.1.bias"],
+                      1e-12))
+    txt_m = extend_neg_masks(txt_masks, dt)
+    img_m = extend_neg_masks(gmap_masks, dt)
+    if cfg.graph_sprels:
+        sprels = (gmap_pair_dists * P[f"{g}.sprel_linear.weight"].reshape(())
+                  + P[f"{g}.sprel_linear.bias"].reshape(()))[:, None]        # :732-736
+        self_m = img_m + sprels                                               # :391-393
+    else:
+        self_m = img_m
+    for l in range(cfg.num_x_layers):
+        p = f"{g}.encoder.x_layers.{l}"
+        x = cross_attention_block(P, f"{p}.visual_attention", x, txt_embeds, txt_m, cfg)
+        x = bert_self_attention_block(P, f"{p}.visn_self_att", x, self_m, cfg)
+        x = bert_ffn_block(P, f"{p}.visn_inter", f"{p}.visn_output", x, cfg)
+    h = torch.relu(linear(x, P["global_sap_head.net.0.weight"], P["global_sap_head.net.0.bias"]))
+    h = layer_norm(h, P["global_sap_head.net.2.weight"], P["global_sap_head.net.2.bias"], 1e-12)
+    logits = linear(h, P["global_sap_head.net.4.weight"], P["global_sap_head.net.4.bias"]).squeeze(-1)
+    logits = logits.masked_fill(gmap_visited_masks, float("-inf"))            # :743
+    logits = logits.masked_fill(~gmap_masks, float("-inf"))                   # :744
+    return {"gmap_embeds": x, "global_logits": logits}
+
+
+def cross_entropy_sum(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
+    """F.cross_entropy(reduction='sum', ignore_index=-100) ss_trainer_ETP.py:892."""
+    keep = target != ignore_index
+    lse = torch.logsumexp(logits, dim=-1)
+    picked = logits.gather(1, target.clamp(min=0)[:, None]).squeeze(1)
+    return ((lse - picked) * keep.to(logits.dtype)).sum()
+
+
+# --------------------------------------------------------------------------
+# node assembly + one whole planner "step" (SURVEY.md §8d unit of work)
+# --------------------------------------------------------------------------
+def assemble_gmap_img_fts(pano_embeds: Tensor, pano_masks: Tensor, view_lens: Tensor, G: int) -> Tensor:
+    """Benchmark node assembly: node 0 = [stop] zeros
+    (ss_trainer_ETP.py:364-366); node 1 = masked mean of the panorama
+    (ss_trainer_ETP.py:838-839: sum(pano*mask)/sum(mask)); node g>=2 = the
+    embedding of view (g-2) mod view_len (ghost nodes with one candidate-view
+    occurrence each, graph_utils.py:224-234), so that gradients reach the pano
+    encoder from every node and G may exceed V (config 5)."""
+    B, V, H = pano_embeds.shape
+    m = pano_masks.to(pano_embeds.dtype)
+    avg = (pano_embeds * m[..., None]).sum(1) / m.sum(1, keepdim=True)
+    idx = (torch.arange(G - 2)[None, :] % view_lens[:, None])              # [B, G-2]
+    views = torch.gather(pano_embeds, 1, idx[..., None].expand(B, G - 2, H))
+    return torch.cat([torch.zeros(B, 1, H, dtype=pano_embeds.dtype), avg[:, None], views], 1)
+
+
+def planner_step(P, cfg: PlannerConfig, batch: Dict[str, Tensor], n_ghost: int = 4):
+    """forward_txt -> forward_panorama -> node assembly -> forward_navigation ->
+    CE(sum)/B, mirroring one rollout step of ss_trainer_ETP.py:801-892,:1055."""
+    txt = forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"])
+    pano, pmask = forward_panorama(P, cfg, batch["rgb_fts"], batch["dep_fts"], batch["loc_fts"],
+                                   batch["nav_types"], batch["view_lens"])
+    G = batch["gmap_step_ids"].shape[1]
+    gimg = assemble_gmap_img_fts(pano, pmask, batch["view_lens"], G)
+    outs = forward_navigation(P, cfg, txt, batch["txt_masks"], batch["gmap_step_ids"], gimg,
+                              batch["gmap_pos_fts"], batch["gmap_masks"],
+                              batch["gmap_visited_masks"], batch["gmap_pair_dists"])
+    B = batch["txt_ids"].shape[0]
+    loss = cross_entropy_sum(outs["global_logits"], batch["labels"]) / B
+    return {"txt_embeds": txt, "pano_embeds": pano, "pano_masks": pmask, "gmap_img_fts": gimg,
+            "gmap_embeds": outs["gmap_embeds"], "global_logits": outs["global_logits"], "loss": loss}
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic inputs
+# --------------------------------------------------------------------------
+def make_batch(cfg: PlannerConfig, B: int, L: int, V: int, G: int, seed: int = 1234,
+               ragged: bool = False, dtype=torch.float32, n_cand: int = 4) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    txt_ids = torch.randint(1000, cfg.vocab_size - 1, (B, L), generator=g)
+    if ragged:
+        tl = torch.randint(max(L // 2, 1), L + 1, (B,), generator=g); tl[0] = L
+        vl = torch.randint(max(V - 6, 1), V + 1, (B,), generator=g); vl[0] = V
+        gl = torch.randint(max(G // 2, 3), G + 1, (B,), generator=g); gl[0] = G
+    else:
+        tl = torch.full((B,), L); vl = torch.full((B,), V); gl = torch.full((B,), G)
+    txt_masks = gen_seq_masks(tl, L)
+    txt_ids = txt_ids * txt_masks          # pad id 0 (bert) -- ss_trainer_ETP.py:775-779
+    rgb = torch.randn(B, V, cfg.image_feat_size, generator=g)
+    dep = torch.randn(B, V, cfg.depth_feat_size, generator=g)
+    v = torch.arange(V)
+    heading = 2 * math.pi * (v % 12) / 12
+    elev = ((v // 12) % 3 - 1) * (math.pi / 6)
+    loc = torch.stack([heading.sin(), heading.cos(), elev.sin(), elev.cos()], -1)[None].repeat(B, 1, 1)
+    nav = torch.zeros(B, V, dtype=torch.long); nav[:, :n_cand] = 1
+    vmask = gen_seq_masks(vl, V)
+    rgb, dep, loc, nav = rgb * vmask[..., None], dep * vmask[..., None], loc * vmask[..., None], nav * vmask
+    step_ids = torch.zeros(B, G, dtype=torch.long); step_ids[:, 1] = 1
+    pos = torch.randn(B, G, cfg.angle_feat_size + 3, generator=g)
+    d = torch.rand(B, G, G, generator=g)
+    d = (d + d.transpose(1, 2)) * 0.5
+    d[:, 0, :] = 0; d[:, :, 0] = 0
+    d = d * (1 - torch.eye(G))[None]
+    gmask = gen_seq_masks(gl, G)
+    pos = pos * gmask[..., None]
+    d = d * gmask[:, :, None] * gmask[:, None, :]
+    visited = torch.zeros(B, G, dtype=torch.bool); visited[:, 1] = True
+    labels = torch.full((B,), 2, dtype=torch.long)
+    if B > 1 and ragged:
+        labels[-1] = -100                      # exercise ignore_index
+    return {"txt_ids": txt_ids, "txt_masks": txt_masks, "rgb_fts": rgb.to(dtype), "dep_fts": dep.to(dtype),
+            "loc_fts": loc.to(dtype), "nav_types": nav, "view_lens": vl, "gmap_step_ids": step_ids,
+            "gmap_pos_fts": pos.to(dtype), "gmap_masks": gmask, "gmap_visited_masks": visited,
+            "gmap_pair_dists": d.to(dtype), "labels": labels}
+
+
+def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4):
+    """Run planner_step with autograd; returns (outputs, {name: grad})."""
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    b = dict(batch)
+    b["rgb_fts"] = batch["rgb_fts"].detach().clone().requires_grad_(True)
+    outs = planner_step(Pg, cfg, b, n_ghost)
+    outs["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    grads["__input__.rgb_fts"] = b["rgb_fts"].grad
+    return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in outs.items()}, grads
