@@ -1,0 +1,158 @@
+"""ctypes binding of libetpnav_hip.so (the C ABI declared in include/etpnav_hip.h).
+
+The prototypes are parsed from the header itself so the Python side cannot drift from the C side.
+There is NO fallback: if the shared object is missing or a symbol cannot be resolved, importing a
+compute path raises.  (Build it with ``python -m etpnav_amd.build``.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "etpnav_hip.h")
+LIB_PATH = os.path.join(HERE, "libetpnav_hip.so")
+
+ETP_F32, ETP_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+
+
+class EtpError(RuntimeError):
+    pass
+
+
+# ---- structs (must mirror include/etpnav_hip.h) ------------------------------------------------
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
+                ("trans_a", ctypes.c_int32), ("trans_b", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("c_dtype", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("batch_inner", ctypes.c_int32),
+                ("sAo", ctypes.c_int64), ("sAi", ctypes.c_int64), ("sBo", ctypes.c_int64),
+                ("sBi", ctypes.c_int64), ("sCo", ctypes.c_int64), ("sCi", ctypes.c_int64),
+                ("ksplit", ctypes.c_int32), ("alpha", ctypes.c_float),
+                ("bias", ctypes.c_void_p), ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64),
+                ("Z", ctypes.c_void_p), ("ldz", ctypes.c_int64),
+                ("act", ctypes.c_int32), ("out_mode", ctypes.c_int32)]
+
+
+class AttnDesc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("Lq", ctypes.c_int32), ("Lk", ctypes.c_int32), ("ldS", ctypes.c_int32),
+                ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+                ("K", ctypes.c_void_p), ("ldk", ctypes.c_int64),
+                ("V", ctypes.c_void_p), ("ldv", ctypes.c_int64),
+                ("P", ctypes.c_void_p), ("ctx", ctypes.c_void_p), ("ldc", ctypes.c_int64),
+                ("keymask", ctypes.c_void_p), ("mask_mode", ctypes.c_int32),
+                ("dist", ctypes.c_void_p), ("sp_w", ctypes.c_void_p), ("sp_b", ctypes.c_void_p),
+                ("alpha", ctypes.c_float)]
+
+
+class AttnBwdDesc(ctypes.Structure):
+    _fields_ = [("f", AttnDesc), ("dctx", ctypes.c_void_p), ("ldd", ctypes.c_int64),
+                ("dP", ctypes.c_void_p),
+                ("dQ", ctypes.c_void_p), ("lddq", ctypes.c_int64),
+                ("dK", ctypes.c_void_p), ("lddk", ctypes.c_int64),
+                ("dV", ctypes.c_void_p), ("lddv", ctypes.c_int64),
+                ("d_sp_w", ctypes.c_void_p), ("d_sp_b", ctypes.c_void_p)]
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("hidden", ctypes.c_int32), ("heads", ctypes.c_int32), ("inter", ctypes.c_int32),
+                ("n_l", ctypes.c_int32), ("n_p", ctypes.c_int32), ("n_x", ctypes.c_int32),
+                ("vocab", ctypes.c_int32), ("max_pos", ctypes.c_int32), ("type_vocab", ctypes.c_int32),
+                ("img_feat", ctypes.c_int32), ("dep_feat", ctypes.c_int32), ("ang_feat", ctypes.c_int32),
+                ("max_steps", ctypes.c_int32), ("use_depth", ctypes.c_int32), ("use_sprels", ctypes.c_int32),
+                ("ln_eps", ctypes.c_float), ("dtype", ctypes.c_int32)]
+
+
+class ParamInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("ndim", ctypes.c_int32), ("shape", ctypes.c_int64 * 2),
+                ("offset", ctypes.c_int64)]
+
+
+# ---- header parsing --------------------------------------------------------------------------
+_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+            "etp_stream_t": ctypes.c_void_p}
+
+
+def _ctype_of(decl: str):
+    d = decl.strip()
+    if "*" in d:
+        if re.match(r"^(const\s+)?char\s*\*$", d.replace(" *", "*").replace("* ", "*")):
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    d = re.sub(r"\bconst\b", "", d).strip()
+    base = d.split()[0]
+    if base == "void":
+        return None
+    if base not in _SCALARS:
+        raise EtpError(f"cannot map C type {decl!r}")
+    return _SCALARS[base]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """-> {function name: (restype, [argtypes])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(etp_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                # strip the parameter name (last identifier), keep the type
+                a_type = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") else a
+                argtypes.append(_ctype_of(a_type if a_type else a))
+        protos[name] = (_ctype_of(ret), argtypes)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the shared object (once) and attach prototypes.  Raises if it is not built."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EtpError(f"{LIB_PATH} is missing: the HIP extension is not built "
+                       f"(run `python -m etpnav_amd.build`); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (res, args) in _protos.items():
+        fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def declared_symbols() -> List[str]:
+    return sorted(parse_header().keys())
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().etp_last_error()
+        raise EtpError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI needs contiguous tensors"
+    return t.data_ptr()

@@ -1,0 +1,61 @@
+"""Build libetpnav_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m etpnav_amd.build [--force]
+
+The shared object is git-ignored but travels with the gpurun snapshot; hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libetpnav_hip.so")
+SOURCES = ["gemm.hip", "norm.hip", "embed.hip", "planner.hip", "capi.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "etpnav_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def needs_build() -> bool:
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return _mtime(OUT) < max(_mtime(d) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and _mtime(obj) >= max(_mtime(srcp), hdr_t):
+            return obj
+        cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,218 @@
+// extern "C" surface of libetpnav_hip.so: per-operator entry points, hipGraph helpers, error state.
+#include <string.h>
+
+#include "kernels.h"
+
+namespace etp {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e > 0 ? (int)e : 999;
+}
+
+}  // namespace etp
+
+using namespace etp;
+
+struct etp_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+extern "C" {
+
+const char* etp_version(void) { return "etpnav_hip 0.1.0 (gfx950)"; }
+const char* etp_last_error(void) { return g_last_error.c_str(); }
+
+int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream) {
+  ETP_REQUIRE(d && d->A && d->B && d->C, "null descriptor/operand");
+  ETP_REQUIRE(d->act >= ETP_ACT_NONE && d->act <= ETP_ACT_RELU_BWD, "bad activation");
+  ETP_REQUIRE((d->act != ETP_ACT_GELU && d->act != ETP_ACT_GELU_BWD && d->act != ETP_ACT_RELU_BWD) || d->Z, "activation needs Z");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = d->A; g.B = d->B; g.C = d->C; g.M = d->M; g.N = d->N; g.K = d->K;
+  g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+  g.nb_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+  g.sAo = d->sAo; g.sAi = d->sAi; g.sBo = d->sBo; g.sBi = d->sBi; g.sCo = d->sCo; g.sCi = d->sCi;
+  g.ksplit = d->ksplit > 0 ? d->ksplit : 1;
+  g.alpha = d->alpha; g.bias = d->bias; g.R = d->R; g.ldr = d->ldr; g.Z = d->Z; g.ldz = d->ldz; g.act = d->act;
+  g.out_mode = d->out_mode;
+  return launch_gemm(d->dtype, d->c_dtype, d->trans_a, d->trans_b, g, d->batch > 0 ? d->batch : 1, (hipStream_t)stream);
+}
+
+int etp_colsum(int dtype, const void* dy, int64_t ld, float* db, int M, int N, etp_stream_t s) {
+  ETP_REQUIRE(dy && db, "null pointer");
+  return colsum(dtype, dy, ld, db, M, N, (hipStream_t)s);
+}
+int etp_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int H, float eps,
+               etp_stream_t s) {
+  ETP_REQUIRE(x && gamma && beta && y, "null pointer");
+  return ln_fwd(dtype, x, gamma, beta, y, stats, M, H, eps, (hipStream_t)s);
+}
+int etp_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+               float* dgamma, float* dbeta, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(dy && x && stats && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)), "null pointer");
+  return ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma, dbeta, M, H, (hipStream_t)s);
+}
+int etp_softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
+                    int heads, int Lq, int Lk, int ldS, int mask_mode, etp_stream_t s) {
+  ETP_REQUIRE(S, "null pointer");
+  return softmax_fwd(dtype, S, keymask, dist, sp_w, sp_b, B, heads, Lq, Lk, ldS, mask_mode, (hipStream_t)s);
+}
+int etp_softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int heads, int Lq,
+                    int Lk, int ldS, etp_stream_t s) {
+  ETP_REQUIRE(P && dP, "null pointer");
+  return softmax_bwd(dtype, P, dP, dist, d_sp_w, d_sp_b, B, heads, Lq, Lk, ldS, (hipStream_t)s);
+}
+
+static AttnBuf to_buf(const etp_attn_desc& f) {
+  AttnBuf a{f.Q, f.ldq, f.K, f.ldk, f.V, f.ldv, f.B, f.Lq, f.Lk, f.ldS, f.keymask, f.mask_mode, f.dist, f.sp_w, f.sp_b};
+  return a;
+}
+int etp_attn_fwd(const etp_attn_desc* d, etp_stream_t s) {
+  ETP_REQUIRE(d && d->Q && d->K && d->V && d->P && d->ctx, "null pointer");
+  ETP_REQUIRE(d->ldS >= d->Lk && d->ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");
+  return attn_fwd_impl(d->dtype, d->heads, to_buf(*d), d->P, d->ctx, d->ldc, d->alpha, (hipStream_t)s);
+}
+int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t s) {
+  ETP_REQUIRE(d && d->f.Q && d->f.K && d->f.V && d->f.P && d->dctx && d->dP && d->dQ && d->dK && d->dV, "null pointer");
+  ETP_REQUIRE(d->f.ldS >= d->f.Lk && d->f.ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");
+  return attn_bwd_impl(d->f.dtype, d->f.heads, to_buf(d->f), d->f.P, d->dctx, d->ldd, d->dP, d->dQ, d->lddq, d->dK, d->lddk,
+                       d->dV, d->lddv, d->f.alpha, d->d_sp_w, d->d_sp_b, (hipStream_t)s);
+}
+
+int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                       const float* beta, void* y, float* stats, int B, int L, int H, float eps, etp_stream_t s) {
+  ETP_REQUIRE(ids && word && pos && type0 && gamma && beta && y && stats, "null pointer");
+  return text_embed_fwd(dtype, ids, word, pos, type0, gamma, beta, y, stats, B, L, H, eps, (hipStream_t)s);
+}
+int etp_text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma,
+                       float* dbeta, int B, int L, int H, etp_stream_t s) {
+  ETP_REQUIRE(dy && ids && word && pos && type0 && gamma && stats && dword && dpos && dtype0 && dgamma && dbeta, "null pointer");
+  return text_embed_bwd(dtype, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, B, L, H, (hipStream_t)s);
+}
+
+static PanoEmbedParams to_params(const float* const* p) {
+  PanoEmbedParams q{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11]};
+  return q;
+}
+int etp_pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const float* const* params,
+                       void* y, float* stats, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(a && loc && nav && params && y && stats, "null pointer");
+  return pano_embed_fwd(dtype, a, d, loc, nav, to_params(params), y, stats, M, H, (hipStream_t)s);
+}
+int etp_pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                       const float* stats, const float* const* params, float* const* grads, void* da, void* dd, int M, int H,
+                       etp_stream_t s) {
+  ETP_REQUIRE(dy && a && loc && nav && stats && params && grads && da && (d == nullptr || dd != nullptr), "null pointer");
+  PanoEmbedGrads g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[6], grads[7], grads[8], grads[9], grads[10],
+                   grads[11]};
+  return pano_embed_bwd(dtype, dy, a, d, loc, nav, stats, to_params(params), g, da, dd, M, H, (hipStream_t)s);
+}
+int etp_gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
+                       int H, int pos_dim, etp_stream_t s) {
+  ETP_REQUIRE(img && step_ids && pos && step_emb && w_pos && b_pos && gamma && beta && x && stats, "null pointer");
+  return gmap_embed_fwd(dtype, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, stats, M, H, pos_dim, (hipStream_t)s);
+}
+int etp_gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+                       const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
+                       float* dbeta, int M, int H, int pos_dim, etp_stream_t s) {
+  ETP_REQUIRE(dx && step_ids && pos && w_pos && b_pos && gamma && stats && d_step_emb && d_w_pos && d_b_pos && dgamma && dbeta,
+              "null pointer");
+  return gmap_embed_bwd(dtype, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M, H,
+                        pos_dim, (hipStream_t)s);
+}
+int etp_sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
+                     const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(r && gamma && beta && w2 && b2 && logits && stats, "null pointer");
+  return sap_tail_fwd(dtype, r, gamma, beta, w2, b2, visited, valid, logits, stats, M, H, (hipStream_t)s);
+}
+int etp_sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
+                     const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
+                     float* dw2, float* db2, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(dlogits && r && gamma && beta && w2 && stats && dz && dgamma && dbeta && dw2 && db2, "null pointer");
+  return sap_tail_bwd(dtype, dlogits, r, gamma, beta, w2, stats, visited, valid, dz, dgamma, dbeta, dw2, db2, M, H, (hipStream_t)s);
+}
+int etp_sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale,
+               int64_t ignore_index, etp_stream_t s) {
+  ETP_REQUIRE(logits && labels && loss, "null pointer");
+  return sap_ce(logits, labels, loss, dlogits, B, G, scale, (long)ignore_index, (hipStream_t)s);
+}
+int etp_gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
+                   int accumulate, etp_stream_t s) {
+  ETP_REQUIRE(src && ptr && idx && w && out, "null pointer");
+  return gather_sum(dtype, src, ptr, idx, w, out, N, H, accumulate, (hipStream_t)s);
+}
+int etp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, etp_stream_t s) {
+  ETP_REQUIRE(src && dst && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "null / unaligned pointer");
+  return cast_f32_to_bf16(src, dst, n, (hipStream_t)s);
+}
+int etp_cast_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, etp_stream_t s) {
+  ETP_REQUIRE(src && dst, "null pointer");
+  return cast_bf16_to_f32(src, dst, n, scale, (hipStream_t)s);
+}
+int etp_scale_f32(float* p, int64_t n, float scale, etp_stream_t s) {
+  ETP_REQUIRE(p, "null pointer");
+  return scale_f32(p, n, scale, (hipStream_t)s);
+}
+
+// ---- streams / graphs -----------------------------------------------------------------
+int etp_stream_create(etp_stream_t* out) {
+  ETP_REQUIRE(out, "null pointer");
+  hipStream_t s;
+  ETP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = (etp_stream_t)s;
+  return ETP_OK;
+}
+int etp_stream_destroy(etp_stream_t s) { ETP_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return ETP_OK; }
+int etp_stream_sync(etp_stream_t s) { ETP_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return ETP_OK; }
+int etp_graph_begin(etp_stream_t s) {
+  ETP_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+  return ETP_OK;
+}
+int etp_graph_end(etp_stream_t s, etp_graph** out) {
+  ETP_REQUIRE(out, "null pointer");
+  hipGraph_t g;
+  ETP_CHECK_HIP(hipStreamEndCapture((hipStream_t)s, &g));
+  hipGraphExec_t e;
+  ETP_CHECK_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+  *out = new etp_graph{g, e};
+  return ETP_OK;
+}
+int etp_graph_launch(etp_graph* g, etp_stream_t s) {
+  ETP_REQUIRE(g, "null graph");
+  ETP_CHECK_HIP(hipGraphLaunch(g->exec, (hipStream_t)s));
+  return ETP_OK;
+}
+int etp_graph_destroy(etp_graph* g) {
+  if (!g) return ETP_OK;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return ETP_OK;
+}
+int etp_memset_async(void* p, int value, int64_t bytes, etp_stream_t s) {
+  ETP_REQUIRE(p && bytes >= 0, "bad arguments");
+  ETP_CHECK_HIP(hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)s));
+  return ETP_OK;
+}
+int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out) {
+  ETP_REQUIRE(g && ms_out && iters > 0, "bad arguments");
+  hipEvent_t a, b;
+  ETP_CHECK_HIP(hipEventCreate(&a));
+  ETP_CHECK_HIP(hipEventCreate(&b));
+  ETP_CHECK_HIP(hipEventRecord(a, (hipStream_t)s));
+  for (int i = 0; i < iters; ++i) ETP_CHECK_HIP(hipGraphLaunch(g->exec, (hipStream_t)s));
+  ETP_CHECK_HIP(hipEventRecord(b, (hipStream_t)s));
+  ETP_CHECK_HIP(hipEventSynchronize(b));
+  ETP_CHECK_HIP(hipEventElapsedTime(ms_out, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return ETP_OK;
+}
+
+}  // extern "C"

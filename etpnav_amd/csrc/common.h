@@ -1,0 +1,113 @@
+// Shared device/host helpers for the ETPNav planner kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/etpnav_hip.h"
+
+namespace etp {
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-to-nearest-even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4 consecutive elements <-> float[4] (16 B for f32, 8 B for bf16)
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// ---- host side ----
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int check_hip(hipError_t e, const char* what);
+
+#define ETP_CHECK_HIP(expr)                                   \
+  do {                                                        \
+    int _rc = ::etp::check_hip((expr), #expr);                \
+    if (_rc) return _rc;                                      \
+  } while (0)
+#define ETP_CHECK_LAUNCH(name) ETP_CHECK_HIP(hipGetLastError())
+#define ETP_REQUIRE(cond, msg)                                \
+  do {                                                        \
+    if (!(cond)) return ::etp::fail(ETP_ERR_INVALID, std::string(__func__) + ": " + (msg)); \
+  } while (0)
+#define ETP_TRY(expr)                                         \
+  do {                                                        \
+    int _rc = (expr);                                         \
+    if (_rc) return _rc;                                      \
+  } while (0)
+
+inline size_t dtype_size(int dt) { return dt == ETP_BF16 ? 2 : 4; }
+inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// ---- internal GEMM interface (gemm.hip) ----
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int nb_inner;                       // batch z -> (zo = z / nb_inner, zi = z % nb_inner)
+  long sAo, sAi, sBo, sBi, sCo, sCi;  // batch strides (elements)
+  int ksplit;                         // split-K (needs out_mode 2)
+  float alpha;
+  const float* bias;                  // [N] fp32 or null
+  const void* R; long ldr;            // residual / grad-add operand (T) or null (non-batched only)
+  void* Z; long ldz;                  // aux tensor (T): act 1 writes, act 3/4 reads
+  int act;                            // ETP_ACT_*
+  int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
+};
+int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
+
+}  // namespace etp

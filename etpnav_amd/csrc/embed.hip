@@ -1,0 +1,773 @@
+// Fused embedding / head / loss / gather kernels of the ETPNav planner (gfx950).
+//
+// All of these are HBM-bound row kernels with hidden size H = NCH*256 (768 on this path): one 64-lane
+// wavefront owns one row, each lane owns NCH groups of 4 consecutive columns (8/16-byte vector accesses,
+// 512 B / 1 KiB contiguous per wave instruction), row statistics are fp32 wave-shuffle reductions.
+// Parameter gradients that reduce over rows are accumulated in LDS (ds_add_f32) per block and flushed with
+// one global atomic per column per block.
+//
+// Reference sites are cited at each kernel.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace etp {
+
+template <int NCH> struct Row {  // per-lane slice of one H-wide row
+  float v[NCH][4];
+};
+
+template <int NCH> __device__ __forceinline__ float row_sum(const Row<NCH>& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += r.v[c][0] + r.v[c][1] + r.v[c][2] + r.v[c][3];
+  return wave_sum(s);
+}
+template <int NCH> __device__ __forceinline__ float row_dot(const Row<NCH>& a, const Row<NCH>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += a.v[c][e] * b.v[c][e];
+  return wave_sum(s);
+}
+template <int NCH, typename T> __device__ __forceinline__ void row_load(Row<NCH>& r, const T* p, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) load4(p + c * 256 + lane * 4, r.v[c]);
+}
+template <int NCH, typename T> __device__ __forceinline__ void row_store(const Row<NCH>& r, T* p, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) store4(p + c * 256 + lane * 4, r.v[c]);
+}
+template <int NCH> __device__ __forceinline__ void row_add(Row<NCH>& a, const Row<NCH>& b) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.v[c][e] += b.v[c][e];
+}
+// in place: x -> xhat = (x-mean)*rstd ; returns mean/rstd (two-pass variance, matches torch.nn.LayerNorm)
+template <int NCH> __device__ __forceinline__ void row_normalize(Row<NCH>& x, float eps, float& mean, float& rstd) {
+  constexpr float invH = 1.0f / (NCH * 256);
+  mean = row_sum<NCH>(x) * invH;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x.v[c][e] -= mean; q += x.v[c][e] * x.v[c][e]; }
+  rstd = rsqrtf(wave_sum(q) * invH + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x.v[c][e] *= rstd;
+}
+template <int NCH> __device__ __forceinline__ void row_affine(Row<NCH>& y, const Row<NCH>& xhat, const float* gamma,
+                                                              const float* beta, int lane) {
+  Row<NCH> g, b;
+  row_load<NCH>(g, gamma, lane);
+  row_load<NCH>(b, beta, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y.v[c][e] = xhat.v[c][e] * g.v[c][e] + b.v[c][e];
+}
+// LayerNorm backward for one row: dy (in) -> dx (out, in place); xhat given
+template <int NCH> __device__ __forceinline__ void row_ln_bwd(Row<NCH>& d, const Row<NCH>& xhat, const float* gamma,
+                                                              float rstd, int lane) {
+  constexpr float invH = 1.0f / (NCH * 256);
+  Row<NCH> g;
+  row_load<NCH>(g, gamma, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.v[c][e] *= g.v[c][e];
+  const float c1 = row_sum<NCH>(d) * invH;
+  const float c2 = row_dot<NCH>(d, xhat) * invH;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.v[c][e] = rstd * (d.v[c][e] - c1 - xhat.v[c][e] * c2);
+}
+// LDS accumulate: acc[col] += a*b (used for dgamma = dy*xhat etc.)
+template <int NCH> __device__ __forceinline__ void lds_acc_mul(float* acc, const Row<NCH>& a, const Row<NCH>& b, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(acc + c * 256 + lane * 4 + e, a.v[c][e] * b.v[c][e]);
+}
+template <int NCH> __device__ __forceinline__ void lds_acc(float* acc, const Row<NCH>& a, float s, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(acc + c * 256 + lane * 4 + e, a.v[c][e] * s);
+}
+template <int NCH> __device__ __forceinline__ void global_acc(float* dst, const Row<NCH>& a, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + c * 256 + lane * 4 + e, a.v[c][e]);
+}
+__device__ __forceinline__ void lds_zero(float* p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
+  __syncthreads();
+}
+__device__ __forceinline__ void lds_flush(float* dst, const float* src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(dst + i, src[i]);
+}
+
+// --------------------------------------------------------------------------------------
+// Text embedding: y = LN(word[id] + pos[l] + type[0])           BertEmbeddings.forward vilmodel_cmt.py:62-77
+// --------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                             const float* __restrict__ pos, const float* __restrict__ type0,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ y, float* __restrict__ stats, int M, int L, float eps) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const long id = ids[row];
+    const int l = row % L;
+    Row<NCH> x, t;
+    row_load<NCH>(x, word + id * H, lane);
+    row_load<NCH>(t, pos + (long)l * H, lane);
+    row_add<NCH>(x, t);
+    row_load<NCH>(t, type0, lane);
+    row_add<NCH>(x, t);
+    float mean, rstd;
+    row_normalize<NCH>(x, eps, mean, rstd);
+    row_affine<NCH>(t, x, gamma, beta, lane);
+    row_store<NCH>(t, y + (long)row * H, lane);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+// backward: scatter-add into word rows (padding_idx 0 gets none: vilmodel_cmt.py:53), pos rows, type row 0
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                             const float* __restrict__ word, const float* __restrict__ pos,
+                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, float* __restrict__ dword,
+                                                             float* __restrict__ dpos, float* __restrict__ dtype0,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int L) {
+  constexpr int H = NCH * 256;
+  __shared__ float acc[3 * H];  // dgamma, dbeta, dtype0
+  lds_zero(acc, 3 * H);
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const long id = ids[row];
+    const int l = row % L;
+    Row<NCH> x, t, d;
+    row_load<NCH>(x, word + id * H, lane);
+    row_load<NCH>(t, pos + (long)l * H, lane);
+    row_add<NCH>(x, t);
+    row_load<NCH>(t, type0, lane);
+    row_add<NCH>(x, t);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[c][e] = (x.v[c][e] - mean) * rstd;
+    row_load<NCH>(d, dy + (long)row * H, lane);
+    lds_acc_mul<NCH>(acc, d, x, lane);
+    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
+    lds_acc<NCH>(acc + 2 * H, d, 1.0f, lane);
+    if (id != 0) global_acc<NCH>(dword + id * H, d, lane);
+    global_acc<NCH>(dpos + (long)l * H, d, lane);
+  }
+  __syncthreads();
+  lds_flush(dgamma, acc, H);
+  lds_flush(dbeta, acc + H, H);
+  lds_flush(dtype0, acc + 2 * H, H);
+}
+
+// --------------------------------------------------------------------------------------
+// Panorama view-embedding fuse                       forward_panorama vilmodel_cmt.py:695-711
+//   y = LN( LN_i(a) + LN_d(d) + LN_l(loc.Wl^T + bl) + nav_emb[nav] + type_emb[1] )      all eps 1e-12
+//   a = rgb.Wi^T + bi and d = dep.Wd^T + bd come from the MFMA GEMM; the K=4 angle projection is done here.
+//   stats[row] = {mean,rstd} x {a, d, loc-proj, sum}
+// --------------------------------------------------------------------------------------
+template <int NCH> __device__ __forceinline__ void loc_project(Row<NCH>& t, const float* loc4, const float* w_loc,
+                                                               const float* bias_loc, int lane) {
+  const float l0 = loc4[0], l1 = loc4[1], l2 = loc4[2], l3 = loc4[3];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = c * 256 + lane * 4 + e;
+      const float4 w = *reinterpret_cast<const float4*>(w_loc + col * 4);
+      t.v[c][e] = bias_loc[col] + l0 * w.x + l1 * w.y + l2 * w.z + l3 * w.w;
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict__ a, const T* __restrict__ d,
+                                                             const float* __restrict__ loc, const int64_t* __restrict__ nav,
+                                                             PanoEmbedParams p, T* __restrict__ y, float* __restrict__ stats,
+                                                             int M) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    float* st = stats + (long)row * 8;
+    Row<NCH> e, x, t;
+    float mean, rstd;
+    row_load<NCH>(x, a + (long)row * H, lane);
+    row_normalize<NCH>(x, 1e-12f, mean, rstd);
+    row_affine<NCH>(e, x, p.g_img, p.b_img, lane);
+    if (lane == 0) { st[0] = mean; st[1] = rstd; }
+    if (d != nullptr) {
+      row_load<NCH>(x, d + (long)row * H, lane);
+      row_normalize<NCH>(x, 1e-12f, mean, rstd);
+      row_affine<NCH>(t, x, p.g_dep, p.b_dep, lane);
+      row_add<NCH>(e, t);
+      if (lane == 0) { st[2] = mean; st[3] = rstd; }
+    }
+    loc_project<NCH>(x, loc + (long)row * 4, p.w_loc, p.bias_loc, lane);
+    row_normalize<NCH>(x, 1e-12f, mean, rstd);
+    row_affine<NCH>(t, x, p.g_loc, p.b_loc, lane);
+    row_add<NCH>(e, t);
+    if (lane == 0) { st[4] = mean; st[5] = rstd; }
+    row_load<NCH>(t, p.nav_emb + nav[row] * H, lane);
+    row_add<NCH>(e, t);
+    row_load<NCH>(t, p.type1, lane);
+    row_add<NCH>(e, t);
+    row_normalize<NCH>(e, 1e-12f, mean, rstd);
+    row_affine<NCH>(t, e, p.g_out, p.b_out, lane);
+    row_store<NCH>(t, y + (long)row * H, lane);
+    if (lane == 0) { st[6] = mean; st[7] = rstd; }
+  }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a,
+                                                             const T* __restrict__ d, const float* __restrict__ loc,
+                                                             const int64_t* __restrict__ nav, const float* __restrict__ stats,
+                                                             PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
+                                                             T* __restrict__ dd, int M) {
+  constexpr int H = NCH * 256;
+  // LDS accumulators: g/b x {img,dep,loc,out} (8H) + nav_emb (2H) + type1 (H) + bias_loc (H) + w_loc (4H) = 16H
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  lds_zero(acc, 16 * H);
+  float *A_gi = acc, *A_bi = acc + H, *A_gd = acc + 2 * H, *A_bd = acc + 3 * H, *A_gl = acc + 4 * H, *A_bl = acc + 5 * H,
+        *A_go = acc + 6 * H, *A_bo = acc + 7 * H, *A_nav = acc + 8 * H, *A_ty = acc + 10 * H, *A_lb = acc + 11 * H,
+        *A_lw = acc + 12 * H;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float* st = stats + (long)row * 8;
+    Row<NCH> e, x, t, de;
+    // rebuild e = sum of the branches, normalised (outer xhat)
+    row_load<NCH>(x, a + (long)row * H, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
+    row_affine<NCH>(e, x, p.g_img, p.b_img, lane);
+    if (d != nullptr) {
+      row_load<NCH>(x, d + (long)row * H, lane);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
+      row_affine<NCH>(t, x, p.g_dep, p.b_dep, lane);
+      row_add<NCH>(e, t);
+    }
+    loc_project<NCH>(x, loc + (long)row * 4, p.w_loc, p.bias_loc, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[4]) * st[5];
+    row_affine<NCH>(t, x, p.g_loc, p.b_loc, lane);
+    row_add<NCH>(e, t);
+    const long nv = nav[row];
+    row_load<NCH>(t, p.nav_emb + nv * H, lane);
+    row_add<NCH>(e, t);
+    row_load<NCH>(t, p.type1, lane);
+    row_add<NCH>(e, t);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e.v[c][k] = (e.v[c][k] - st[6]) * st[7];
+    // outer LN backward
+    row_load<NCH>(de, dy + (long)row * H, lane);
+    lds_acc_mul<NCH>(A_go, de, e, lane);
+    lds_acc<NCH>(A_bo, de, 1.0f, lane);
+    row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);   // de = grad wrt the branch sum
+    lds_acc<NCH>(A_nav + nv * H, de, 1.0f, lane);
+    lds_acc<NCH>(A_ty, de, 1.0f, lane);
+    // loc branch (x still holds its xhat)
+    t = de;
+    lds_acc_mul<NCH>(A_gl, t, x, lane);
+    lds_acc<NCH>(A_bl, t, 1.0f, lane);
+    row_ln_bwd<NCH>(t, x, p.g_loc, st[5], lane);
+    lds_acc<NCH>(A_lb, t, 1.0f, lane);
+    {
+      const float* l4 = loc + (long)row * 4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = c * 256 + lane * 4 + k;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(A_lw + col * 4 + j, t.v[c][k] * l4[j]);
+        }
+    }
+    // img branch
+    row_load<NCH>(x, a + (long)row * H, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
+    t = de;
+    lds_acc_mul<NCH>(A_gi, t, x, lane);
+    lds_acc<NCH>(A_bi, t, 1.0f, lane);
+    row_ln_bwd<NCH>(t, x, p.g_img, st[1], lane);
+    row_store<NCH>(t, da + (long)row * H, lane);
+    if (d != nullptr) {
+      row_load<NCH>(x, d + (long)row * H, lane);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
+      t = de;
+      lds_acc_mul<NCH>(A_gd, t, x, lane);
+      lds_acc<NCH>(A_bd, t, 1.0f, lane);
+      row_ln_bwd<NCH>(t, x, p.g_dep, st[3], lane);
+      row_store<NCH>(t, dd + (long)row * H, lane);
+    }
+  }
+  __syncthreads();
+  lds_flush(g.g_img, A_gi, H); lds_flush(g.b_img, A_bi, H);
+  if (d != nullptr) { lds_flush(g.g_dep, A_gd, H); lds_flush(g.b_dep, A_bd, H); }
+  lds_flush(g.g_loc, A_gl, H); lds_flush(g.b_loc, A_bl, H);
+  lds_flush(g.g_out, A_go, H); lds_flush(g.b_out, A_bo, H);
+  lds_flush(g.nav_emb, A_nav, 2 * H);
+  lds_flush(g.type1, A_ty, H);
+  lds_flush(g.bias_loc, A_lb, H);
+  lds_flush(g.w_loc, A_lw, 4 * H);
+}
+
+// --------------------------------------------------------------------------------------
+// Graph-node embedding: x = img + step_emb[step] + LN(pos.Wp^T + bp)      forward_navigation vilmodel_cmt.py:728-730
+// --------------------------------------------------------------------------------------
+template <int NCH, int PK> __device__ __forceinline__ void pos_project(Row<NCH>& t, const float* pos, const float* w,
+                                                                       const float* bias, int lane) {
+  float pv[PK];
+#pragma unroll
+  for (int j = 0; j < PK; ++j) pv[j] = pos[j];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = c * 256 + lane * 4 + e;
+      float s = bias[col];
+#pragma unroll
+      for (int j = 0; j < PK; ++j) s += pv[j] * w[col * PK + j];
+      t.v[c][e] = s;
+    }
+}
+
+template <typename T, int NCH, int PK>
+__global__ __launch_bounds__(256) void gmap_embed_fwd_kernel(const T* __restrict__ img, const int64_t* __restrict__ step_ids,
+                                                             const float* __restrict__ pos, const float* __restrict__ step_emb,
+                                                             const float* __restrict__ w_pos, const float* __restrict__ b_pos,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ x, float* __restrict__ stats, int M) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    Row<NCH> t, o, u;
+    pos_project<NCH, PK>(t, pos + (long)row * PK, w_pos, b_pos, lane);
+    float mean, rstd;
+    row_normalize<NCH>(t, 1e-12f, mean, rstd);
+    row_affine<NCH>(o, t, gamma, beta, lane);
+    row_load<NCH>(u, step_emb + step_ids[row] * H, lane);
+    row_add<NCH>(o, u);
+    row_load<NCH>(u, img + (long)row * H, lane);
+    row_add<NCH>(o, u);
+    row_store<NCH>(o, x + (long)row * H, lane);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+template <typename T, int NCH, int PK>
+__global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ step_ids,
+                                                             const float* __restrict__ pos, const float* __restrict__ w_pos,
+                                                             const float* __restrict__ b_pos, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, float* __restrict__ d_step_emb,
+                                                             float* __restrict__ d_w_pos, float* __restrict__ d_b_pos,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+  constexpr int H = NCH * 256;
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // dgamma, dbeta, d_b_pos, d_w_pos[PK]
+  lds_zero(acc, (3 + PK) * H);
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    Row<NCH> t, d;
+    pos_project<NCH, PK>(t, pos + (long)row * PK, w_pos, b_pos, lane);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t.v[c][e] = (t.v[c][e] - mean) * rstd;
+    row_load<NCH>(d, dx + (long)row * H, lane);
+    global_acc<NCH>(d_step_emb + step_ids[row] * H, d, lane);
+    lds_acc_mul<NCH>(acc, d, t, lane);
+    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    row_ln_bwd<NCH>(d, t, gamma, rstd, lane);
+    lds_acc<NCH>(acc + 2 * H, d, 1.0f, lane);
+    const float* pr = pos + (long)row * PK;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = c * 256 + lane * 4 + e;
+#pragma unroll
+        for (int j = 0; j < PK; ++j) atomicAdd(acc + 3 * H + col * PK + j, d.v[c][e] * pr[j]);
+      }
+  }
+  __syncthreads();
+  lds_flush(dgamma, acc, H);
+  lds_flush(dbeta, acc + H, H);
+  lds_flush(d_b_pos, acc + 2 * H, H);
+  lds_flush(d_w_pos, acc + 3 * H, PK * H);
+}
+
+// --------------------------------------------------------------------------------------
+// SAP head tail: logit = LN(r).w2 + b2, -inf where visited or padded     NextActionPrediction vilmodel_cmt.py:651-661,
+//   r = relu(x.W1^T + b1) comes from the MFMA GEMM (ReLU epilogue).                                    :742-744
+// --------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void sap_tail_fwd_kernel(const T* __restrict__ r, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const uint8_t* __restrict__ visited,
+                                                           const uint8_t* __restrict__ valid, float* __restrict__ logits,
+                                                           float* __restrict__ stats, int M) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    Row<NCH> x, n, w;
+    row_load<NCH>(x, r + (long)row * H, lane);
+    float mean, rstd;
+    row_normalize<NCH>(x, 1e-12f, mean, rstd);
+    row_affine<NCH>(n, x, gamma, beta, lane);
+    row_load<NCH>(w, w2, lane);
+    const float v = row_dot<NCH>(n, w) + b2[0];
+    if (lane == 0) {
+      const bool masked = (visited && visited[row]) || (valid && !valid[row]);
+      logits[row] = masked ? -INFINITY : v;
+      stats[2 * row] = mean; stats[2 * row + 1] = rstd;
+    }
+  }
+}
+
+// dz (written over the ReLU mask) = LNbwd(dlogit*w2) * (r > 0)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restrict__ dlogits, const T* __restrict__ r,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ w2, const float* __restrict__ stats,
+                                                           const uint8_t* __restrict__ visited, const uint8_t* __restrict__ valid,
+                                                           T* __restrict__ dz, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dw2,
+                                                           float* __restrict__ db2, int M) {
+  constexpr int H = NCH * 256;
+  __shared__ float acc[3 * H + 4];
+  lds_zero(acc, 3 * H + 4);
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const bool masked = (visited && visited[row]) || (valid && !valid[row]);
+    const float dl = masked ? 0.f : dlogits[row];
+    Row<NCH> x, rr, n, d;
+    row_load<NCH>(rr, r + (long)row * H, lane);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[c][e] = (rr.v[c][e] - mean) * rstd;
+    row_affine<NCH>(n, x, gamma, beta, lane);
+    lds_acc<NCH>(acc + 2 * H, n, dl, lane);          // dw2 += dl * n
+    if (lane == 0) atomicAdd(acc + 3 * H, dl);       // db2
+    row_load<NCH>(d, w2, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d.v[c][e] *= dl;
+    lds_acc_mul<NCH>(acc, d, x, lane);
+    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d.v[c][e] = rr.v[c][e] > 0.f ? d.v[c][e] : 0.f;
+    row_store<NCH>(d, dz + (long)row * H, lane);
+  }
+  __syncthreads();
+  lds_flush(dgamma, acc, H);
+  lds_flush(dbeta, acc + H, H);
+  lds_flush(dw2, acc + 2 * H, H);
+  if (threadIdx.x == 0) atomicAdd(db2, acc[3 * H]);
+}
+
+// --------------------------------------------------------------------------------------
+// Cross entropy (sum, ignore_index) + its gradient        F.cross_entropy ss_trainer_ETP.py:892
+//   loss += scale * sum_b [lse(logits_b) - logits_b[y_b]],  dlogits = scale * (softmax - onehot)
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sap_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ loss, float* __restrict__ dlogits, int B, int G,
+                                                     float scale, long ignore_index) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += gridDim.x * 4) {
+    const float* s = logits + (long)row * G;
+    const long y = labels[row];
+    const bool keep = (y != ignore_index);
+    float mx = -INFINITY;
+    for (int k = lane; k < G; k += 64) mx = fmaxf(mx, s[k]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < G; k += 64) sum += expf(s[k] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    if (dlogits != nullptr)
+      for (int k = lane; k < G; k += 64) {
+        float gk = 0.f;
+        if (keep) gk = scale * (expf(s[k] - lse) - (k == y ? 1.f : 0.f));
+        dlogits[(long)row * G + k] = gk;
+      }
+    if (lane == 0 && keep) atomicAdd(loss, scale * (lse - s[y]));
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// Weighted gather-sum (node aggregation and its transpose for backward):
+//   out[n,:] (+)= sum_{j in [ptr[n],ptr[n+1])} w[j] * src[idx[j],:]
+// covers the masked panorama mean (ss_trainer_ETP.py:838-839), ghost-node means (graph_utils.py:272-276) and
+// pretrain _aggregate_gmap_features (pretrain_src/.../vilmodel.py:585-619).
+// --------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void gather_sum_kernel(const T* __restrict__ src, const int32_t* __restrict__ ptr,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ w,
+                                                         T* __restrict__ out, int N, int accumulate) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
+    Row<NCH> o, t;
+    if (accumulate) row_load<NCH>(o, out + (long)n * H, lane);
+    else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[c][e] = 0.f;
+    }
+    for (int j = ptr[n]; j < ptr[n + 1]; ++j) {
+      row_load<NCH>(t, src + (long)idx[j] * H, lane);
+      const float wj = w[j];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[c][e] += wj * t.v[c][e];
+    }
+    row_store<NCH>(o, out + (long)n * H, lane);
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// Column sum (bias gradients): db[n] += sum_m dY[m,n]
+// --------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long ld, float* __restrict__ db, int M, int N,
+                                                     int rows_per_block) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < N)
+    for (int r = r0 + wave; r < r1; r += 4) {
+      float v[4];
+      load4(dy + (long)r * ld + col, v);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = a[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) atomicAdd(db + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// --------------------------------------------------------------------------------------
+// dtype conversion (fp32 master weights / inputs -> bf16 operands) and fp32 axpy-free helpers
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+      uint4 o;
+      o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+      o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+      o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+      o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+      *reinterpret_cast<uint4*>(dst + i) = o;
+    } else {
+      for (long j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n,
+                                                            float scale) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = bf16_to_f32(src[i]) * scale;
+}
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, long n, float scale) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] *= scale;
+}
+
+// ---- host launchers -------------------------------------------------------------------
+#define ETP_DISPATCH_H(H, CALL)                                                         \
+  switch ((H) / 256) {                                                                  \
+    case 1: { constexpr int NCH = 1; CALL; } break;                                     \
+    case 2: { constexpr int NCH = 2; CALL; } break;                                     \
+    case 3: { constexpr int NCH = 3; CALL; } break;                                     \
+    case 4: { constexpr int NCH = 4; CALL; } break;                                     \
+    default: return fail(ETP_ERR_INVALID, "hidden size must be 256, 512, 768 or 1024"); \
+  }
+
+static inline int row_grid(int M, int cap) { return (int)std::min<long>(((long)M + 3) / 4, cap); }
+
+int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                   const float* beta, void* y, float* stats, int B, int L, int H, float eps, hipStream_t st) {
+  ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
+  const int M = B * L, grid = row_grid(M, 4096);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, (bf16_t*)y, stats, M, L, eps)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, (float*)y, stats, M, L, eps)); }
+  ETP_CHECK_LAUNCH("text_embed_fwd");
+  return ETP_OK;
+}
+
+int text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                   const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                   int B, int L, int H, hipStream_t st) {
+  ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
+  const int M = B * L, grid = row_grid(M, 128);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L)); }
+  ETP_CHECK_LAUNCH("text_embed_bwd");
+  return ETP_OK;
+}
+
+int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
+                   void* y, float* stats, int M, int H, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
+  const int grid = row_grid(M, 4096);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, (bf16_t*)y, stats, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, (float*)y, stats, M)); }
+  ETP_CHECK_LAUNCH("pano_embed_fwd");
+  return ETP_OK;
+}
+
+int pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                   const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
+                   hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
+  const int grid = row_grid(M, 64);
+  const size_t smem = 16 * (size_t)H * sizeof(float);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, (const float*)dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M)); }
+  ETP_CHECK_LAUNCH("pano_embed_bwd");
+  return ETP_OK;
+}
+
+int gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
+                   int H, int PK, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
+  const int grid = row_grid(M, 4096);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), 0, st, (const bf16_t*)img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, (bf16_t*)x, stats, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), 0, st, (const float*)img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, (float*)x, stats, M)); }
+  ETP_CHECK_LAUNCH("gmap_embed_fwd");
+  return ETP_OK;
+}
+
+int gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+                   const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
+                   float* dbeta, int M, int H, int PK, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
+  const int grid = row_grid(M, 64);
+  const size_t smem = (3 + 7) * (size_t)H * sizeof(float);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, (const float*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
+  ETP_CHECK_LAUNCH("gmap_embed_bwd");
+  return ETP_OK;
+}
+
+int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
+                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
+  const int grid = row_grid(M, 4096);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M)); }
+  ETP_CHECK_LAUNCH("sap_tail_fwd");
+  return ETP_OK;
+}
+
+int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
+                 const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
+                 float* dw2, float* db2, int M, int H, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
+  const int grid = row_grid(M, 64);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M)); }
+  ETP_CHECK_LAUNCH("sap_tail_bwd");
+  return ETP_OK;
+}
+
+int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale, long ignore_index,
+           hipStream_t st) {
+  ETP_REQUIRE(B > 0 && G > 0, "bad dims");
+  hipLaunchKernelGGL(sap_ce_kernel, dim3(row_grid(B, 1024)), dim3(256), 0, st, logits, labels, loss, dlogits, B, G, scale, ignore_index);
+  ETP_CHECK_LAUNCH("sap_ce");
+  return ETP_OK;
+}
+
+int gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
+               int accumulate, hipStream_t st) {
+  ETP_REQUIRE(N > 0 && H % 256 == 0, "bad dims");
+  const int grid = row_grid(N, 4096);
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gather_sum_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, ptr, idx, w, (bf16_t*)out, N, accumulate)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gather_sum_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)src, ptr, idx, w, (float*)out, N, accumulate)); }
+  ETP_CHECK_LAUNCH("gather_sum");
+  return ETP_OK;
+}
+
+int colsum(int dtype, const void* dy, long ld, float* db, int M, int N, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "bad dims");
+  const int rpb = 64;
+  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+  if (dtype == ETP_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ld, db, M, N, rpb);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ld, db, M, N, rpb);
+  ETP_CHECK_LAUNCH("colsum");
+  return ETP_OK;
+}
+
+int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  const int grid = (int)std::min<long>((n / 8 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  ETP_CHECK_LAUNCH("cast_f32_bf16");
+  return ETP_OK;
+}
+int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, scale);
+  ETP_CHECK_LAUNCH("cast_bf16_f32");
+  return ETP_OK;
+}
+int scale_f32(float* p, long n, float scale, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid), dim3(256), 0, st, p, n, scale);
+  ETP_CHECK_LAUNCH("scale_f32");
+  return ETP_OK;
+}
+
+}  // namespace etp

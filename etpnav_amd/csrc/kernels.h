@@ -1,0 +1,63 @@
+// Internal launcher prototypes (definitions in norm.hip / embed.hip / gemm.hip).
+#pragma once
+#include "common.h"
+
+namespace etp {
+
+struct PanoEmbedParams {
+  const float *g_img, *b_img, *g_dep, *b_dep, *w_loc, *bias_loc, *g_loc, *b_loc, *nav_emb, *type1, *g_out, *b_out;
+};
+struct PanoEmbedGrads {
+  float *g_img, *b_img, *g_dep, *b_dep, *w_loc, *bias_loc, *g_loc, *b_loc, *nav_emb, *type1, *g_out, *b_out;
+};
+
+int ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int H, float eps,
+           hipStream_t st);
+int ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+           float* dgamma, float* dbeta, int M, int H, hipStream_t st);
+int softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
+                int nh, int Lq, int Lk, int ldS, int mask_mode, hipStream_t st);
+int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int nh, int Lq,
+                int Lk, int ldS, hipStream_t st);
+
+int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                   const float* beta, void* y, float* stats, int B, int L, int H, float eps, hipStream_t st);
+int text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                   const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                   int B, int L, int H, hipStream_t st);
+int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
+                   void* y, float* stats, int M, int H, hipStream_t st);
+int pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                   const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
+                   hipStream_t st);
+int gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
+                   int H, int PK, hipStream_t st);
+int gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+                   const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
+                   float* dbeta, int M, int H, int PK, hipStream_t st);
+int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
+                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st);
+int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
+                 const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
+                 float* dw2, float* db2, int M, int H, hipStream_t st);
+int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale, long ignore_index,
+           hipStream_t st);
+int gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
+               int accumulate, hipStream_t st);
+int colsum(int dtype, const void* dy, long ld, float* db, int M, int N, hipStream_t st);
+int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);
+int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st);
+int scale_f32(float* p, long n, float scale, hipStream_t st);
+
+// attention = batched MFMA GEMMs + masked softmax (planner.hip); head dim 64, heads interleaved in the row
+struct AttnBuf {
+  const void* Q; long ldq; const void* K; long ldk; const void* V; long ldv;
+  int B, Lq, Lk, ldS;
+  const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
+};
+int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st);
+int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
+                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st);
+
+}  // namespace etp

@@ -1,0 +1,865 @@
+// Planner engine: forward/backward of forward_txt / forward_panorama / forward_navigation
+// (vlnce_baselines/models/etp/vilmodel_cmt.py:684-750) over one flat fp32 parameter arena.
+//
+// Host-side orchestration only: every product is an MFMA GEMM launch (gemm.hip) with a fused epilogue,
+// everything else a row kernel (norm.hip / embed.hip).  No allocation and no synchronisation happen here, so a
+// whole training step can be captured into one hipGraph by the caller.
+//
+// HBM layout
+//   params  fp32 arena  [ GEMM weight matrices | vectors & small projections | embedding tables ]
+//   shadow  bf16 copy of the leading matrix region (same element offsets), refreshed once per step
+//   grads   fp32 arena with the same offsets (accumulated: wgrad RMW / split-K atomics, row-kernel atomics)
+//   q/k/v weights of one attention are adjacent so QKV (self) and KV (cross) projections are single GEMMs.
+//   stash   per forward call: saved activations in compute dtype T (+ fp32 LN statistics)
+//   ws      per backward call: gradient scratch reused across layers
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+namespace etp {
+
+struct AttnP { int qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
+struct FfnP { int i_w, i_b, o_w, o_b, ln_g, ln_b; };
+struct TxtLayerP { AttnP att; FfnP ffn; };
+struct PanoLayerP { int in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_g, n1_b, n2_g, n2_b; };
+struct XLayerP { int q_w, q_b, kv_w, kv_b, xo_w, xo_b, xln_g, xln_b; AttnP self; FfnP ffn; };
+
+struct PInfo { std::string name; int ndim; long shape[2]; int region; long offset; long numel; };
+
+}  // namespace etp
+
+struct etp_planner {
+  etp_config cfg;
+  std::vector<etp::PInfo> params;
+  long total = 0, n_matrix = 0;
+  // named indices
+  int word, pos, type, emb_g, emb_b;
+  std::vector<etp::TxtLayerP> txt;
+  int img_w, img_b, img_g, img_bb, dep_w, dep_b, dep_g, dep_bb, loc_w, loc_b, loc_g, loc_bb, nav_emb, pe_g, pe_b;
+  std::vector<etp::PanoLayerP> pano;
+  int pn_g, pn_b;
+  int gpos_w, gpos_b, gpos_g, gpos_bb, step_emb, sp_w, sp_b;
+  std::vector<etp::XLayerP> xl;
+  int sap0_w, sap0_b, sap2_g, sap2_b, sap4_w, sap4_b;
+  // bound arenas
+  float* P = nullptr; void* S = nullptr; float* G = nullptr;
+
+  long off(int i) const { return params[i].offset; }
+  const float* pf(int i) const { return P + params[i].offset; }          // fp32 parameter
+  float* gf(int i) const { return G + params[i].offset; }                // fp32 gradient
+  const void* pw(int i) const {                                          // GEMM operand in compute dtype
+    if (cfg.dtype == ETP_BF16) return reinterpret_cast<const uint16_t*>(S) + params[i].offset;
+    return P + params[i].offset;
+  }
+};
+
+namespace etp {
+
+static int add_param(etp_planner* pl, const std::string& name, long r, long c, int region) {
+  PInfo p;
+  p.name = name; p.ndim = c > 0 ? 2 : 1; p.shape[0] = r; p.shape[1] = c > 0 ? c : 0; p.region = region;
+  p.numel = c > 0 ? r * c : r; p.offset = -1;
+  pl->params.push_back(p);
+  return (int)pl->params.size() - 1;
+}
+
+// region 0: GEMM matrices, 1: vectors / small, 2: embedding tables
+static void build_layout(etp_planner* pl) {
+  const etp_config& c = pl->cfg;
+  const long H = c.hidden, I = c.inter;
+  auto mat = [&](const std::string& n, long r, long k) { return add_param(pl, n, r, k, 0); };
+  auto vec = [&](const std::string& n, long r) { return add_param(pl, n, r, 0, 1); };
+  auto small = [&](const std::string& n, long r, long k) { return add_param(pl, n, r, k, 1); };
+  auto table = [&](const std::string& n, long r, long k) { return add_param(pl, n, r, k, 2); };
+
+  pl->word = table("embeddings.word_embeddings.weight", c.vocab, H);
+  pl->pos = table("embeddings.position_embeddings.weight", c.max_pos, H);
+  pl->type = table("embeddings.token_type_embeddings.weight", c.type_vocab, H);
+  pl->emb_g = vec("embeddings.LayerNorm.weight", H);
+  pl->emb_b = vec("embeddings.LayerNorm.bias", H);
+
+  auto self_att = [&](const std::string& p) {
+    AttnP a;
+    a.qkv_w = mat(p + ".self.query.weight", H, H);
+    mat(p + ".self.key.weight", H, H);
+    mat(p + ".self.value.weight", H, H);
+    a.qkv_b = vec(p + ".self.query.bias", H);
+    vec(p + ".self.key.bias", H);
+    vec(p + ".self.value.bias", H);
+    a.o_w = mat(p + ".output.dense.weight", H, H);
+    a.o_b = vec(p + ".output.dense.bias", H);
+    a.ln_g = vec(p + ".output.LayerNorm.weight", H);
+    a.ln_b = vec(p + ".output.LayerNorm.bias", H);
+    return a;
+  };
+  auto ffn = [&](const std::string& pi, const std::string& po) {
+    FfnP f;
+    f.i_w = mat(pi + ".dense.weight", I, H);
+    f.i_b = vec(pi + ".dense.bias", I);
+    f.o_w = mat(po + ".dense.weight", H, I);
+    f.o_b = vec(po + ".dense.bias", H);
+    f.ln_g = vec(po + ".LayerNorm.weight", H);
+    f.ln_b = vec(po + ".LayerNorm.bias", H);
+    return f;
+  };
+  for (int l = 0; l < c.n_l; ++l) {
+    const std::string p = "lang_encoder.layer." + std::to_string(l);
+    TxtLayerP t;
+    t.att = self_att(p + ".attention");
+    t.ffn = ffn(p + ".intermediate", p + ".output");
+    pl->txt.push_back(t);
+  }
+  const std::string e = "img_embeddings";
+  pl->img_w = mat(e + ".img_linear.weight", H, c.img_feat);
+  pl->img_b = vec(e + ".img_linear.bias", H);
+  pl->img_g = vec(e + ".img_layer_norm.weight", H);
+  pl->img_bb = vec(e + ".img_layer_norm.bias", H);
+  pl->loc_w = small(e + ".loc_linear.weight", H, c.ang_feat);
+  pl->loc_b = vec(e + ".loc_linear.bias", H);
+  pl->loc_g = vec(e + ".loc_layer_norm.weight", H);
+  pl->loc_bb = vec(e + ".loc_layer_norm.bias", H);
+  if (c.use_depth) {
+    pl->dep_w = mat(e + ".dep_linear.weight", H, c.dep_feat);
+    pl->dep_b = vec(e + ".dep_linear.bias", H);
+    pl->dep_g = vec(e + ".dep_layer_norm.weight", H);
+    pl->dep_bb = vec(e + ".dep_layer_norm.bias", H);
+  } else {
+    pl->dep_w = pl->dep_b = pl->dep_g = pl->dep_bb = -1;
+  }
+  pl->nav_emb = table(e + ".nav_type_embedding.weight", 2, H);
+  pl->pe_g = vec(e + ".layer_norm.weight", H);
+  pl->pe_b = vec(e + ".layer_norm.bias", H);
+  for (int l = 0; l < c.n_p; ++l) {
+    const std::string p = e + ".pano_encoder.layers." + std::to_string(l);
+    PanoLayerP q;
+    q.in_w = mat(p + ".self_attn.in_proj_weight", 3 * H, H);
+    q.in_b = vec(p + ".self_attn.in_proj_bias", 3 * H);
+    q.out_w = mat(p + ".self_attn.out_proj.weight", H, H);
+    q.out_b = vec(p + ".self_attn.out_proj.bias", H);
+    q.l1_w = mat(p + ".linear1.weight", I, H);
+    q.l1_b = vec(p + ".linear1.bias", I);
+    q.l2_w = mat(p + ".linear2.weight", H, I);
+    q.l2_b = vec(p + ".linear2.bias", H);
+    q.n1_g = vec(p + ".norm1.weight", H);
+    q.n1_b = vec(p + ".norm1.bias", H);
+    q.n2_g = vec(p + ".norm2.weight", H);
+    q.n2_b = vec(p + ".norm2.bias", H);
+    pl->pano.push_back(q);
+  }
+  if (c.n_p > 0) {
+    pl->pn_g = vec(e + ".pano_encoder.norm.weight", H);
+    pl->pn_b = vec(e + ".pano_encoder.norm.bias", H);
+  } else {
+    pl->pn_g = pl->pn_b = -1;
+  }
+  const std::string g = "global_encoder";
+  pl->gpos_w = small(g + ".gmap_pos_embeddings.0.weight", H, c.ang_feat + 3);
+  pl->gpos_b = vec(g + ".gmap_pos_embeddings.0.bias", H);
+  pl->gpos_g = vec(g + ".gmap_pos_embeddings.1.weight", H);
+  pl->gpos_bb = vec(g + ".gmap_pos_embeddings.1.bias", H);
+  pl->step_emb = table(g + ".gmap_step_embeddings.weight", c.max_steps, H);
+  for (int l = 0; l < c.n_x; ++l) {
+    const std::string p = g + ".encoder.x_layers." + std::to_string(l);
+    XLayerP x;
+    x.self = self_att(p + ".visn_self_att");
+    x.ffn = ffn(p + ".visn_inter", p + ".visn_output");
+    x.q_w = mat(p + ".visual_attention.att.query.weight", H, H);
+    x.q_b = vec(p + ".visual_attention.att.query.bias", H);
+    x.kv_w = mat(p + ".visual_attention.att.key.weight", H, H);
+    mat(p + ".visual_attention.att.value.weight", H, H);
+    x.kv_b = vec(p + ".visual_attention.att.key.bias", H);
+    vec(p + ".visual_attention.att.value.bias", H);
+    x.xo_w = mat(p + ".visual_attention.output.dense.weight", H, H);
+    x.xo_b = vec(p + ".visual_attention.output.dense.bias", H);
+    x.xln_g = vec(p + ".visual_attention.output.LayerNorm.weight", H);
+    x.xln_b = vec(p + ".visual_attention.output.LayerNorm.bias", H);
+    pl->xl.push_back(x);
+  }
+  if (c.use_sprels) {
+    pl->sp_w = small(g + ".sprel_linear.weight", 1, 1);
+    pl->sp_b = vec(g + ".sprel_linear.bias", 1);
+  } else {
+    pl->sp_w = pl->sp_b = -1;
+  }
+  pl->sap0_w = mat("global_sap_head.net.0.weight", H, H);
+  pl->sap0_b = vec("global_sap_head.net.0.bias", H);
+  pl->sap2_g = vec("global_sap_head.net.2.weight", H);
+  pl->sap2_b = vec("global_sap_head.net.2.bias", H);
+  pl->sap4_w = small("global_sap_head.net.4.weight", 1, H);
+  pl->sap4_b = vec("global_sap_head.net.4.bias", 1);
+
+  long off = 0;
+  for (int region = 0; region < 3; ++region) {
+    for (auto& p : pl->params)
+      if (p.region == region) { p.offset = off; off += round_up(p.numel, 64); }
+    if (region == 0) pl->n_matrix = off;
+  }
+  pl->total = off;
+}
+
+// ---- bump allocator over caller-provided stash / workspace -----------------------------
+struct Bump {
+  char* base; size_t off = 0;
+  explicit Bump(void* b) : base(reinterpret_cast<char*>(b)) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return p;
+  }
+};
+
+struct Ctx {
+  etp_planner* pl; hipStream_t st; int dt; size_t es;  // element size of T
+  int H, I, nh;
+};
+static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
+  Ctx c;
+  c.pl = pl; c.st = reinterpret_cast<hipStream_t>(s); c.dt = pl->cfg.dtype; c.es = dtype_size(c.dt);
+  c.H = pl->cfg.hidden; c.I = pl->cfg.inter; c.nh = pl->cfg.heads;
+  return c;
+}
+
+static GemmArgs base_args() {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.nb_inner = 1; g.ksplit = 1; g.alpha = 1.f;
+  return g;
+}
+
+// Y[M,N] = act(X[M,K] . W[N,K]^T + b) (+R)
+static int linear_fwd(const Ctx& c, const void* X, long ldx, int wi, int bi, void* Y, long ldy, int M, int N, int K, int act,
+                      void* Z, const void* R, long ldr) {
+  GemmArgs g = base_args();
+  g.A = X; g.lda = ldx; g.B = c.pl->pw(wi); g.ldb = K; g.C = Y; g.ldc = ldy;
+  g.M = M; g.N = N; g.K = K;
+  g.bias = bi >= 0 ? c.pl->pf(bi) : nullptr;
+  g.act = act; g.Z = Z; g.ldz = ldy; g.R = R; g.ldr = ldr;
+  return launch_gemm(c.dt, c.dt, 0, 0, g, 1, c.st);
+}
+// dX[M,K] = act_bwd(dY[M,N] . W[N,K]) (+R)      (B operand = W stored [N (reduction)][K])
+static int linear_dgrad(const Ctx& c, const void* dY, long ldy, int wi, void* dX, long ldx, int M, int N, int K, int act,
+                        void* Z, long ldz, const void* R, long ldr, int out_mode = 0) {
+  GemmArgs g = base_args();
+  g.A = dY; g.lda = ldy; g.B = c.pl->pw(wi); g.ldb = K; g.C = dX; g.ldc = ldx;
+  g.M = M; g.N = K; g.K = N;
+  g.act = act; g.Z = Z; g.ldz = ldz; g.R = R; g.ldr = ldr; g.out_mode = out_mode;
+  return launch_gemm(c.dt, c.dt, 0, 1, g, 1, c.st);
+}
+// dW[N,K] += dY[M,N]^T . X[M,K] ; db[N] += colsum(dY)
+static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, long ldx, int wi, int bi, int M, int N, int K) {
+  GemmArgs g = base_args();
+  g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = c.pl->gf(wi); g.ldc = K;
+  g.M = N; g.N = K; g.K = M;
+  // split the token reduction when the weight alone cannot fill 256 CUs
+  const int bk = c.dt == ETP_BF16 ? 64 : 32;
+  const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+  int ks = (int)std::max<long>(1, std::min<long>(256 / std::max<long>(tiles, 1), (M + 255) / 256));
+  if (ks > 1) {
+    const int per = (int)round_up((M + ks - 1) / ks, bk);
+    ks = (M + per - 1) / per;
+  }
+  g.ksplit = ks;
+  g.out_mode = ks > 1 ? 2 : 1;
+  ETP_TRY(launch_gemm(c.dt, ETP_F32, 1, 1, g, 1, c.st));
+  if (bi >= 0) ETP_TRY(colsum(c.dt, dY, ldy, c.pl->gf(bi), M, N, c.st));
+  return ETP_OK;
+}
+
+// ---- attention (head dim 64, heads interleaved in the row) ------------------------------
+static inline const void* offs(const void* p, long elems, size_t es) { return reinterpret_cast<const char*>(p) + elems * es; }
+static inline void* offs(void* p, long elems, size_t es) { return reinterpret_cast<char*>(p) + elems * es; }
+
+int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
+  const int dh = 64;
+  GemmArgs g = base_args();
+  // S = alpha * Q K^T
+  g.A = a.Q; g.lda = a.ldq; g.sAo = (long)a.Lq * a.ldq; g.sAi = dh;
+  g.B = a.K; g.ldb = a.ldk; g.sBo = (long)a.Lk * a.ldk; g.sBi = dh;
+  g.C = P; g.ldc = a.ldS; g.sCo = (long)nh * a.Lq * a.ldS; g.sCi = (long)a.Lq * a.ldS;
+  g.M = a.Lq; g.N = a.Lk; g.K = dh; g.nb_inner = nh; g.alpha = alpha;
+  ETP_TRY(launch_gemm(dt, dt, 0, 0, g, a.B * nh, st));
+  ETP_TRY(softmax_fwd(dt, P, a.keymask, a.dist, a.sp_w, a.sp_b, a.B, nh, a.Lq, a.Lk, a.ldS, a.mask_mode, st));
+  // ctx = P V
+  GemmArgs h = base_args();
+  h.A = P; h.lda = a.ldS; h.sAo = g.sCo; h.sAi = g.sCi;
+  h.B = a.V; h.ldb = a.ldv; h.sBo = (long)a.Lk * a.ldv; h.sBi = dh;
+  h.C = ctx; h.ldc = ldc; h.sCo = (long)a.Lq * ldc; h.sCi = dh;
+  h.M = a.Lq; h.N = dh; h.K = a.Lk; h.nb_inner = nh;
+  return launch_gemm(dt, dt, 0, 1, h, a.B * nh, st);
+}
+
+int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
+                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st) {
+  const int dh = 64;
+  const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;
+  // dP = dctx V^T
+  GemmArgs g = base_args();
+  g.A = dctx; g.lda = ldd; g.sAo = (long)a.Lq * ldd; g.sAi = dh;
+  g.B = a.V; g.ldb = a.ldv; g.sBo = (long)a.Lk * a.ldv; g.sBi = dh;
+  g.C = dP; g.ldc = a.ldS; g.sCo = sPo; g.sCi = sPi;
+  g.M = a.Lq; g.N = a.Lk; g.K = dh; g.nb_inner = nh;
+  ETP_TRY(launch_gemm(dt, dt, 0, 0, g, a.B * nh, st));
+  // dV = P^T dctx
+  GemmArgs v = base_args();
+  v.A = P; v.lda = a.ldS; v.sAo = sPo; v.sAi = sPi;
+  v.B = dctx; v.ldb = ldd; v.sBo = (long)a.Lq * ldd; v.sBi = dh;
+  v.C = dV; v.ldc = lddv; v.sCo = (long)a.Lk * lddv; v.sCi = dh;
+  v.M = a.Lk; v.N = dh; v.K = a.Lq; v.nb_inner = nh;
+  ETP_TRY(launch_gemm(dt, dt, 1, 1, v, a.B * nh, st));
+  // dS = P * (dP - rowsum(dP*P))
+  ETP_TRY(softmax_bwd(dt, P, dP, a.dist, d_sp_w, d_sp_b, a.B, nh, a.Lq, a.Lk, a.ldS, st));
+  // dQ = alpha dS K
+  GemmArgs q = base_args();
+  q.A = dP; q.lda = a.ldS; q.sAo = sPo; q.sAi = sPi;
+  q.B = a.K; q.ldb = a.ldk; q.sBo = (long)a.Lk * a.ldk; q.sBi = dh;
+  q.C = dQ; q.ldc = lddq; q.sCo = (long)a.Lq * lddq; q.sCi = dh;
+  q.M = a.Lq; q.N = dh; q.K = a.Lk; q.nb_inner = nh; q.alpha = alpha;
+  ETP_TRY(launch_gemm(dt, dt, 0, 1, q, a.B * nh, st));
+  // dK = alpha dS^T Q
+  GemmArgs k = base_args();
+  k.A = dP; k.lda = a.ldS; k.sAo = sPo; k.sAi = sPi;
+  k.B = a.Q; k.ldb = a.ldq; k.sBo = (long)a.Lq * a.ldq; k.sBi = dh;
+  k.C = dK; k.ldc = lddk; k.sCo = (long)a.Lk * lddk; k.sCi = dh;
+  k.M = a.Lk; k.N = dh; k.K = a.Lq; k.nb_inner = nh; k.alpha = alpha;
+  return launch_gemm(dt, dt, 1, 1, k, a.B * nh, st);
+}
+
+// ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
+struct SelfAttStash { void *qkv, *P, *ctx, *s; float* st; void* y; };
+struct FfnStash { void *z, *h, *s; float* st; void* y; };
+struct CrossStash { void *q, *kv, *P, *ctx, *s; float* st; void* y; };
+
+static SelfAttStash plan_self(Bump& b, size_t es, long M, int Bn, int nh, int L, int ldS, int H, bool own_y) {
+  SelfAttStash s;
+  s.qkv = b.take(M * 3 * H * es);
+  s.P = b.take((size_t)Bn * nh * L * ldS * es);
+  s.ctx = b.take(M * H * es);
+  s.s = b.take(M * H * es);
+  s.st = (float*)b.take(M * 2 * sizeof(float));
+  s.y = own_y ? b.take(M * H * es) : nullptr;
+  return s;
+}
+static FfnStash plan_ffn(Bump& b, size_t es, long M, int H, int I, bool own_y) {
+  FfnStash f;
+  f.z = b.take(M * I * es);
+  f.h = b.take(M * I * es);
+  f.s = b.take(M * H * es);
+  f.st = (float*)b.take(M * 2 * sizeof(float));
+  f.y = own_y ? b.take(M * H * es) : nullptr;
+  return f;
+}
+
+// y = LN(dense(attn(x)) + x)
+static int self_att_fwd(const Ctx& c, const AttnP& p, const void* x, SelfAttStash& s, int Bn, int L, const uint8_t* keymask,
+                        const float* dist, const float* sp_w, const float* sp_b, float eps) {
+  const int H = c.H, M = Bn * L;
+  ETP_TRY(linear_fwd(c, x, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+  AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
+            keymask, 0, dist, sp_w, sp_b};
+  ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st));
+  ETP_TRY(linear_fwd(c, s.ctx, H, p.o_w, p.o_b, s.s, H, M, H, H, ETP_ACT_NONE, nullptr, x, H));
+  return ln_fwd(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y, s.st, M, H, eps, c.st);
+}
+// g: in = dL/dy, out = dL/dx (same buffer); t1,t2: [M,H] scratch; dqkv: [M,3H]; dP: like P
+static int self_att_bwd(const Ctx& c, const AttnP& p, const void* x, const SelfAttStash& s, int Bn, int L,
+                        const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, float* d_sp_w,
+                        float* d_sp_b, void* g, void* t1, void* t2, void* dqkv, void* dP) {
+  const int H = c.H, M = Bn * L;
+  etp_planner* pl = c.pl;
+  ETP_TRY(ln_bwd(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, t1, pl->gf(p.ln_g), pl->gf(p.ln_b), M, H, c.st));  // t1 = ds
+  ETP_TRY(linear_wgrad(c, t1, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
+  ETP_TRY(linear_dgrad(c, t1, H, p.o_w, t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));                   // t2 = dctx
+  AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
+            keymask, 0, dist, sp_w, sp_b};
+  ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, t2, H, dP, dqkv, 3L * H, offs(dqkv, H, c.es), 3L * H, offs(dqkv, 2 * H, c.es),
+                        3L * H, 0.125f, d_sp_w, d_sp_b, c.st));
+  ETP_TRY(linear_wgrad(c, dqkv, 3 * H, x, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
+  return linear_dgrad(c, dqkv, 3 * H, p.qkv_w, g, H, M, 3 * H, H, ETP_ACT_NONE, nullptr, 0, t1, H);               // g = dx
+}
+
+static int ffn_fwd(const Ctx& c, const FfnP& p, const void* x, FfnStash& f, int M, float eps) {
+  const int H = c.H, I = c.I;
+  ETP_TRY(linear_fwd(c, x, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU, f.z, nullptr, 0));
+  ETP_TRY(linear_fwd(c, f.h, I, p.o_w, p.o_b, f.s, H, M, H, I, ETP_ACT_NONE, nullptr, x, H));
+  return ln_fwd(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y, f.st, M, H, eps, c.st);
+}
+static int ffn_bwd(const Ctx& c, const FfnP& p, const void* x, const FfnStash& f, int M, void* g, void* t1, void* dI) {
+  const int H = c.H, I = c.I;
+  etp_planner* pl = c.pl;
+  ETP_TRY(ln_bwd(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, t1, pl->gf(p.ln_g), pl->gf(p.ln_b), M, H, c.st));   // t1 = ds
+  ETP_TRY(linear_wgrad(c, t1, H, f.h, I, p.o_w, p.o_b, M, H, I));
+  ETP_TRY(linear_dgrad(c, t1, H, p.o_w, dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));                    // dI = dz
+  ETP_TRY(linear_wgrad(c, dI, I, x, H, p.i_w, p.i_b, M, I, H));
+  return linear_dgrad(c, dI, I, p.i_w, g, H, M, I, H, ETP_ACT_NONE, nullptr, 0, t1, H);                            // g = dx
+}
+
+// ======================================================================================
+// forward_txt
+// ======================================================================================
+struct TxtStash {
+  void* x0; float* st0;
+  std::vector<SelfAttStash> att; std::vector<FfnStash> ffn;
+};
+static TxtStash plan_txt(const etp_planner* pl, Bump& b, int Bn, int L) {
+  const size_t es = dtype_size(pl->cfg.dtype);
+  const int H = pl->cfg.hidden;
+  const long M = (long)Bn * L;
+  TxtStash t;
+  t.x0 = b.take(M * H * es);
+  t.st0 = (float*)b.take(M * 2 * sizeof(float));
+  for (int l = 0; l < pl->cfg.n_l; ++l) {
+    t.att.push_back(plan_self(b, es, M, Bn, pl->cfg.heads, L, (int)round_up(L, 8), H, true));
+    t.ffn.push_back(plan_ffn(b, es, M, H, pl->cfg.inter, l + 1 < pl->cfg.n_l));   // last y = caller's output
+  }
+  return t;
+}
+struct BwdWs { void *g, *t1, *t2, *dI, *dqkv, *dP, *dq, *dkv, *dP2; };
+
+}  // namespace etp
+
+using namespace etp;
+
+extern "C" {
+
+etp_planner* etp_planner_create(const etp_config* cfg) {
+  if (!cfg) { set_error("etp_planner_create: null config"); return nullptr; }
+  if (cfg->hidden % 256 != 0 || cfg->hidden > 1024 || cfg->heads * 64 != cfg->hidden || cfg->inter % 8 != 0 ||
+      cfg->img_feat % 8 != 0 || (cfg->use_depth && cfg->dep_feat % 8 != 0) || cfg->ang_feat != 4 ||
+      (cfg->dtype != ETP_F32 && cfg->dtype != ETP_BF16) || cfg->n_l < 0 || cfg->n_p < 0 || cfg->n_x < 0) {
+    set_error("etp_planner_create: unsupported config (hidden must be 256..1024 in steps of 256 with 64-wide heads, "
+              "feature sizes multiples of 8, angle_feat_size 4)");
+    return nullptr;
+  }
+  etp_planner* pl = new etp_planner();
+  pl->cfg = *cfg;
+  build_layout(pl);
+  return pl;
+}
+void etp_planner_destroy(etp_planner* p) { delete p; }
+int etp_planner_param_count(const etp_planner* p) { return p ? (int)p->params.size() : 0; }
+int etp_planner_param_info(const etp_planner* p, int i, etp_param_info* out) {
+  ETP_REQUIRE(p && out && i >= 0 && i < (int)p->params.size(), "bad index");
+  const PInfo& q = p->params[i];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, q.name.c_str(), sizeof(out->name) - 1);
+  out->ndim = q.ndim; out->shape[0] = q.shape[0]; out->shape[1] = q.shape[1]; out->offset = q.offset;
+  return ETP_OK;
+}
+int64_t etp_planner_arena_elems(const etp_planner* p) { return p ? p->total : 0; }
+int64_t etp_planner_matrix_elems(const etp_planner* p) { return p ? p->n_matrix : 0; }
+int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads) {
+  ETP_REQUIRE(p && params, "null planner/params");
+  ETP_REQUIRE(p->cfg.dtype == ETP_F32 || shadow != nullptr, "bf16 mode needs a shadow arena");
+  ETP_REQUIRE(((uintptr_t)params % 256 == 0) && ((uintptr_t)shadow % 256 == 0) && ((uintptr_t)grads % 256 == 0),
+              "arenas must be 256-byte aligned");
+  p->P = params; p->S = shadow; p->G = grads;
+  return ETP_OK;
+}
+int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P, "planner not bound");
+  if (p->cfg.dtype != ETP_BF16) return ETP_OK;
+  return cast_f32_to_bf16(p->P, p->S, p->n_matrix, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_txt(p, b, B, L);
+  return (int64_t)b.off + 256;
+}
+static BwdWs plan_ws(Bump& b, size_t es, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
+  BwdWs w;
+  memset(&w, 0, sizeof(w));
+  w.g = b.take(M * H * es);
+  w.t1 = b.take(M * H * es);
+  w.t2 = b.take(M * H * es);
+  w.dI = b.take(M * I * es);
+  w.dqkv = b.take(M * 3 * H * es);
+  w.dP = b.take((size_t)Bn * nh * Lq * ldS * es);
+  return w;
+}
+int64_t etp_txt_ws_bytes(const etp_planner* p, int B, int L) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_ws(b, dtype_size(p->cfg.dtype), (long)B * L, B, p->cfg.heads, L, (int)round_up(L, 8), p->cfg.hidden, p->cfg.inter);
+  return (int64_t)b.off + 256;
+}
+
+int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, int L, void* out, void* stash,
+                etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && ids && mask && out && stash && B > 0 && L > 0 && L <= p->cfg.max_pos, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  TxtStash t = plan_txt(p, b, B, L);
+  const int H = c.H, M = B * L;
+  const float eps = p->cfg.ln_eps;
+  ETP_TRY(text_embed_fwd(c.dt, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), p->pf(p->emb_b), t.x0,
+                         t.st0, B, L, H, eps, c.st));
+  const void* x = t.x0;
+  for (int l = 0; l < p->cfg.n_l; ++l) {
+    if (l + 1 == p->cfg.n_l) t.ffn[l].y = out;
+    ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps));
+    ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps));
+    x = t.ffn[l].y;
+  }
+  if (p->cfg.n_l == 0) ETP_CHECK_HIP(hipMemcpyAsync(out, t.x0, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  return ETP_OK;
+}
+
+int etp_txt_bwd(etp_planner* p, const void* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
+                etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && dout && ids && mask && stash && ws && B > 0 && L > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  TxtStash t = plan_txt(p, b, B, L);
+  Bump wb(ws);
+  const int H = c.H, M = B * L;
+  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+  ETP_CHECK_HIP(hipMemcpyAsync(w.g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  for (int l = p->cfg.n_l - 1; l >= 0; --l) {
+    const void* x = l == 0 ? t.x0 : t.ffn[l - 1].y;
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, w.g, w.t1, w.dI));
+    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, w.g, w.t1,
+                         w.t2, w.dqkv, w.dP));
+  }
+  return text_embed_bwd(c.dt, w.g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
+                        p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st);
+}
+
+// ======================================================================================
+// forward_panorama
+// ======================================================================================
+namespace {
+struct PanoLayerStash { void* a; float* st1; void *qkv, *P, *ctx, *x1, *f; float* st2; void *z, *h, *x2; };
+struct PanoStash {
+  void *rgbT, *depT, *a, *d; float* est; void* x0; uint8_t* mask;
+  std::vector<PanoLayerStash> layers;
+  float* stn;
+};
+PanoStash plan_pano(const etp_planner* pl, Bump& b, int Bn, int V) {
+  const etp_config& c = pl->cfg;
+  const size_t es = dtype_size(c.dtype);
+  const long M = (long)Bn * V;
+  const int H = c.hidden, I = c.inter, ldS = (int)round_up(V, 8);
+  PanoStash s;
+  s.rgbT = c.dtype == ETP_BF16 ? b.take(M * c.img_feat * es) : nullptr;
+  s.depT = (c.dtype == ETP_BF16 && c.use_depth) ? b.take(M * c.dep_feat * es) : nullptr;
+  s.a = b.take(M * H * es);
+  s.d = c.use_depth ? b.take(M * H * es) : nullptr;
+  s.est = (float*)b.take(M * 8 * sizeof(float));
+  s.x0 = b.take(M * H * es);
+  s.mask = (uint8_t*)b.take(M);
+  for (int l = 0; l < c.n_p; ++l) {
+    PanoLayerStash q;
+    q.a = b.take(M * H * es);
+    q.st1 = (float*)b.take(M * 2 * sizeof(float));
+    q.qkv = b.take(M * 3 * H * es);
+    q.P = b.take((size_t)Bn * c.heads * V * ldS * es);
+    q.ctx = b.take(M * H * es);
+    q.x1 = b.take(M * H * es);
+    q.f = b.take(M * H * es);
+    q.st2 = (float*)b.take(M * 2 * sizeof(float));
+    q.z = b.take(M * I * es);
+    q.h = b.take(M * I * es);
+    q.x2 = b.take(M * H * es);
+    s.layers.push_back(q);
+  }
+  s.stn = (float*)b.take(M * 2 * sizeof(float));
+  return s;
+}
+__global__ void seq_mask_kernel(const int64_t* __restrict__ lens, uint8_t* __restrict__ m1, uint8_t* __restrict__ m2, int Bn,
+                                int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Bn * V) {
+    const uint8_t v = (i % V) < lens[i / V] ? 1 : 0;      // gen_seq_masks common/ops.py:36-44
+    m1[i] = v;
+    if (m2) m2[i] = v;
+  }
+}
+PanoEmbedParams pano_params(const etp_planner* p) {
+  PanoEmbedParams q;
+  q.g_img = p->pf(p->img_g); q.b_img = p->pf(p->img_bb);
+  q.g_dep = p->cfg.use_depth ? p->pf(p->dep_g) : nullptr; q.b_dep = p->cfg.use_depth ? p->pf(p->dep_bb) : nullptr;
+  q.w_loc = p->pf(p->loc_w); q.bias_loc = p->pf(p->loc_b); q.g_loc = p->pf(p->loc_g); q.b_loc = p->pf(p->loc_bb);
+  q.nav_emb = p->pf(p->nav_emb); q.type1 = p->pf(p->type) + p->cfg.hidden;
+  q.g_out = p->pf(p->pe_g); q.b_out = p->pf(p->pe_b);
+  return q;
+}
+PanoEmbedGrads pano_grads(const etp_planner* p) {
+  PanoEmbedGrads q;
+  q.g_img = p->gf(p->img_g); q.b_img = p->gf(p->img_bb);
+  q.g_dep = p->cfg.use_depth ? p->gf(p->dep_g) : nullptr; q.b_dep = p->cfg.use_depth ? p->gf(p->dep_bb) : nullptr;
+  q.w_loc = p->gf(p->loc_w); q.bias_loc = p->gf(p->loc_b); q.g_loc = p->gf(p->loc_g); q.b_loc = p->gf(p->loc_bb);
+  q.nav_emb = p->gf(p->nav_emb); q.type1 = p->gf(p->type) + p->cfg.hidden;
+  q.g_out = p->gf(p->pe_g); q.b_out = p->gf(p->pe_b);
+  return q;
+}
+}  // namespace
+
+int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_pano(p, b, B, V);
+  return (int64_t)b.off + 256;
+}
+int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_ws(b, dtype_size(p->cfg.dtype), (long)B * V, B, p->cfg.heads, V, (int)round_up(V, 8), p->cfg.hidden, p->cfg.inter);
+  b.take((size_t)B * V * p->cfg.hidden * dtype_size(p->cfg.dtype));   // second [M,H] gradient (depth branch)
+  return (int64_t)b.off + 256;
+}
+
+int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float* loc, const int64_t* nav,
+                 const int64_t* view_lens, int B, int V, void* out, uint8_t* out_mask, void* stash, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && rgb && loc && nav && view_lens && out && stash && B > 0 && V > 0, "bad arguments");
+  ETP_REQUIRE(!p->cfg.use_depth || dep, "depth features required");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  PanoStash s = plan_pano(p, b, B, V);
+  const etp_config& cf = p->cfg;
+  const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
+  hipLaunchKernelGGL(seq_mask_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, view_lens, s.mask, out_mask, B, V);
+  ETP_CHECK_LAUNCH("seq_mask");
+  const void* rgbT = rgb; const void* depT = dep;
+  if (c.dt == ETP_BF16) {
+    ETP_TRY(cast_f32_to_bf16(rgb, s.rgbT, (long)M * cf.img_feat, c.st));
+    rgbT = s.rgbT;
+    if (cf.use_depth) { ETP_TRY(cast_f32_to_bf16(dep, s.depT, (long)M * cf.dep_feat, c.st)); depT = s.depT; }
+  }
+  ETP_TRY(linear_fwd(c, rgbT, cf.img_feat, p->img_w, p->img_b, s.a, H, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
+  if (cf.use_depth)
+    ETP_TRY(linear_fwd(c, depT, cf.dep_feat, p->dep_w, p->dep_b, s.d, H, M, H, cf.dep_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
+  void* x0 = cf.n_p == 0 ? out : s.x0;
+  ETP_TRY(pano_embed_fwd(c.dt, s.a, s.d, loc, nav, pano_params(p), x0, s.est, M, H, c.st));
+  const void* x = x0;
+  for (int l = 0; l < cf.n_p; ++l) {   // TransformerEncoderLayer.forward_pre common/transformer.py:170-182
+    const PanoLayerP& q = p->pano[l];
+    PanoLayerStash& t = s.layers[l];
+    ETP_TRY(ln_fwd(c.dt, x, p->pf(q.n1_g), p->pf(q.n1_b), t.a, t.st1, M, H, 1e-5f, c.st));
+    ETP_TRY(linear_fwd(c, t.a, H, q.in_w, q.in_b, t.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
+              nullptr, nullptr};
+    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st));
+    ETP_TRY(linear_fwd(c, t.ctx, H, q.out_w, q.out_b, t.x1, H, M, H, H, ETP_ACT_NONE, nullptr, x, H));
+    ETP_TRY(ln_fwd(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), t.f, t.st2, M, H, 1e-5f, c.st));
+    ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU, t.z, nullptr, 0));
+    ETP_TRY(linear_fwd(c, t.h, I, q.l2_w, q.l2_b, t.x2, H, M, H, I, ETP_ACT_NONE, nullptr, t.x1, H));
+    x = t.x2;
+  }
+  if (cf.n_p > 0) ETP_TRY(ln_fwd(c.dt, x, p->pf(p->pn_g), p->pf(p->pn_b), out, s.stn, M, H, 1e-12f, c.st));
+  return ETP_OK;
+}
+
+int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float* dep, const float* loc, const int64_t* nav,
+                 int B, int V, void* d_rgb, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && dout && rgb && loc && nav && stash && ws && B > 0 && V > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  PanoStash s = plan_pano(p, b, B, V);
+  const etp_config& cf = p->cfg;
+  const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
+  Bump wb(ws);
+  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
+  void* g2 = wb.take((size_t)M * H * c.es);
+  if (cf.n_p > 0) {
+    const void* xin = s.layers[cf.n_p - 1].x2;
+    ETP_TRY(ln_bwd(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, w.g, p->gf(p->pn_g), p->gf(p->pn_b), M, H, c.st));
+  } else {
+    ETP_CHECK_HIP(hipMemcpyAsync(w.g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  }
+  for (int l = cf.n_p - 1; l >= 0; --l) {
+    const PanoLayerP& q = p->pano[l];
+    const PanoLayerStash& t = s.layers[l];
+    const void* x = l == 0 ? s.x0 : s.layers[l - 1].x2;
+    // FFN: x2 = x1 + W2 gelu(W1 LN2(x1))
+    ETP_TRY(linear_wgrad(c, w.g, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
+    ETP_TRY(linear_dgrad(c, w.g, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
+    ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
+    ETP_TRY(linear_dgrad(c, w.dI, I, q.l1_w, w.t1, H, M, I, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t1 = df
+    ETP_TRY(ln_bwd(c.dt, w.t1, t.x1, t.st2, p->pf(q.n2_g), w.g, w.t2, p->gf(q.n2_g), p->gf(q.n2_b), M, H, c.st)); // t2 = dx1
+    // attention: x1 = x + Wo attn(LN1(x))
+    ETP_TRY(linear_wgrad(c, w.t2, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
+    ETP_TRY(linear_dgrad(c, w.t2, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
+    AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
+              nullptr, nullptr};
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
+                          offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st));
+    ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
+    ETP_TRY(linear_dgrad(c, w.dqkv, 3 * H, q.in_w, w.t1, H, M, 3 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));  // t1 = da
+    ETP_TRY(ln_bwd(c.dt, w.t1, x, t.st1, p->pf(q.n1_g), w.t2, w.g, p->gf(q.n1_g), p->gf(q.n1_b), M, H, c.st));    // g = dx
+  }
+  // embedding fuse backward -> da (t1), dd (g2)
+  ETP_TRY(pano_embed_bwd(c.dt, w.g, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, g2, M, H, c.st));
+  const void* rgbT = c.dt == ETP_BF16 ? s.rgbT : (const void*)rgb;
+  const void* depT = c.dt == ETP_BF16 ? s.depT : (const void*)dep;
+  ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
+  if (cf.use_depth) ETP_TRY(linear_wgrad(c, g2, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
+  if (d_rgb) ETP_TRY(linear_dgrad(c, w.t1, H, p->img_w, d_rgb, cf.img_feat, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+  return ETP_OK;
+}
+
+// ======================================================================================
+// forward_navigation
+// ======================================================================================
+namespace {
+struct XStash { CrossStash cross; SelfAttStash self; FfnStash ffn; };
+struct NavStash {
+  void* x0; float* st0;
+  std::vector<XStash> layers;
+  void* r; float* str;
+};
+NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
+  const etp_config& c = pl->cfg;
+  const size_t es = dtype_size(c.dtype);
+  const long Mg = (long)Bn * G, Mt = (long)Bn * L;
+  const int H = c.hidden, ldL = (int)round_up(L, 8), ldG = (int)round_up(G, 8);
+  NavStash s;
+  s.x0 = b.take(Mg * H * es);
+  s.st0 = (float*)b.take(Mg * 2 * sizeof(float));
+  for (int l = 0; l < c.n_x; ++l) {
+    XStash x;
+    x.cross.q = b.take(Mg * H * es);
+    x.cross.kv = b.take(Mt * 2 * H * es);
+    x.cross.P = b.take((size_t)Bn * c.heads * G * ldL * es);
+    x.cross.ctx = b.take(Mg * H * es);
+    x.cross.s = b.take(Mg * H * es);
+    x.cross.st = (float*)b.take(Mg * 2 * sizeof(float));
+    x.cross.y = b.take(Mg * H * es);
+    x.self = plan_self(b, es, Mg, Bn, c.heads, G, ldG, H, true);
+    x.ffn = plan_ffn(b, es, Mg, H, c.inter, l + 1 < c.n_x);
+    s.layers.push_back(x);
+  }
+  s.r = b.take(Mg * H * es);
+  s.str = (float*)b.take(Mg * 2 * sizeof(float));
+  return s;
+}
+struct NavWs { BwdWs w; void *dq, *dkv, *dPx; };
+NavWs plan_nav_ws(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
+  const etp_config& c = pl->cfg;
+  const size_t es = dtype_size(c.dtype);
+  const long Mg = (long)Bn * G, Mt = (long)Bn * L;
+  NavWs n;
+  n.w = plan_ws(b, es, Mg, Bn, c.heads, G, (int)round_up(G, 8), c.hidden, c.inter);
+  n.dq = b.take(Mg * c.hidden * es);
+  n.dkv = b.take(Mt * 2 * c.hidden * es);
+  n.dPx = b.take((size_t)Bn * c.heads * G * round_up(L, 8) * es);
+  return n;
+}
+}  // namespace
+
+int64_t etp_nav_stash_bytes(const etp_planner* p, int B, int L, int G) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_nav(p, b, B, L, G);
+  return (int64_t)b.off + 256;
+}
+int64_t etp_nav_ws_bytes(const etp_planner* p, int B, int L, int G) {
+  if (!p) return 0;
+  Bump b(nullptr);
+  plan_nav_ws(p, b, B, L, G);
+  return (int64_t)b.off + 256;
+}
+
+int etp_nav_fwd(etp_planner* p, const void* txt, const uint8_t* txt_mask, const int64_t* step_ids, const void* img,
+                const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
+                void* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && txt && txt_mask && step_ids && img && pos && gmask && visited && out_embeds && out_logits && stash &&
+                  B > 0 && L > 0 && G > 0,
+              "bad arguments");
+  ETP_REQUIRE(!p->cfg.use_sprels || dists, "gmap_pair_dists required when graph_sprels is on");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  NavStash s = plan_nav(p, b, B, L, G);
+  const etp_config& cf = p->cfg;
+  const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
+  const float eps = cf.ln_eps;
+  void* x0 = cf.n_x == 0 ? out_embeds : s.x0;
+  ETP_TRY(gmap_embed_fwd(c.dt, img, step_ids, pos, p->pf(p->step_emb), p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g),
+                         p->pf(p->gpos_bb), x0, s.st0, Mg, H, cf.ang_feat + 3, c.st));
+  const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
+  const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
+  const void* x = x0;
+  for (int l = 0; l < cf.n_x; ++l) {   // GraphLXRTXLayer.forward vilmodel_cmt.py:383-398
+    const XLayerP& q = p->xl[l];
+    XStash& t = s.layers[l];
+    if (l + 1 == cf.n_x) t.ffn.y = out_embeds;
+    // cross attention nodes -> text (BertXAttention :360-363)
+    ETP_TRY(linear_fwd(c, x, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    ETP_TRY(linear_fwd(c, txt, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
+              nullptr, nullptr};
+    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st));
+    ETP_TRY(linear_fwd(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, H, Mg, H, H, ETP_ACT_NONE, nullptr, x, H));
+    ETP_TRY(ln_fwd(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y, t.cross.st, Mg, H, eps, c.st));
+    // graph self attention with the pairwise-distance bias (:391-393)
+    ETP_TRY(self_att_fwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, eps));
+    ETP_TRY(ffn_fwd(c, q.ffn, t.self.y, t.ffn, Mg, eps));
+    x = t.ffn.y;
+  }
+  // SAP head: Linear -> ReLU (GEMM epilogue) -> LN -> Linear(H->1) -> masks
+  ETP_TRY(linear_fwd(c, x, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
+  return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
+                      out_logits, s.str, Mg, H, c.st);
+}
+
+int etp_nav_bwd(etp_planner* p, const void* d_embeds, const float* d_logits, const void* gmap_embeds, const void* txt,
+                const uint8_t* txt_mask, const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited,
+                const float* dists, int B, int L, int G, void* d_txt, void* d_img, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && gmap_embeds && txt && txt_mask && step_ids && pos && gmask && visited && d_txt && d_img &&
+                  stash && ws && B > 0 && L > 0 && G > 0 && (d_embeds || d_logits),
+              "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  NavStash s = plan_nav(p, b, B, L, G);
+  Bump wb(ws);
+  NavWs n = plan_nav_ws(p, wb, B, L, G);
+  BwdWs& w = n.w;
+  const etp_config& cf = p->cfg;
+  const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
+  const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
+  const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
+  float* dspw = cf.use_sprels ? p->gf(p->sp_w) : nullptr;
+  float* dspb = cf.use_sprels ? p->gf(p->sp_b) : nullptr;
+  // head (gmap_embeds = output of the last x-layer, owned by the caller)
+  if (d_logits) {
+    ETP_TRY(sap_tail_bwd(c.dt, d_logits, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), s.str, visited, gmask,
+                         w.t1, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
+    ETP_TRY(linear_wgrad(c, w.t1, H, gmap_embeds, H, p->sap0_w, p->sap0_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, w.t1, H, p->sap0_w, w.g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, d_embeds, H));
+  } else {
+    ETP_CHECK_HIP(hipMemcpyAsync(w.g, d_embeds, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  }
+  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * c.es, c.st));
+  for (int l = cf.n_x - 1; l >= 0; --l) {
+    const XLayerP& q = p->xl[l];
+    const XStash& t = s.layers[l];
+    const void* x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
+    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, w.g, w.t1, w.dI));
+    ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, w.g,
+                         w.t1, w.t2, w.dqkv, w.dP));
+    // cross attention backward
+    ETP_TRY(ln_bwd(c.dt, w.g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1, p->gf(q.xln_g), p->gf(q.xln_b), Mg, H, c.st));
+    ETP_TRY(linear_wgrad(c, w.t1, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, w.t1, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+    AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
+              nullptr, nullptr};
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, n.dPx, n.dq, H, n.dkv, 2L * H, offs(n.dkv, H, c.es), 2L * H, 0.125f,
+                          nullptr, nullptr, c.st));
+    ETP_TRY(linear_wgrad(c, n.dq, H, x, H, q.q_w, q.q_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, n.dq, H, q.q_w, w.g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, w.t1, H));
+    ETP_TRY(linear_wgrad(c, n.dkv, 2 * H, txt, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
+    ETP_TRY(linear_dgrad(c, n.dkv, 2 * H, q.kv_w, d_txt, H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0,
+                         l == cf.n_x - 1 ? 0 : 1));
+  }
+  ETP_TRY(gmap_embed_bwd(c.dt, w.g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
+                         p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
+                         cf.ang_feat + 3, c.st));
+  ETP_CHECK_HIP(hipMemcpyAsync(d_img, w.g, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  return ETP_OK;
+}
+
+}  // extern "C"

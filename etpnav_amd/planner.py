@@ -1,0 +1,397 @@
+"""MI355X-native drop-in for the reference planner module.
+
+``GlocalTextPathNavCMT`` mirrors vlnce_baselines/models/etp/vilmodel_cmt.py:663-750:
+same constructor contract (a config object with the attributes set by
+vlnbert_init.py:32-59), same method names / argument order / return values
+(``forward_txt``, ``forward_panorama``, ``forward_navigation``), and the same
+state-dict names and shapes — but every parameter is a view
+into ONE flat fp32 arena in HBM and all arithmetic runs in the hand-written HIP
+kernels of libetpnav_hip.so through its C ABI.  There is no torch fallback: without
+the shared object (or without a GPU) the compute methods raise.
+
+Numerics modes (same kernels): ``dtype=torch.float32`` = parity mode (fp32 MFMA,
+matches the fp32 reference to ~1e-5); ``dtype=torch.bfloat16`` = performance mode
+(bf16 operands/activations, fp32 accumulation, statistics, logits and gradients —
+the MI355X counterpart of the reference's fp16 autocast, ss_trainer_ETP.py:502).
+Dropout layers of the reference are identity here (eval semantics) — see DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _cfg_get(config, name, default=None):
+    if isinstance(config, dict):
+        return config.get(name, default)
+    return getattr(config, name, default)
+
+
+def make_c_config(config, dtype: torch.dtype) -> _lib.Config:
+    """vis_config (vlnbert_init.py:32-59 + bert_config/*.json) -> etp_config."""
+    c = _lib.Config()
+    c.hidden = int(_cfg_get(config, "hidden_size", 768))
+    c.heads = int(_cfg_get(config, "num_attention_heads", 12))
+    c.inter = int(_cfg_get(config, "intermediate_size", 3072))
+    c.n_l = int(_cfg_get(config, "num_l_layers", 9))
+    c.n_p = int(_cfg_get(config, "num_pano_layers", 2))
+    c.n_x = int(_cfg_get(config, "num_x_layers", 4))
+    c.vocab = int(_cfg_get(config, "vocab_size", 30522))
+    c.max_pos = int(_cfg_get(config, "max_position_embeddings", 512))
+    c.type_vocab = int(_cfg_get(config, "type_vocab_size", 2))
+    c.img_feat = int(_cfg_get(config, "image_feat_size", 512))
+    c.dep_feat = int(_cfg_get(config, "depth_feat_size", 128))
+    c.ang_feat = int(_cfg_get(config, "angle_feat_size", 4))
+    c.max_steps = int(_cfg_get(config, "max_action_steps", 100))
+    c.use_depth = 1 if _cfg_get(config, "use_depth_embedding", True) else 0
+    c.use_sprels = 1 if _cfg_get(config, "graph_sprels", True) else 0
+    c.ln_eps = float(_cfg_get(config, "layer_norm_eps", 1e-12))
+    if dtype == torch.float32:
+        c.dtype = _lib.ETP_F32
+    elif dtype == torch.bfloat16:
+        c.dtype = _lib.ETP_BF16
+    else:
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    if c.hidden % c.heads != 0:
+        # same check / message as BertSelfAttention.__init__ (vilmodel_cmt.py:82-85)
+        raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                         % (c.hidden, c.heads))
+    return c
+
+
+class _Node(nn.Module):
+    """Plain container used to reproduce the reference's module tree (state-dict names)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("container module; call the planner's forward_* methods")
+
+
+class Engine:
+    """Owns the C planner handle, the flat arenas and the per-shape workspaces."""
+
+    def __init__(self, cconf: _lib.Config, device: torch.device):
+        self.L = _lib.lib()
+        self.cconf = cconf
+        self.device = device
+        self.handle = self.L.etp_planner_create(ctypes.byref(cconf))
+        if not self.handle:
+            raise _lib.EtpError("etp_planner_create: " + self.L.etp_last_error().decode())
+        n = self.L.etp_planner_param_count(self.handle)
+        self.table = []
+        info = _lib.ParamInfo()
+        for i in range(n):
+            check(self.L.etp_planner_param_info(self.handle, i, ctypes.byref(info)), "param_info")
+            shape = tuple(int(info.shape[k]) for k in range(info.ndim))
+            self.table.append((info.name.decode(), shape, int(info.offset)))
+        self.total = int(self.L.etp_planner_arena_elems(self.handle))
+        self.n_matrix = int(self.L.etp_planner_matrix_elems(self.handle))
+        self.tdtype = torch.bfloat16 if cconf.dtype == _lib.ETP_BF16 else torch.float32
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.shadow = (torch.zeros(self.n_matrix, dtype=torch.bfloat16, device=device)
+                       if cconf.dtype == _lib.ETP_BF16 else None)
+        self._shadow_version = -1
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.bind()
+
+    def bind(self):
+        if self.device.type == "cuda":
+            check(self.L.etp_planner_bind(self.handle, ptr(self.params), ptr(self.shadow), ptr(self.grads)), "bind")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.L.etp_planner_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def require_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.EtpError("the ETPNav planner kernels need an MI355X (cuda/hip device); no CPU fallback exists")
+
+    @staticmethod
+    def stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def refresh_weights(self, force: bool = False):
+        """bf16 mode: re-cast the GEMM weights when the fp32 masters changed (autocast's per-forward cast)."""
+        if self.shadow is None:
+            return
+        v = self.params._version
+        if force or v != self._shadow_version:
+            check(self.L.etp_planner_refresh_weights(self.handle, self.stream()), "refresh_weights")
+            self._shadow_version = self.params._version
+
+    def buf(self, nbytes: int) -> torch.Tensor:
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+
+    def ws(self, key: tuple, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self.buf(nbytes)
+            self._ws[key] = t
+        return t
+
+
+# ---- autograd bridges ------------------------------------------------------------------------
+class _TxtFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, txt_ids, txt_masks):
+        B, L = txt_ids.shape
+        H = eng.cconf.hidden
+        out = torch.empty(B, L, H, dtype=eng.tdtype, device=eng.device)
+        stash = eng.buf(eng.L.etp_txt_stash_bytes(eng.handle, B, L))
+        check(eng.L.etp_txt_fwd(eng.handle, ptr(txt_ids), ptr(txt_masks), B, L, ptr(out), ptr(stash), eng.stream()),
+              "etp_txt_fwd")
+        ctx.eng, ctx.stash, ctx.dims = eng, stash, (B, L)
+        ctx.save_for_backward(txt_ids, txt_masks)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, (B, L) = ctx.eng, ctx.dims
+        txt_ids, txt_masks = ctx.saved_tensors
+        dout = dout.to(eng.tdtype).contiguous()
+        ws = eng.ws(("txt", B, L), eng.L.etp_txt_ws_bytes(eng.handle, B, L))
+        check(eng.L.etp_txt_bwd(eng.handle, ptr(dout), ptr(txt_ids), ptr(txt_masks), B, L, ptr(ctx.stash), ptr(ws),
+                                eng.stream()), "etp_txt_bwd")
+        return None, None, None, None
+
+
+class _PanoFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, rgb, dep, loc, nav_types, view_lens):
+        B, V, _ = rgb.shape
+        H = eng.cconf.hidden
+        out = torch.empty(B, V, H, dtype=eng.tdtype, device=eng.device)
+        masks = torch.empty(B, V, dtype=torch.bool, device=eng.device)
+        stash = eng.buf(eng.L.etp_pano_stash_bytes(eng.handle, B, V))
+        check(eng.L.etp_pano_fwd(eng.handle, ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), ptr(view_lens), B, V, ptr(out),
+                                 ptr(masks), ptr(stash), eng.stream()), "etp_pano_fwd")
+        ctx.eng, ctx.stash, ctx.dims = eng, stash, (B, V)
+        ctx.need_rgb_grad = rgb.requires_grad
+        ctx.save_for_backward(rgb, dep, loc, nav_types)
+        ctx.mark_non_differentiable(masks)
+        return out, masks
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        eng, (B, V) = ctx.eng, ctx.dims
+        rgb, dep, loc, nav_types = ctx.saved_tensors
+        dout = dout.to(eng.tdtype).contiguous()
+        d_rgb = torch.empty(B, V, eng.cconf.img_feat, dtype=eng.tdtype, device=eng.device) if ctx.need_rgb_grad else None
+        ws = eng.ws(("pano", B, V), eng.L.etp_pano_ws_bytes(eng.handle, B, V))
+        check(eng.L.etp_pano_bwd(eng.handle, ptr(dout), ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), B, V, ptr(d_rgb),
+                                 ptr(ctx.stash), ptr(ws), eng.stream()), "etp_pano_bwd")
+        return None, None, (d_rgb.float() if d_rgb is not None else None), None, None, None, None
+
+
+class _NavFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, txt_embeds, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
+        B, L, H = txt_embeds.shape
+        G = step_ids.shape[1]
+        out = torch.empty(B, G, H, dtype=eng.tdtype, device=eng.device)
+        logits = torch.empty(B, G, dtype=torch.float32, device=eng.device)
+        stash = eng.buf(eng.L.etp_nav_stash_bytes(eng.handle, B, L, G))
+        check(eng.L.etp_nav_fwd(eng.handle, ptr(txt_embeds), ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts),
+                                ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(out), ptr(logits), ptr(stash),
+                                eng.stream()), "etp_nav_fwd")
+        ctx.eng, ctx.stash, ctx.dims = eng, stash, (B, L, G)
+        ctx.save_for_backward(txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists, out)
+        return out, logits
+
+    @staticmethod
+    def backward(ctx, d_out, d_logits):
+        eng, (B, L, G) = ctx.eng, ctx.dims
+        txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists, out = ctx.saved_tensors
+        H = eng.cconf.hidden
+        d_out = d_out.to(eng.tdtype).contiguous() if d_out is not None else None
+        d_logits = d_logits.float().contiguous() if d_logits is not None else None
+        d_txt = torch.empty(B, L, H, dtype=eng.tdtype, device=eng.device)
+        d_img = torch.empty(B, G, H, dtype=eng.tdtype, device=eng.device)
+        ws = eng.ws(("nav", B, L, G), eng.L.etp_nav_ws_bytes(eng.handle, B, L, G))
+        check(eng.L.etp_nav_bwd(eng.handle, ptr(d_out), ptr(d_logits), ptr(out), ptr(txt_embeds), ptr(txt_masks),
+                                ptr(step_ids), ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_txt),
+                                ptr(d_img), ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd")
+        return None, None, d_txt, None, None, d_img, None, None, None, None
+
+
+class GlocalTextPathNavCMT(nn.Module):
+    """Drop-in for vilmodel_cmt.py:663 ``GlocalTextPathNavCMT`` (see module docstring)."""
+
+    def __init__(self, config, dtype: torch.dtype = torch.bfloat16, device=None):
+        super().__init__()
+        self.config = config
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self._engine = Engine(make_c_config(config, dtype), torch.device(device))
+        self.compute_dtype = self._engine.tdtype
+        self._build_tree()
+        self.init_weights()
+        # vilmodel_cmt.py:675-682
+        if _cfg_get(config, "fix_lang_embedding", False):
+            for k, v in self.named_parameters():
+                if k.startswith("embeddings.") or k.startswith("lang_encoder."):
+                    v.requires_grad = False
+        if _cfg_get(config, "fix_pano_embedding", False):
+            for k, v in self.named_parameters():
+                if k.startswith("img_embeddings."):
+                    v.requires_grad = False
+        self._anchor = torch.zeros(1, device=self._engine.device, requires_grad=True)
+
+    # ---- parameter tree over the flat arena ---------------------------------------------------
+    def _build_tree(self):
+        eng = self._engine
+        self._views: List[tuple] = []
+        for name, shape, off in eng.table:
+            n = 1
+            for s in shape:
+                n *= s
+            p = nn.Parameter(eng.params[off:off + n].view(shape), requires_grad=True)
+            parts = name.split(".")
+            mod = self
+            for part in parts[:-1]:
+                if not hasattr(mod, part):
+                    mod.add_module(part, _Node())
+                mod = getattr(mod, part)
+            mod.register_parameter(parts[-1], p)
+            self._views.append((p, off, n, shape))
+        self._attach_grads(force=True)
+
+    def _attach_grads(self, force: bool = False):
+        """Point every ``param.grad`` at its slice of the flat gradient arena.  If an optimizer reset grads to
+        None (torch's default ``zero_grad(set_to_none=True)``, ss_trainer_ETP.py:499) the arena is zeroed first."""
+        eng = self._engine
+        lost = any(p.grad is None for p, _, _, _ in self._views if p.requires_grad)
+        if not (force or lost):
+            return
+        if lost and not force:
+            eng.grads.zero_()
+        for p, off, n, shape in self._views:
+            if p.requires_grad:
+                p.grad = eng.grads[off:off + n].view(shape)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self._engine.grads.zero_()
+        self._attach_grads(force=True)
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._engine.params
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        return self._engine.grads
+
+    def init_weights(self, seed: Optional[int] = None):
+        """BERT-style init (normal(0,0.02) weights, zero biases, LN = (1,0)) as the reference ctor's
+        ``self.init_weights()`` (vilmodel_cmt.py:673)."""
+        g = None
+        if seed is not None:
+            g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                is_ln = ("LayerNorm" in name or "layer_norm" in name or ".norm" in name
+                         or "gmap_pos_embeddings.1" in name or "global_sap_head.net.2" in name)
+                if is_ln:
+                    p.fill_(1.0 if name.endswith("weight") else 0.0)
+                elif name.endswith("bias"):
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+    def _apply(self, fn, recurse=True):
+        """``.to(device)`` / ``.cuda()``: move the arenas and rebuild the parameter views (dtype casts are refused:
+        the masters stay fp32, the compute dtype is chosen at construction)."""
+        eng = self._engine
+        new = fn(eng.params)
+        if new.dtype != torch.float32:
+            raise TypeError("the planner's master parameters stay fp32; choose the compute dtype at construction")
+        if new.device != eng.device:
+            with torch.no_grad():
+                eng.device = new.device
+                old_params = eng.params
+                eng.params = new.contiguous()
+                eng.grads = torch.zeros_like(eng.params)
+                if eng.shadow is not None:
+                    eng.shadow = torch.zeros(eng.n_matrix, dtype=torch.bfloat16, device=new.device)
+                eng._shadow_version = -1
+                eng._ws.clear()
+                for p, off, n, shape in self._views:
+                    p.data = eng.params[off:off + n].view(shape)
+                del old_params
+                self._anchor = torch.zeros(1, device=eng.device, requires_grad=True)
+                self._attach_grads(force=True)
+                eng.bind()
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        r = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self._engine._shadow_version = -1
+        return r
+
+    # ---- the three planner entry points -------------------------------------------------------
+    def _prep(self):
+        eng = self._engine
+        eng.require_gpu()
+        self._attach_grads()
+        eng.refresh_weights()
+        return eng
+
+    def forward_txt(self, txt_ids, txt_masks):
+        """vilmodel_cmt.py:684-688.  txt_ids [B,L] int64, txt_masks [B,L] bool -> [B,L,H]."""
+        eng = self._prep()
+        out = _TxtFn.apply(self._anchor, eng, txt_ids.contiguous(), txt_masks.to(torch.bool).contiguous())
+        if _cfg_get(self.config, "fix_lang_embedding", False):
+            out = out.detach()   # LanguageEncoder.forward :431-432
+        return out
+
+    def forward_panorama(self, rgb_fts, dep_fts, loc_fts, nav_types, view_lens):
+        """vilmodel_cmt.py:690-719 -> (pano_embeds [B,V,H], pano_masks [B,V] bool)."""
+        eng = self._prep()
+        dep = dep_fts.float().contiguous() if dep_fts is not None else None
+        return _PanoFn.apply(self._anchor, eng, rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
+                             nav_types.long().contiguous(), view_lens.long().contiguous())
+
+    def forward_navigation(self, txt_embeds, txt_masks, gmap_vpids, gmap_step_ids, gmap_img_fts, gmap_pos_fts,
+                           gmap_masks, gmap_visited_masks, gmap_pair_dists):
+        """vilmodel_cmt.py:721-750 (gmap_vpids is ignored, as in the reference)."""
+        eng = self._prep()
+        t = eng.tdtype
+        dists = gmap_pair_dists.float().contiguous() if gmap_pair_dists is not None else None
+        embeds, logits = _NavFn.apply(self._anchor, eng, txt_embeds.to(t).contiguous(),
+                                      txt_masks.to(torch.bool).contiguous(), gmap_step_ids.long().contiguous(),
+                                      gmap_img_fts.to(t).contiguous(), gmap_pos_fts.float().contiguous(),
+                                      gmap_masks.to(torch.bool).contiguous(),
+                                      gmap_visited_masks.to(torch.bool).contiguous(), dists)
+        return {"gmap_embeds": embeds, "global_logits": logits}
+
+    def forward(self, mode, batch, **kwargs):
+        # the reference's own forward (vilmodel_cmt.py:752-771) is dead code calling non-existent methods
+        raise NotImplementedError("use forward_txt / forward_panorama / forward_navigation")
+
+
+def default_config(task_type: str = "r2r", **overrides) -> SimpleNamespace:
+    """The vis_config of vlnbert_init.py:32-59 without HF: bert-base-uncased / xlm-roberta-base JSON values."""
+    cfg = dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
+               hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+               vocab_size=30522, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+               max_action_steps=100, image_feat_size=512, use_depth_embedding=True, depth_feat_size=128,
+               angle_feat_size=4, num_l_layers=9, num_pano_layers=2, num_x_layers=4, graph_sprels=True,
+               glocal_fuse="global", fix_lang_embedding=False, fix_pano_embedding=False, update_lang_bert=True,
+               output_attentions=True, pred_head_dropout_prob=0.1, use_lang2visn_attn=False)
+    if task_type == "rxr":
+        cfg.update(vocab_size=250002, max_position_embeddings=514, type_vocab_size=2, layer_norm_eps=1e-5)
+    elif task_type != "r2r":
+        raise ValueError("task_type must be 'r2r' or 'rxr'")
+    cfg.update(overrides)
+    return SimpleNamespace(**cfg)

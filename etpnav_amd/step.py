@@ -1,0 +1,162 @@
+"""One whole planner training step (the unit of BASELINE.json's metric) driven straight through the C ABI.
+
+``PlannerStep`` preallocates every buffer for a fixed (B, L, V, G) shape and runs
+
+    weight refresh (bf16) -> zero grads -> forward_txt -> forward_panorama -> node assembly (gather-mean)
+    -> forward_navigation -> cross-entropy(sum)/B -> backward of all of it into the flat gradient arena
+
+mirroring one rollout step of ss_trainer_ETP.py:801-892 plus the backward of :504.  Nothing is
+allocated or synchronised inside ``run_eager`` so the step can be captured into one hipGraph
+(``capture()`` / ``replay()``) — launch-bound inner loops replay from the graph instead of being re-issued.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+from .planner import GlocalTextPathNavCMT
+
+
+def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
+    """CSR (and its transpose) of the benchmark node assembly: node 0 = [stop] (empty), node 1 = mean of the valid
+    views (ss_trainer_ETP.py:838-839), node g>=2 = view (g-2) mod view_len (one-occurrence ghost nodes,
+    graph_utils.py:224-234).  Host-side index bookkeeping only (the reference does this in Python too)."""
+    B = view_lens.numel()
+    vl = [int(x) for x in view_lens.tolist()]
+    ptr_f, idx_f, w_f = [0], [], []
+    rev = [[] for _ in range(B * V)]
+    for b in range(B):
+        for g in range(G):
+            n = b * G + g
+            if g == 1:
+                for v in range(vl[b]):
+                    idx_f.append(b * V + v); w_f.append(1.0 / vl[b]); rev[b * V + v].append((n, 1.0 / vl[b]))
+            elif g >= 2:
+                v = (g - 2) % vl[b]
+                idx_f.append(b * V + v); w_f.append(1.0); rev[b * V + v].append((n, 1.0))
+            ptr_f.append(len(idx_f))
+    ptr_b, idx_b, w_b = [0], [], []
+    for r in rev:
+        for n, w in r:
+            idx_b.append(n); w_b.append(w)
+        ptr_b.append(len(idx_b))
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    return (i32(ptr_f), i32(idx_f), f32(w_f)), (i32(ptr_b), i32(idx_b), f32(w_b))
+
+
+class PlannerStep:
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor]):
+        self.model = model
+        eng = self.eng = model._engine
+        eng.require_gpu()
+        dev = eng.device
+        self.L = eng.L
+        self.B, self.Lt = batch["txt_ids"].shape
+        self.V = batch["rgb_fts"].shape[1]
+        self.G = batch["gmap_step_ids"].shape[1]
+        B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
+        t = eng.tdtype
+        mv = lambda x, dt=None: (x.to(dt) if dt is not None else x).contiguous().to(dev)
+        self.inp = {
+            "txt_ids": mv(batch["txt_ids"], torch.int64), "txt_masks": mv(batch["txt_masks"], torch.bool),
+            "rgb": mv(batch["rgb_fts"], torch.float32), "dep": mv(batch["dep_fts"], torch.float32),
+            "loc": mv(batch["loc_fts"], torch.float32), "nav": mv(batch["nav_types"], torch.int64),
+            "view_lens": mv(batch["view_lens"], torch.int64), "step_ids": mv(batch["gmap_step_ids"], torch.int64),
+            "pos": mv(batch["gmap_pos_fts"], torch.float32), "gmask": mv(batch["gmap_masks"], torch.bool),
+            "visited": mv(batch["gmap_visited_masks"], torch.bool), "dists": mv(batch["gmap_pair_dists"], torch.float32),
+            "labels": mv(batch["labels"], torch.int64),
+        }
+        (pf, xf, wf), (pb, xb, wb) = build_node_csr(batch["view_lens"].cpu(), V, G)
+        self.csr_f = tuple(x.to(dev) for x in (pf, xf, wf))
+        self.csr_b = tuple(x.to(dev) for x in (pb, xb, wb))
+        e = lambda *s, dt=t: torch.empty(*s, dtype=dt, device=dev)
+        self.txt = e(B, Lt, H); self.pano = e(B, V, H); self.pmask = e(B, V, dt=torch.bool)
+        self.gimg = e(B, G, H); self.gemb = e(B, G, H); self.logits = e(B, G, dt=torch.float32)
+        self.dlogits = e(B, G, dt=torch.float32); self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.d_txt = e(B, Lt, H); self.d_gimg = e(B, G, H); self.d_pano = e(B, V, H)
+        h = eng.handle
+        self.st_txt = eng.buf(self.L.etp_txt_stash_bytes(h, B, Lt))
+        self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, B, V))
+        self.st_nav = eng.buf(self.L.etp_nav_stash_bytes(h, B, Lt, G))
+        ws = max(self.L.etp_txt_ws_bytes(h, B, Lt), self.L.etp_pano_ws_bytes(h, B, V), self.L.etp_nav_ws_bytes(h, B, Lt, G))
+        self.ws = eng.buf(ws)
+        self.graph = None
+        self.stream = None
+
+    # ------------------------------------------------------------------------------------------
+    def run_eager(self, stream: Optional[int] = None, backward: bool = True):
+        """Enqueue one step on `stream` (default: torch's current stream)."""
+        L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
+        s = stream if stream is not None else eng.stream()
+        B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
+        dt = eng.cconf.dtype
+        check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
+        check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
+        if backward:
+            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s), "memset grads")
+        check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
+        check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), B, V,
+                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s), "pano_fwd")
+        pf, xf, wf = self.csr_f
+        check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
+        check(L.etp_nav_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
+                            ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.gemb), ptr(self.logits),
+                            ptr(self.st_nav), s), "nav_fwd")
+        check(L.etp_sap_ce(ptr(self.logits), ptr(i["labels"]), ptr(self.loss), ptr(self.dlogits) if backward else None, B, G,
+                           1.0 / B, -100, s), "sap_ce")
+        if not backward:
+            return
+        check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.gemb), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
+                            ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
+                            ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws), s), "nav_bwd")
+        pb, xb, wb = self.csr_b
+        check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), B * V, H, 0, s),
+              "node assembly bwd")
+        check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), B, V, None,
+                             ptr(self.st_pano), ptr(self.ws), s), "pano_bwd")
+        check(L.etp_txt_bwd(h, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.st_txt), ptr(self.ws), s),
+              "txt_bwd")
+
+    # ------------------------------------------------------------------------------------------
+    def capture(self, backward: bool = True):
+        """Warm up eagerly (sets kernel attributes), then capture the step into a hipGraph on a private stream."""
+        torch.cuda.synchronize()
+        self.run_eager(backward=backward)
+        torch.cuda.synchronize()
+        s = ctypes.c_void_p()
+        check(self.L.etp_stream_create(ctypes.byref(s)), "stream_create")
+        self.stream = s.value
+        check(self.L.etp_graph_begin(self.stream), "graph_begin")
+        try:
+            self.run_eager(stream=self.stream, backward=backward)
+        finally:
+            g = ctypes.c_void_p()
+            rc = self.L.etp_graph_end(self.stream, ctypes.byref(g))
+        check(rc, "graph_end")
+        self.graph = g.value
+        return self
+
+    def replay(self):
+        check(self.L.etp_graph_launch(self.graph, self.stream), "graph_launch")
+
+    def sync(self):
+        if self.stream is not None:
+            check(self.L.etp_stream_sync(self.stream), "stream_sync")
+        torch.cuda.synchronize()
+
+    def time_replays(self, iters: int) -> float:
+        """HIP-event time (ms) of `iters` back-to-back graph replays on the capture stream."""
+        ms = ctypes.c_float()
+        check(self.L.etp_graph_time(self.graph, self.stream, iters, ctypes.byref(ms)), "graph_time")
+        return float(ms.value)
+
+    def close(self):
+        if self.graph is not None:
+            self.L.etp_graph_destroy(self.graph); self.graph = None
+        if self.stream is not None:
+            self.L.etp_stream_destroy(self.stream); self.stream = None

@@ -1,0 +1,240 @@
+/* etpnav_hip.h — C ABI of the MI355X-native ETPNav planner hot path (libetpnav_hip.so).
+ *
+ * The reference (MarSaKi/ETPNav) is 100 % Python/PyTorch and has no FFI; the "interface each entry point
+ * replaces" is therefore the reference Python call site whose arithmetic it takes over (paths relative to
+ * the reference root).  Every function:
+ *   - takes raw device pointers (caller-owned, caller-allocated), plain integer sizes and a hipStream_t
+ *     passed as void*; no torch / C++ types cross the boundary;
+ *   - enqueues work on that stream and returns immediately (hipGraph-capturable: no allocation, no sync);
+ *   - returns 0 on success, <0 for an invalid argument, >0 for a hipError_t; etp_last_error() gives text.
+ * "T" below means the compute dtype selected by `dtype` (ETP_F32 parity mode, ETP_BF16 performance mode);
+ * parameters, statistics, logits and losses are always fp32.
+ */
+#ifndef ETPNAV_HIP_H
+#define ETPNAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETP_OK 0
+#define ETP_ERR_INVALID (-1)
+#define ETP_ERR_STATE (-2)
+
+#define ETP_F32 0
+#define ETP_BF16 1
+
+/* GEMM epilogue activations */
+#define ETP_ACT_NONE 0
+#define ETP_ACT_GELU 1      /* C = gelu_erf(v), aux Z = v            (BertIntermediate vilmodel_cmt.py:177-180) */
+#define ETP_ACT_RELU 2      /* C = relu(v)                           (NextActionPrediction :654-655)           */
+#define ETP_ACT_GELU_BWD 3  /* C = v * gelu_erf'(Z)                                                              */
+#define ETP_ACT_RELU_BWD 4  /* C = v * (Z > 0)                                                                   */
+
+typedef void* etp_stream_t; /* hipStream_t */
+
+const char* etp_version(void);
+const char* etp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Per-operator entry points (one per implicit device op of SURVEY.md §2.1)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* C[m,n] = epi(alpha * sum_k A[m,k]*B[n,k]); replaces every nn.Linear / torch.matmul on the path
+ * (vilmodel_cmt.py:108-110,117,133,151,178,190,326-328,335,348; common/transformer.py:138,140-142) and their
+ * autograd backward (dgrad / wgrad).  trans_a/trans_b = 1 means the operand is stored [K][rows]. */
+typedef struct etp_gemm_desc {
+  const void* A; const void* B; void* C;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int32_t trans_a, trans_b;
+  int32_t dtype;            /* operand dtype */
+  int32_t c_dtype;          /* output dtype (ETP_F32 allowed with bf16 operands: weight gradients) */
+  int32_t batch, batch_inner;               /* z -> (zo = z / batch_inner, zi = z % batch_inner) */
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi;     /* batch strides in elements */
+  int32_t ksplit;           /* >1: split the reduction, needs out_mode 2 */
+  float alpha;
+  const float* bias;        /* [N] or NULL */
+  const void* R; int64_t ldr; /* residual added after the activation, dtype T, or NULL */
+  void* Z; int64_t ldz;     /* aux tensor for the activation epilogues, dtype T */
+  int32_t act;              /* ETP_ACT_* */
+  int32_t out_mode;         /* 0 store, 1 C += v, 2 atomicAdd (fp32 C) */
+} etp_gemm_desc;
+int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream);
+
+/* db[n] += sum_m dY[m,n]  (bias gradient of every nn.Linear). */
+int etp_colsum(int dtype, const void* dy, int64_t ld, float* db, int M, int N, etp_stream_t stream);
+
+/* y = LayerNorm(x); stats[row] = {mean, rstd}.  BertLayerNorm / nn.LayerNorm: vilmodel_cmt.py:59,147,186,459-478,
+ * 571,656; common/transformer.py:144-145; common/ops.py:19-23. */
+int etp_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int H,
+               float eps, etp_stream_t stream);
+/* dx = LNbwd(dy) (+ add if non-NULL); dgamma/dbeta accumulated atomically. */
+int etp_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+               float* dgamma, float* dbeta, int M, int H, etp_stream_t stream);
+
+/* In-place masked row softmax over scores S[B,heads,Lq,ldS] (vilmodel_cmt.py:117-127,335-346,391-393,732-736):
+ *   s += keymask(b,k) + (sp_w*dist[b,q,k] + sp_b);  mask_mode 0: (1-m)*-10000 (ops.py:25-34), 1: -inf (MHA key padding).
+ * Columns [Lk, ldS) are written as 0. */
+int etp_softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b,
+                    int B, int heads, int Lq, int Lk, int ldS, int mask_mode, etp_stream_t stream);
+int etp_softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int heads,
+                    int Lq, int Lk, int ldS, etp_stream_t stream);
+
+/* softmax(alpha*Q.K^T + mask)V for [B,heads] problems with head dim 64, head-interleaved row layouts
+ * (BertSelfAttention / BertOutAttention / nn.MultiheadAttention).  P [B,heads,Lq,ldS] is saved for backward. */
+typedef struct etp_attn_desc {
+  int32_t dtype, B, heads, Lq, Lk, ldS;
+  const void* Q; int64_t ldq;   /* Q rows [B*Lq], head h at column h*64 */
+  const void* K; int64_t ldk;
+  const void* V; int64_t ldv;
+  void* P;                      /* [B,heads,Lq,ldS] scratch/saved probabilities */
+  void* ctx; int64_t ldc;       /* [B*Lq, heads*64] */
+  const uint8_t* keymask;       /* [B,Lk] 1 = valid */
+  int32_t mask_mode;
+  const float* dist;            /* [B,Lq,Lk] or NULL (graph_sprels) */
+  const float* sp_w; const float* sp_b;
+  float alpha;
+} etp_attn_desc;
+int etp_attn_fwd(const etp_attn_desc* d, etp_stream_t stream);
+typedef struct etp_attn_bwd_desc {
+  etp_attn_desc f;              /* same as forward (ctx unused) */
+  const void* dctx; int64_t ldd;
+  void* dP;                     /* scratch [B,heads,Lq,ldS] */
+  void* dQ; int64_t lddq; void* dK; int64_t lddk; void* dV; int64_t lddv;
+  float* d_sp_w; float* d_sp_b; /* accumulated, or NULL */
+} etp_attn_bwd_desc;
+int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t stream);
+
+/* BertEmbeddings.forward vilmodel_cmt.py:62-77 (eval): y = LN(word[id] + pos[l] + type[0]). */
+int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* beta, void* y, float* stats, int B, int L, int H, float eps,
+                       etp_stream_t stream);
+int etp_text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos,
+                       const float* type0, const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0,
+                       float* dgamma, float* dbeta, int B, int L, int H, etp_stream_t stream);
+
+/* Panorama view-embedding fuse, forward_panorama vilmodel_cmt.py:695-711:
+ *   y = LN(LN_i(a) + LN_d(d) + LN_l(loc.Wl^T+bl) + nav_emb[nav] + type_emb[1]); a,d = MFMA projections of rgb/depth.
+ * params / grads: 12 fp32 pointers in the order g_img,b_img,g_dep,b_dep,w_loc,bias_loc,g_loc,b_loc,nav_emb,type1,g_out,b_out.
+ * stats: [M,8]. */
+int etp_pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav,
+                       const float* const* params, void* y, float* stats, int M, int H, etp_stream_t stream);
+int etp_pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                       const float* stats, const float* const* params, float* const* grads, void* da, void* dd, int M, int H,
+                       etp_stream_t stream);
+
+/* forward_navigation vilmodel_cmt.py:728-730: x = img + step_emb[step] + LN(pos.Wp^T+bp). */
+int etp_gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats,
+                       int M, int H, int pos_dim, etp_stream_t stream);
+int etp_gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos,
+                       const float* b_pos, const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos,
+                       float* d_b_pos, float* dgamma, float* dbeta, int M, int H, int pos_dim, etp_stream_t stream);
+
+/* NextActionPrediction tail vilmodel_cmt.py:651-661 + masked_fill_ :742-744: logits = LN(r).w2 + b2, -inf where
+ * visited or !valid; r = relu(x.W1^T+b1) from etp_gemm(ETP_ACT_RELU). */
+int etp_sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
+                     const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H,
+                     etp_stream_t stream);
+int etp_sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
+                     const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
+                     float* dw2, float* db2, int M, int H, etp_stream_t stream);
+
+/* F.cross_entropy(reduction='sum', ignore_index) ss_trainer_ETP.py:892 scaled by `scale` (:1055):
+ * *loss += scale*sum_b nll_b ; dlogits = scale*(softmax - onehot) (0 on ignored rows); dlogits may be NULL. */
+int etp_sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale,
+               int64_t ignore_index, etp_stream_t stream);
+
+/* out[n,:] (+)= sum_{j in [ptr[n],ptr[n+1])} w[j]*src[idx[j],:] — node aggregation (ss_trainer_ETP.py:838-839,
+ * graph_utils.py:272-276, pretrain vilmodel.py:585-619) and, with the transposed CSR, its backward. */
+int etp_gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
+                   int accumulate, etp_stream_t stream);
+
+int etp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, etp_stream_t stream);
+int etp_cast_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, etp_stream_t stream);
+int etp_scale_f32(float* p, int64_t n, float scale, etp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Planner engine: whole forward/backward of the three planner entry points over one flat parameter arena.
+ * Replaces GlocalTextPathNavCMT.forward_txt / forward_panorama / forward_navigation (vilmodel_cmt.py:684-750)
+ * and their autograd backward.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct etp_config {
+  int32_t hidden, heads, inter;
+  int32_t n_l, n_p, n_x;                 /* text / panorama / cross-modal layer counts (vlnbert_init.py:46-48) */
+  int32_t vocab, max_pos, type_vocab;
+  int32_t img_feat, dep_feat, ang_feat, max_steps;
+  int32_t use_depth, use_sprels;
+  float ln_eps;                          /* config.layer_norm_eps (1e-12 bert / 1e-5 xlm-r) */
+  int32_t dtype;                         /* ETP_F32 | ETP_BF16 */
+} etp_config;
+
+typedef struct etp_param_info {
+  char name[128];                        /* reference state-dict name */
+  int32_t ndim; int64_t shape[2];
+  int64_t offset;                        /* element offset in the fp32 arena (and grad arena, and bf16 shadow) */
+} etp_param_info;
+
+typedef struct etp_planner etp_planner;
+
+etp_planner* etp_planner_create(const etp_config* cfg);      /* NULL on error */
+void etp_planner_destroy(etp_planner* p);
+int etp_planner_param_count(const etp_planner* p);
+int etp_planner_param_info(const etp_planner* p, int i, etp_param_info* out);
+int64_t etp_planner_arena_elems(const etp_planner* p);       /* total fp32 elements */
+int64_t etp_planner_matrix_elems(const etp_planner* p);      /* leading region holding the GEMM weights */
+/* params: fp32 master arena; shadow: bf16 copy of the matrix region (NULL in fp32 mode); grads: fp32 arena. */
+int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads);
+/* bf16 mode: refresh the bf16 shadow of the GEMM weights from the fp32 masters (autocast's per-step weight cast). */
+int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
+
+int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L);
+int64_t etp_txt_ws_bytes(const etp_planner* p, int B, int L);
+int etp_txt_fwd(etp_planner* p, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L, void* txt_embeds /*T [B,L,H]*/,
+                void* stash, etp_stream_t stream);
+int etp_txt_bwd(etp_planner* p, const void* d_txt_embeds, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L,
+                void* stash, void* ws, etp_stream_t stream);
+
+int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V);
+int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V);
+int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float* loc, const int64_t* nav_types,
+                 const int64_t* view_lens, int B, int V, void* pano_embeds /*T [B,V,H]*/, uint8_t* pano_masks /*[B,V]*/,
+                 void* stash, etp_stream_t stream);
+int etp_pano_bwd(etp_planner* p, const void* d_pano_embeds, const float* rgb, const float* dep, const float* loc,
+                 const int64_t* nav_types, int B, int V, void* d_rgb /*T [B,V,img_feat] or NULL*/, void* stash, void* ws,
+                 etp_stream_t stream);
+
+int64_t etp_nav_stash_bytes(const etp_planner* p, int B, int L, int G);
+int64_t etp_nav_ws_bytes(const etp_planner* p, int B, int L, int G);
+int etp_nav_fwd(etp_planner* p, const void* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                const void* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
+                const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G,
+                void* gmap_embeds /*T [B,G,H]*/, float* global_logits /*[B,G]*/, void* stash, etp_stream_t stream);
+int etp_nav_bwd(etp_planner* p, const void* d_gmap_embeds /*T or NULL*/, const float* d_logits /*or NULL*/,
+                const void* gmap_embeds /*forward output*/, const void* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
+                const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G,
+                void* d_txt_embeds /*T [B,L,H], overwritten*/, void* d_gmap_img_fts /*T [B,G,H], overwritten*/, void* stash,
+                void* ws, etp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * hipGraph helpers (launch-bound inner loops are captured once and replayed) and timing.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct etp_graph etp_graph;
+int etp_stream_create(etp_stream_t* out);
+int etp_stream_destroy(etp_stream_t s);
+int etp_stream_sync(etp_stream_t s);
+int etp_graph_begin(etp_stream_t s);
+int etp_graph_end(etp_stream_t s, etp_graph** out);
+int etp_graph_launch(etp_graph* g, etp_stream_t s);
+int etp_graph_destroy(etp_graph* g);
+int etp_memset_async(void* p, int value, int64_t bytes, etp_stream_t s);
+/* HIP-event timing on the given stream: elapsed ms of `iters` graph replays. */
+int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETPNAV_HIP_H */

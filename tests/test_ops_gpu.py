@@ -1,0 +1,299 @@
+"""Per-kernel parity on the MI355X: every C-ABI operator against plain torch math on the same inputs.
+
+fp32 kernels ("parity mode") are held to 2e-4 abs on O(1) data (fp32 round-off, k-ordered MFMA chains);
+bf16 kernels to the bf16 resolution of the result (documented per test).
+"""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from etpnav_amd import _lib  # noqa: E402
+from etpnav_amd._lib import GemmDesc, AttnDesc, AttnBwdDesc, check, ptr  # noqa: E402
+
+DEV = "cuda"
+
+
+def L():
+    return _lib.lib()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == _lib.ETP_BF16 else torch.float32
+
+
+def tol(dtype, scale=1.0):
+    return (3e-2 if dtype == _lib.ETP_BF16 else 2e-4) * scale
+
+
+def gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+def run_gemm(A, B, C, M, N, K, ta, tb, dtype, c_dtype=None, alpha=1.0, bias=None, R=None, Z=None, act=0, out_mode=0,
+             ksplit=1, batch=1, batch_inner=1, strides=(0, 0, 0, 0, 0, 0), lda=None, ldb=None, ldc=None):
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda = lda if lda is not None else A.stride(-2)
+    d.ldb = ldb if ldb is not None else B.stride(-2)
+    d.ldc = ldc if ldc is not None else C.stride(-2)
+    d.trans_a, d.trans_b = ta, tb
+    d.dtype = dtype
+    d.c_dtype = dtype if c_dtype is None else c_dtype
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi = strides
+    d.ksplit, d.alpha = ksplit, alpha
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.R = R.data_ptr() if R is not None else None
+    d.ldr = R.stride(-2) if R is not None else 0
+    d.Z = Z.data_ptr() if Z is not None else None
+    d.ldz = Z.stride(-2) if Z is not None else 0
+    d.act, d.out_mode = act, out_mode
+    check(L().etp_gemm(ctypes.byref(d), stream()), "etp_gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(20, 24, 64), (200, 136, 160), (256, 384, 512), (640, 768, 96)])
+def test_gemm_layouts(dtype, ta, tb, M, N, K):
+    """Asymmetric random operands (catches row/col swaps), ragged tiles, all storage pairings."""
+    torch.manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    t = tdt(dtype)
+    A = torch.randn(M, K, device=DEV).to(t)
+    B = torch.randn(N, K, device=DEV).to(t) * 0.5 + 0.1
+    ref = A.float() @ B.float().t()
+    As = A.t().contiguous() if ta else A
+    Bs = B.t().contiguous() if tb else B
+    # transposed operands need a leading dim that is a multiple of the 16-byte chunk
+    def pad_ld(X):
+        ld = (X.shape[1] + 7) // 8 * 8
+        buf = torch.zeros(X.shape[0], ld, device=DEV, dtype=t)
+        buf[:, :X.shape[1]] = X
+        return buf
+    As, Bs = pad_ld(As), pad_ld(Bs)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=t)
+    run_gemm(As, Bs, C, M, N, K, ta, tb, dtype)
+    err = (C.float() - ref).abs().max().item()
+    assert err <= tol(dtype, math.sqrt(K)), f"max err {err}"
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+def test_gemm_epilogues(dtype):
+    torch.manual_seed(0)
+    t = tdt(dtype)
+    M, N, K = 150, 200, 128
+    A = torch.randn(M, K, device=DEV).to(t)
+    B = (torch.randn(N, K, device=DEV) * 0.1).to(t)
+    bias = torch.randn(N, device=DEV)
+    R = torch.randn(M, N, device=DEV).to(t)
+    v = 0.5 * (A.float() @ B.float().t()) + bias
+    # bias + gelu (+ saved pre-activation) + residual
+    C = torch.empty(M, N, device=DEV, dtype=t); Z = torch.empty(M, N, device=DEV, dtype=t)
+    run_gemm(A, B, C, M, N, K, 0, 0, dtype, alpha=0.5, bias=bias, R=R, Z=Z, act=_lib.ACT_GELU)
+    assert (Z.float() - v).abs().max().item() <= tol(dtype, 4)
+    assert (C.float() - (gelu(v) + R.float())).abs().max().item() <= tol(dtype, 4)
+    # relu
+    run_gemm(A, B, C, M, N, K, 0, 0, dtype, alpha=0.5, bias=bias, act=_lib.ACT_RELU)
+    assert (C.float() - torch.relu(v)).abs().max().item() <= tol(dtype, 4)
+    # gelu backward / relu backward read Z
+    Zin = torch.randn(M, N, device=DEV).to(t)
+    raw = A.float() @ B.float().t()
+    run_gemm(A, B, C, M, N, K, 0, 0, dtype, Z=Zin, act=_lib.ACT_GELU_BWD)
+    assert (C.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= tol(dtype, 4)
+    run_gemm(A, B, C, M, N, K, 0, 0, dtype, Z=Zin, act=_lib.ACT_RELU_BWD)
+    assert (C.float() - raw * (Zin.float() > 0)).abs().max().item() <= tol(dtype, 4)
+    # accumulate into C
+    C0 = torch.randn(M, N, device=DEV).to(t); C = C0.clone()
+    run_gemm(A, B, C, M, N, K, 0, 0, dtype, out_mode=1)
+    assert (C.float() - (C0.float() + raw)).abs().max().item() <= tol(dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+def test_gemm_wgrad_splitk_fp32_out(dtype):
+    """dW[N,K] += dY[M,N]^T X[M,K]: TN storage, fp32 output, RMW and atomic split-K."""
+    torch.manual_seed(1)
+    t = tdt(dtype)
+    M, N, K = 1000, 192, 136
+    dY = torch.randn(M, N, device=DEV).to(t)
+    X = torch.randn(M, K, device=DEV).to(t)
+    ref = dY.float().t() @ X.float()
+    W0 = torch.randn(N, K, device=DEV)
+    for ks, mode in ((1, 1), (4, 2)):
+        W = W0.clone()
+        run_gemm(dY, X, W, N, K, M, 1, 1, dtype, c_dtype=_lib.ETP_F32, out_mode=mode, ksplit=ks)
+        err = (W - (W0 + ref)).abs().max().item()
+        assert err <= tol(dtype, math.sqrt(M) / 4), f"ksplit {ks}: {err}"
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("H", [768, 256])
+def test_layer_norm(dtype, H):
+    torch.manual_seed(2)
+    t = tdt(dtype)
+    M = 77
+    x = (torch.randn(M, H, device=DEV) * 2 + 0.3).to(t)
+    g = torch.randn(H, device=DEV); b = torch.randn(H, device=DEV)
+    y = torch.empty_like(x); stats = torch.empty(M, 2, device=DEV)
+    check(L().etp_ln_fwd(dtype, ptr(x), ptr(g), ptr(b), ptr(y), ptr(stats), M, H, 1e-12, stream()), "ln_fwd")
+    xr = x.float().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-12)
+    assert (y.float() - yr).abs().max().item() <= tol(dtype, 2)
+    assert (stats[:, 0] - x.float().mean(-1)).abs().max().item() < 1e-4
+    dy = torch.randn(M, H, device=DEV).to(t)
+    add = torch.randn(M, H, device=DEV).to(t)
+    yr.backward(dy.float())
+    dx = torch.empty_like(x); dg = torch.zeros(H, device=DEV); db = torch.zeros(H, device=DEV)
+    check(L().etp_ln_bwd(dtype, ptr(dy), ptr(x), ptr(stats), ptr(g), ptr(add), ptr(dx), ptr(dg), ptr(db), M, H, stream()),
+          "ln_bwd")
+    assert (dx.float() - (xr.grad + add.float())).abs().max().item() <= tol(dtype, 4)
+    assert (dg - gr.grad).abs().max().item() <= tol(dtype, 1) + 1e-3
+    assert (db - br.grad).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("mask_mode", [0, 1])
+def test_softmax(dtype, mask_mode):
+    torch.manual_seed(3)
+    t = tdt(dtype)
+    B, nh, Lq, Lk, ldS = 3, 4, 9, 13, 16
+    S = torch.full((B, nh, Lq, ldS), float("nan"), device=DEV, dtype=t)
+    S[..., :Lk] = torch.randn(B, nh, Lq, Lk, device=DEV).to(t)
+    km = torch.rand(B, Lk, device=DEV) > 0.3
+    km[:, 0] = True
+    dist = torch.rand(B, Lq, Lk, device=DEV)
+    w = torch.tensor([0.7], device=DEV); b0 = torch.tensor([-0.2], device=DEV)
+    s = S[..., :Lk].float() + (w * dist + b0)[:, None]
+    if mask_mode == 0:
+        s = s + (1.0 - km.float())[:, None, None, :] * -10000.0
+    else:
+        s = s.masked_fill(~km[:, None, None, :], float("-inf"))
+    sr = s.clone().requires_grad_(True)
+    pr = torch.softmax(sr, -1)
+    P = S.clone()
+    check(L().etp_softmax_fwd(dtype, ptr(P), ptr(km), ptr(dist), ptr(w), ptr(b0), B, nh, Lq, Lk, ldS, mask_mode, stream()),
+          "softmax_fwd")
+    assert (P[..., :Lk].float() - pr).abs().max().item() <= tol(dtype, 0.5)
+    assert (P[..., Lk:].float() == 0).all()
+    dP = torch.zeros_like(P)
+    dP[..., :Lk] = torch.randn(B, nh, Lq, Lk, device=DEV).to(t)
+    pr2 = P[..., :Lk].float().detach().requires_grad_(True)
+    # reference backward from the kernel's own (rounded) P so the check isolates the backward math
+    dot = (pr2 * dP[..., :Lk].float()).sum(-1, keepdim=True)
+    ds_ref = pr2 * (dP[..., :Lk].float() - dot)
+    dw = torch.zeros(1, device=DEV); db = torch.zeros(1, device=DEV)
+    check(L().etp_softmax_bwd(dtype, ptr(P), ptr(dP), ptr(dist), ptr(dw), ptr(db), B, nh, Lq, Lk, ldS, stream()), "softmax_bwd")
+    assert (dP[..., :Lk].float() - ds_ref).abs().max().item() <= tol(dtype, 1)
+    assert (dP[..., Lk:].float() == 0).all()
+    assert abs(dw.item() - (ds_ref.sum(1) * dist).sum().item()) <= tol(dtype, 2) + 1e-3
+    assert abs(db.item() - ds_ref.sum().item()) <= tol(dtype, 2) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("Lq,Lk", [(80, 80), (9, 20), (36, 36), (16, 512)])
+def test_attention_fwd_bwd(dtype, Lq, Lk):
+    """softmax(QK^T/8 + mask + sprel)V and its backward against torch autograd (head dim 64)."""
+    torch.manual_seed(4)
+    t = tdt(dtype)
+    B, nh, dh = 2, 3, 64
+    H = nh * dh
+    ldS = (Lk + 7) // 8 * 8
+    q = torch.randn(B * Lq, H, device=DEV).to(t)
+    kv = torch.randn(B * Lk, 2 * H, device=DEV).to(t)
+    km = torch.rand(B, Lk, device=DEV) > 0.2
+    km[:, 0] = True
+    dist = torch.rand(B, Lq, Lk, device=DEV)
+    w = torch.tensor([0.3], device=DEV); b0 = torch.tensor([0.1], device=DEV)
+    qr = q.float().requires_grad_(True); kvr = kv.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True); br = b0.clone().requires_grad_(True)
+    qh = qr.view(B, Lq, nh, dh).permute(0, 2, 1, 3)
+    kh = kvr[:, :H].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    vh = kvr[:, H:].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / 8.0 + (1.0 - km.float())[:, None, None, :] * -10000.0 + (wr * dist + br)[:, None]
+    ctx_ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Lq, H)
+    P = torch.empty(B, nh, Lq, ldS, device=DEV, dtype=t)
+    ctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
+    d = AttnDesc()
+    d.dtype, d.B, d.heads, d.Lq, d.Lk, d.ldS = dtype, B, nh, Lq, Lk, ldS
+    d.Q, d.ldq = q.data_ptr(), H
+    d.K, d.ldk = kv.data_ptr(), 2 * H
+    d.V, d.ldv = kv.data_ptr() + H * q.element_size(), 2 * H
+    d.P, d.ctx, d.ldc = P.data_ptr(), ctx.data_ptr(), H
+    d.keymask, d.mask_mode = km.data_ptr(), 0
+    d.dist, d.sp_w, d.sp_b = dist.data_ptr(), w.data_ptr(), b0.data_ptr()
+    d.alpha = 0.125
+    check(L().etp_attn_fwd(ctypes.byref(d), stream()), "attn_fwd")
+    torch.cuda.synchronize()
+    assert (ctx.float() - ctx_ref).abs().max().item() <= tol(dtype, 2)
+    dctx = torch.randn(B * Lq, H, device=DEV).to(t)
+    ctx_ref.backward(dctx.float())
+    bd = AttnBwdDesc()
+    bd.f = d
+    dP = torch.empty_like(P); dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+    dw = torch.zeros(1, device=DEV); db = torch.zeros(1, device=DEV)
+    bd.dctx, bd.ldd, bd.dP = dctx.data_ptr(), H, dP.data_ptr()
+    bd.dQ, bd.lddq = dq.data_ptr(), H
+    bd.dK, bd.lddk = dkv.data_ptr(), 2 * H
+    bd.dV, bd.lddv = dkv.data_ptr() + H * q.element_size(), 2 * H
+    bd.d_sp_w, bd.d_sp_b = dw.data_ptr(), db.data_ptr()
+    check(L().etp_attn_bwd(ctypes.byref(bd), stream()), "attn_bwd")
+    torch.cuda.synchronize()
+    sc = 4 if dtype == _lib.ETP_F32 else 3
+    assert (dq.float() - qr.grad).abs().max().item() <= tol(dtype, sc)
+    assert (dkv.float() - kvr.grad).abs().max().item() <= tol(dtype, sc)
+    assert abs(dw.item() - wr.grad.item()) <= tol(dtype, 4) + 2e-3
+    assert abs(db.item() - br.grad.item()) <= tol(dtype, 4) + 2e-3
+
+
+def test_cross_entropy_and_gather():
+    torch.manual_seed(5)
+    B, G = 7, 11
+    logits = torch.randn(B, G, device=DEV)
+    logits[:, 1] = float("-inf")
+    labels = torch.randint(2, G, (B,), device=DEV)
+    labels[3] = -100
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, reduction="sum", ignore_index=-100) / B
+    ref.backward()
+    loss = torch.zeros(1, device=DEV); dl = torch.empty(B, G, device=DEV)
+    check(L().etp_sap_ce(ptr(logits), ptr(labels), ptr(loss), ptr(dl), B, G, 1.0 / B, -100, stream()), "sap_ce")
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert (dl - lr.grad).abs().max().item() < 1e-6
+    # gather-sum
+    for dtype in (_lib.ETP_F32, _lib.ETP_BF16):
+        t = tdt(dtype)
+        src = torch.randn(10, 768, device=DEV).to(t)
+        p = torch.tensor([0, 0, 3, 4], dtype=torch.int32, device=DEV)
+        idx = torch.tensor([1, 5, 9, 2], dtype=torch.int32, device=DEV)
+        w = torch.tensor([0.5, 0.25, 0.25, 2.0], device=DEV)
+        out = torch.full((3, 768), float("nan"), device=DEV, dtype=t)
+        check(L().etp_gather_sum(dtype, ptr(src), ptr(p), ptr(idx), ptr(w), ptr(out), 3, 768, 0, stream()), "gather_sum")
+        s = src.float()
+        ref = torch.stack([torch.zeros(768, device=DEV), 0.5 * s[1] + 0.25 * s[5] + 0.25 * s[9], 2 * s[2]])
+        assert (out.float() - ref).abs().max().item() <= tol(dtype, 0.5)
+
+
+def test_colsum_and_cast():
+    torch.manual_seed(6)
+    for dtype in (_lib.ETP_F32, _lib.ETP_BF16):
+        t = tdt(dtype)
+        dy = torch.randn(333, 776, device=DEV).to(t)
+        db = torch.ones(776, device=DEV)
+        check(L().etp_colsum(dtype, ptr(dy), 776, ptr(db), 333, 776, stream()), "colsum")
+        assert (db - (1 + dy.float().sum(0))).abs().max().item() < 2e-3
+    x = torch.randn(100003, device=DEV)
+    y = torch.empty(100003, device=DEV, dtype=torch.bfloat16)
+    check(L().etp_cast_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream()), "cast")
+    assert torch.equal(y, x.to(torch.bfloat16))
