@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py — planner fwd+bwd steps/sec on synthetic R2R-CE-shaped batches (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = forward_txt + forward_panorama + node assembly + forward_navigation + CE(sum)/B + the backward of all of
+it into the flat gradient arena (incl. the bf16 refresh of the GEMM weights and zeroing of the gradients), on one
+batch of synthetic input resident in HBM; with N > 1 (one process per GPU, launched by torch.distributed.run) each
+rank owns its own batch (weak scaling = the reference's per-rank batch semantics) and the step ends when the RCCL
+gradient mean has completed.  Workload at N=1: BASELINE.json configs[1] (B=32, 36 views x 768-d, 80 tokens, 16 nodes,
+bf16).  Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the CPU
+oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[1]/[2]
+    "c2": dict(task="r2r", B=32, L=80, V=36, G=16, image_feat_size=768),
+    # configs[4] per-GPU shape
+    "c5": dict(task="r2r", B=8, L=80, V=36, G=64, image_feat_size=768),
+    # configs[3] per-GPU shape
+    "c4": dict(task="rxr", B=16, L=512, V=36, G=16, image_feat_size=768),
+}
+
+
+def flops_per_step(w, cfg):
+    """Algorithmic FLOPs (2MNK per product, bwd = 2x fwd) — SURVEY.md Appendix C."""
+    H, I, B, L, V, G = cfg.hidden_size, cfg.intermediate_size, w["B"], w["L"], w["V"], w["G"]
+    lin = 8 * H * H + 4 * H * I
+    lang = cfg.num_l_layers * (B * L * lin + B * 4 * L * L * H)
+    pano = B * V * 2 * H * (cfg.image_feat_size + cfg.depth_feat_size + 4) + cfg.num_pano_layers * (B * V * lin + B * 4 * V * V * H)
+    xl = cfg.num_x_layers * (B * G * 4 * H * H + B * L * 4 * H * H + B * 4 * G * L * H + B * G * 8 * H * H + B * 4 * G * G * H
+                             + B * G * 4 * H * I)
+    head = B * G * (2 * H * H + 2 * H)
+    return 3.0 * (lang + pano + xl + head)
+
+
+def cpu_baseline(w, cfg_kwargs, budget_s=25.0):
+    """Time the CPU oracle (test infrastructure; the checker, not the product) on the same workload."""
+    from oracle import planner_oracle as po
+    ocfg = po.PlannerConfig.rxr(**cfg_kwargs) if w["task"] == "rxr" else po.PlannerConfig.r2r(**cfg_kwargs)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = po.init_params(ocfg, seed=0)
+    batch = po.make_batch(ocfg, B=w["B"], L=w["L"], V=w["V"], G=w["G"], seed=1234)
+    t0 = time.time()
+    po.step_with_grads(P, ocfg, batch)            # warm-up
+    warm = time.time() - t0
+    n = max(1, min(8, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(n):
+        po.step_with_grads(P, ocfg, batch)
+    dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed fwd+bwd steps (after 1 warm-up) of the same workload, fp32 torch CPU oracle "
+                      f"(oracle/planner_oracle.py), {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="issue kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://")
+
+    from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
+    from etpnav_amd.step import PlannerStep
+    from etpnav_amd.synthetic import make_batch
+    from etpnav_amd import _lib, dp
+
+    w = WORKLOADS[args.workload]
+    cfg = default_config(w["task"], image_feat_size=w["image_feat_size"])
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = GlocalTextPathNavCMT(cfg, dtype=tdt, device=f"cuda:{local_rank}")
+    model.init_weights(seed=0)                                   # same weights on every rank (DDP's broadcast)
+    batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
+                       seed=1234 + rank)                          # each rank owns its episodes
+    step = PlannerStep(model, batch)
+    reducer = None
+    if world > 1:
+        ranges, sparse = dp.planner_buckets(model)
+        reducer = dp.GradReducer(model.flat_grads, ranges,
+                                 comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
+                                 sparse_rows=sparse)
+    use_graph = not args.no_graph
+    if use_graph:
+        step.capture(split_text_bwd=world > 1)
+
+    def one_step():
+        if world == 1:
+            step.replay() if use_graph else step.run_eager()
+            return
+        if use_graph:
+            step.replay(part=0)
+        else:
+            step.enqueue_main(model._engine.stream())
+        reducer.reduce_bucket(0)                                 # non-text matrices: overlaps the text backward
+        if use_graph:
+            step.replay(part=1)
+        else:
+            step.enqueue_txt_bwd(model._engine.stream())
+        for i in range(1, len(reducer.ranges)):
+            reducer.reduce_bucket(i)
+        reducer.reduce_sparse_rows(step.inp["txt_ids"])
+        reducer.finish()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(step.loss.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline leg: HIP-event timing of every GEMM launch over eager steps (rank 0) ----
+    roofline, gemm_table = None, []
+    if rank == 0:
+        L = _lib.lib()
+        step.run_eager(); torch.cuda.synchronize()
+        L.etp_prof_reset(); L.etp_prof_enable(1)
+        nprof = 3
+        for _ in range(nprof):
+            step.run_eager()
+        torch.cuda.synchronize()
+        L.etp_prof_enable(0)
+        ents = (_lib.ProfEntry * 64)()
+        n = L.etp_prof_report(ents, 64)
+        L.etp_prof_reset()
+        for e in list(ents)[:n]:
+            gemm_table.append({"kernel": e.name.decode(), "launches_per_step": e.launches / nprof,
+                               "avg_us": e.ms / e.launches * 1e3, "ms_per_step": e.ms / nprof,
+                               "tflops": e.flops / (e.ms * 1e-3) / 1e12, "alg_gbs": e.bytes / (e.ms * 1e-3) / 1e9})
+        gemm_table.sort(key=lambda r: -r["ms_per_step"])
+        if gemm_table:
+            d = gemm_table[0]
+            roofline = {"kernel": d["kernel"], "bound": "mfma", "achieved": round(d["tflops"], 2), "peak": PEAK_BF16_TFLOPS
+                        if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                        "frac": round(d["tflops"] / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                        "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches_per_step"],
+                        "traffic": None,
+                        "note": "achieved = algorithmic 2MNK FLOPs of every launch of this kernel in a step / summed "
+                                "HIP-event durations (events on the launch stream, eager replays after the timed region)"}
+
+    out = None
+    if rank == 0:
+        fl = flops_per_step(w, cfg)
+        out = {
+            "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
+            "value": round(world * 1.0 / (ms_per_step * 1e-3), 3) if False else round(args.steps / elapsed * world, 3),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
+                                   f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
+                                   f"{w['task']} planner 9/2/4 layers, random-init weights",
+                       "global_batch": w["B"] * world, "parallelism": f"dp{world}",
+                       "graph": use_graph, "grad_comm_dtype": args.comm_dtype if world > 1 else None},
+            "loss": round(loss, 5),
+            "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
+            "model_flops_per_step": fl,
+            "roofline": roofline,
+            "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, dict(image_feat_size=w["image_feat_size"]))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    step.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,11 @@ class ParamInfo(ctypes.Structure):
                 ("offset", ctypes.c_int64)]
 
 
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96), ("launches", ctypes.c_int64), ("ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 # ---- header parsing --------------------------------------------------------------------------
 _SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
             "etp_stream_t": ctypes.c_void_p}

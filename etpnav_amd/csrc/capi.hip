@@ -215,4 +215,11 @@ int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out) {
   return ETP_OK;
 }
 
+int etp_prof_enable(int on) { prof_enable(on != 0); return ETP_OK; }
+int etp_prof_reset(void) { prof_reset(); return ETP_OK; }
+int etp_prof_report(etp_prof_entry* out, int cap) {
+  if (!out || cap <= 0) return 0;
+  return prof_report(out, cap);
+}
+
 }  // extern "C"

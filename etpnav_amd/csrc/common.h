@@ -109,5 +109,8 @@ struct GemmArgs {
   int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
+void prof_enable(bool on);
+void prof_reset();
+int prof_report(etp_prof_entry* out, int cap);
 
 }  // namespace etp

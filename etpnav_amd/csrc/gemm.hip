@@ -21,6 +21,12 @@
 //     backward forms, residual add, fp32 accumulate / atomic split-K for wgrad.
 // The lane->k assignment is the same for every read mode (group g = lane>>4, element e:
 // k = 32*s + 8*g + e), so any A/B storage pairing is consistent.
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.h"
 
 namespace etp {
@@ -257,6 +263,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   }
 }
 
+// ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
+struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<std::string> g_prof_names;
+static std::mutex g_prof_mu;
+
+void prof_enable(bool on) { g_prof_on = on; }
+void prof_reset() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof_recs.clear();
+}
+static int prof_id(const std::string& name) {
+  for (size_t i = 0; i < g_prof_names.size(); ++i)
+    if (g_prof_names[i] == name) return (int)i;
+  g_prof_names.push_back(name);
+  return (int)g_prof_names.size() - 1;
+}
+int prof_report(etp_prof_entry* out, int cap) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::vector<etp_prof_entry> agg(g_prof_names.size());
+  for (size_t i = 0; i < agg.size(); ++i) {
+    memset(&agg[i], 0, sizeof(etp_prof_entry));
+    strncpy(agg[i].name, g_prof_names[i].c_str(), sizeof(agg[i].name) - 1);
+  }
+  for (auto& r : g_prof_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    agg[r.id].launches += 1; agg[r.id].ms += ms; agg[r.id].flops += r.flops; agg[r.id].bytes += r.bytes;
+  }
+  int n = 0;
+  for (auto& e : agg)
+    if (e.launches > 0 && n < cap) out[n++] = e;
+  return n;
+}
+
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   using GA = TileGeom<T, TA, BM>;
@@ -270,8 +314,27 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   dim3 grid(tiles, nbatch * g.ksplit, 1);
+  ProfRec rec;
+  const bool prof = g_prof_on;
+  if (prof) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "gemm<%s,%s,%s%s,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
+             TA ? "T" : "N", TB ? "N" : "T", BM, BN);   // BLAS-style: opA,opB of C = opA(A) opB(B)
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    rec.id = prof_id(nm);
+    rec.flops = 2.0 * g.M * g.N * g.K * nbatch;
+    rec.bytes = ((double)g.M * g.K + (double)g.N * g.K) * nbatch * sizeof(T) + (double)g.M * g.N * nbatch * sizeof(TC);
+    ETP_CHECK_HIP(hipEventCreate(&rec.a));
+    ETP_CHECK_HIP(hipEventCreate(&rec.b));
+    ETP_CHECK_HIP(hipEventRecord(rec.a, st));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
   ETP_CHECK_LAUNCH("gemm");
+  if (prof) {
+    ETP_CHECK_HIP(hipEventRecord(rec.b, st));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(rec);
+  }
   return ETP_OK;
 }
 

@@ -86,13 +86,14 @@ class PlannerStep:
         ws = max(self.L.etp_txt_ws_bytes(h, B, Lt), self.L.etp_pano_ws_bytes(h, B, V), self.L.etp_nav_ws_bytes(h, B, Lt, G))
         self.ws = eng.buf(ws)
         self.graph = None
+        self.graphs = []
         self.stream = None
 
     # ------------------------------------------------------------------------------------------
-    def run_eager(self, stream: Optional[int] = None, backward: bool = True):
-        """Enqueue one step on `stream` (default: torch's current stream)."""
+    def enqueue_main(self, s: int, backward: bool = True):
+        """Everything except the text-encoder backward: weight refresh, zero grads, the three forwards, loss and the
+        navigation + panorama backward (their gradients are complete when this returns to the stream)."""
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
-        s = stream if stream is not None else eng.stream()
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
         dt = eng.cconf.dtype
         check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
@@ -119,30 +120,55 @@ class PlannerStep:
               "node assembly bwd")
         check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), B, V, None,
                              ptr(self.st_pano), ptr(self.ws), s), "pano_bwd")
-        check(L.etp_txt_bwd(h, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.st_txt), ptr(self.ws), s),
-              "txt_bwd")
+
+    def enqueue_txt_bwd(self, s: int):
+        L, eng, i = self.L, self.eng, self.inp
+        check(L.etp_txt_bwd(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
+                            ptr(self.st_txt), ptr(self.ws), s), "txt_bwd")
+
+    def run_eager(self, stream: Optional[int] = None, backward: bool = True):
+        """Enqueue one step on `stream` (default: torch's current stream)."""
+        s = stream if stream is not None else self.eng.stream()
+        self.enqueue_main(s, backward)
+        if backward:
+            self.enqueue_txt_bwd(s)
 
     # ------------------------------------------------------------------------------------------
-    def capture(self, backward: bool = True):
-        """Warm up eagerly (sets kernel attributes), then capture the step into a hipGraph on a private stream."""
+    def _capture_one(self, fn):
+        check(self.L.etp_graph_begin(self.stream), "graph_begin")
+        try:
+            fn(self.stream)
+        finally:
+            g = ctypes.c_void_p()
+            rc = self.L.etp_graph_end(self.stream, ctypes.byref(g))
+        check(rc, "graph_end")
+        return g.value
+
+    def capture(self, backward: bool = True, split_text_bwd: bool = False):
+        """Warm up eagerly (sets kernel attributes), then capture the step into hipGraph(s) on a private stream.
+        With split_text_bwd the text-encoder backward is a second graph so that a gradient all-reduce of everything
+        else can be issued between the two (data-parallel overlap)."""
         torch.cuda.synchronize()
         self.run_eager(backward=backward)
         torch.cuda.synchronize()
         s = ctypes.c_void_p()
         check(self.L.etp_stream_create(ctypes.byref(s)), "stream_create")
         self.stream = s.value
-        check(self.L.etp_graph_begin(self.stream), "graph_begin")
-        try:
-            self.run_eager(stream=self.stream, backward=backward)
-        finally:
-            g = ctypes.c_void_p()
-            rc = self.L.etp_graph_end(self.stream, ctypes.byref(g))
-        check(rc, "graph_end")
-        self.graph = g.value
+        self.graphs = []
+        if backward and split_text_bwd:
+            self.graphs.append(self._capture_one(lambda st: self.enqueue_main(st, True)))
+            self.graphs.append(self._capture_one(self.enqueue_txt_bwd))
+        else:
+            self.graphs.append(self._capture_one(lambda st: self.run_eager(stream=st, backward=backward)))
+        self.graph = self.graphs[0]
         return self
 
-    def replay(self):
-        check(self.L.etp_graph_launch(self.graph, self.stream), "graph_launch")
+    def replay(self, part: Optional[int] = None, stream: Optional[int] = None):
+        """Launch the captured graph(s) on `stream` (default: torch's current stream, so torch ops order after it)."""
+        s = stream if stream is not None else self.eng.stream()
+        for k, g in enumerate(self.graphs):
+            if part is None or part == k:
+                check(self.L.etp_graph_launch(g, s), "graph_launch")
 
     def sync(self):
         if self.stream is not None:
@@ -150,13 +176,15 @@ class PlannerStep:
         torch.cuda.synchronize()
 
     def time_replays(self, iters: int) -> float:
-        """HIP-event time (ms) of `iters` back-to-back graph replays on the capture stream."""
+        """HIP-event time (ms) of `iters` back-to-back replays of the single-graph step on the capture stream."""
+        assert len(self.graphs) == 1
         ms = ctypes.c_float()
-        check(self.L.etp_graph_time(self.graph, self.stream, iters, ctypes.byref(ms)), "graph_time")
+        check(self.L.etp_graph_time(self.graphs[0], self.stream, iters, ctypes.byref(ms)), "graph_time")
         return float(ms.value)
 
     def close(self):
-        if self.graph is not None:
-            self.L.etp_graph_destroy(self.graph); self.graph = None
+        for g in getattr(self, "graphs", []) or []:
+            self.L.etp_graph_destroy(g)
+        self.graphs, self.graph = [], None
         if self.stream is not None:
             self.L.etp_stream_destroy(self.stream); self.stream = None

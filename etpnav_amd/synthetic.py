@@ -1,0 +1,47 @@
+"""Seeded synthetic planner inputs with the shapes/dtypes of the reference's batches.
+
+There are no R2R-CE features or checkpoints offline, so benchmarks and smoke tests use these: token ids uniform
+in [1000, vocab-1), N(0,1) view features, angle features [sin h, cos h, sin e, cos e] on the 12x3 panorama grid
+(pretrain_src/.../data/common.py:51-68), candidate views first (ss_trainer_ETP.py:308-342), symmetric pair distances
+with a zero [stop] row/column (ss_trainer_ETP.py:371-387).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+
+def make_batch(vocab_size: int, image_feat_size: int, depth_feat_size: int, B: int, L: int, V: int, G: int,
+               seed: int = 1234, ragged: bool = False, n_cand: int = 4) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, vocab_size - 1, (B, L), generator=g)
+    if ragged:
+        tl = torch.randint(max(L // 2, 1), L + 1, (B,), generator=g); tl[0] = L
+        vl = torch.randint(max(V - 6, 1), V + 1, (B,), generator=g); vl[0] = V
+        gl = torch.randint(max(G // 2, 3), G + 1, (B,), generator=g); gl[0] = G
+    else:
+        tl, vl, gl = torch.full((B,), L), torch.full((B,), V), torch.full((B,), G)
+    ar = lambda n: torch.arange(n)[None, :]
+    tmask, vmask, gmask = ar(L) < tl[:, None], ar(V) < vl[:, None], ar(G) < gl[:, None]
+    ids = ids * tmask
+    rgb = torch.randn(B, V, image_feat_size, generator=g) * vmask[..., None]
+    dep = torch.randn(B, V, depth_feat_size, generator=g) * vmask[..., None]
+    v = torch.arange(V)
+    heading = 2 * math.pi * (v % 12) / 12
+    elev = ((v // 12) % 3 - 1) * (math.pi / 6)
+    loc = torch.stack([heading.sin(), heading.cos(), elev.sin(), elev.cos()], -1)[None].repeat(B, 1, 1) * vmask[..., None]
+    nav = torch.zeros(B, V, dtype=torch.long); nav[:, :n_cand] = 1
+    nav = nav * vmask
+    step_ids = torch.zeros(B, G, dtype=torch.long); step_ids[:, 1] = 1
+    pos = torch.randn(B, G, 7, generator=g) * gmask[..., None]
+    d = torch.rand(B, G, G, generator=g)
+    d = (d + d.transpose(1, 2)) * 0.5
+    d[:, 0, :] = 0; d[:, :, 0] = 0
+    d = d * (1 - torch.eye(G))[None] * gmask[:, :, None] * gmask[:, None, :]
+    visited = torch.zeros(B, G, dtype=torch.bool); visited[:, 1] = True
+    labels = torch.full((B,), 2, dtype=torch.long)
+    return {"txt_ids": ids, "txt_masks": tmask, "rgb_fts": rgb, "dep_fts": dep, "loc_fts": loc, "nav_types": nav,
+            "view_lens": vl, "gmap_step_ids": step_ids, "gmap_pos_fts": pos, "gmap_masks": gmask,
+            "gmap_visited_masks": visited, "gmap_pair_dists": d, "labels": labels}

@@ -234,6 +234,18 @@ int etp_memset_async(void* p, int value, int64_t bytes, etp_stream_t s);
 /* HIP-event timing on the given stream: elapsed ms of `iters` graph replays. */
 int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out);
 
+/* Per-launch HIP-event timing of the MFMA GEMM family (events recorded on the launch stream; eager launches only —
+ * do not enable during graph capture).  etp_prof_report synchronises the recorded events and returns one entry per
+ * kernel instantiation: launches, summed ms, summed algorithmic FLOPs and algorithmic bytes (A+B+C once). */
+typedef struct etp_prof_entry {
+  char name[96];
+  int64_t launches;
+  double ms, flops, bytes;
+} etp_prof_entry;
+int etp_prof_enable(int on);
+int etp_prof_reset(void);
+int etp_prof_report(etp_prof_entry* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

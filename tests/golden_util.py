@@ -56,7 +56,7 @@ def compare_grads(z, grads, atol, rel=None, rel_sample=None):
         assert err <= atol, f"grad {name}: sample err {err:.3e} > {atol}"
         scale = max(fp[1], 1e-12)
         if rel_sample is not None:   # per-tensor relative bound on the samples
-            assert err <= rel_sample * scale + 1e-7, f"grad {name}: sample err {err:.3e} vs abs-max {scale:.3e}"
+            assert err <= rel_sample * scale + 2e-6, f"grad {name}: sample err {err:.3e} vs abs-max {scale:.3e}"
         if rel is not None:
             assert abs(float(g.abs().max()) - fp[1]) <= rel * scale + atol, f"grad {name}: abs-max"
             assert abs(float(g.norm()) - fp[2]) <= rel * max(fp[2], 1e-12) + atol, f"grad {name}: L2"

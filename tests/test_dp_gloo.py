@@ -1,0 +1,83 @@
+"""Data-parallel gradient averaging (etpnav_amd/dp.py) with world_size 2 on CPU (gloo backend): dense buckets in
+fp32 and bf16 transport, plus the row-sparse word-embedding exchange, against the analytically known mean."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from etpnav_amd import dp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, comm_dtype, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        n_rows, row_len = 50, 8
+        n = 1000 + n_rows * row_len
+        grads = [torch.randn(n) for _ in range(world)]          # every rank can rebuild all ranks' gradients
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 + r)
+            grads[r] = torch.randn(n, generator=g)
+            table = grads[r][1000:].view(n_rows, row_len)
+            ids_r = torch.tensor([3 + r, 7, 7, 20 + 2 * r])
+            mask = torch.zeros(n_rows, dtype=torch.bool); mask[ids_r] = True
+            table[~mask] = 0                                     # row-sparse, as an embedding gradient is
+        mine = grads[rank].clone()
+        ids = torch.tensor([3 + rank, 7, 7, 20 + 2 * rank])
+        red = dp.GradReducer(mine, [(600, 1000), (0, 600)], comm_dtype=comm_dtype, sparse_rows=(1000, n_rows, row_len))
+        red.reduce_bucket(0)
+        red.reduce_bucket(1)
+        red.reduce_sparse_rows(ids)
+        red.finish()
+        if comm_dtype == torch.float32:
+            expect = sum(grads) / world
+            tol = 1e-6
+        else:
+            expect = sum(g.to(comm_dtype).float() for g in grads) / world
+            tol = 2e-2
+        err = (mine - expect).abs().max().item()
+        q.put((rank, err <= tol, err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_grad_reducer_world2_gloo(comm_dtype):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f"rank {rank}: max err {err}"
+
+
+def test_planner_bucket_ranges_cover_the_arena_once():
+    from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
+    m = GlocalTextPathNavCMT(default_config(vocab_size=1024), dtype=torch.float32, device="cpu")
+    ranges, (woff, wrows, wlen) = dp.planner_buckets(m)
+    cover = torch.zeros(m.flat_grads.numel(), dtype=torch.int32)
+    for s, e in ranges:
+        cover[s:e] += 1
+    cover[woff:woff + wrows * wlen] += 1
+    for name, p in m.named_parameters():
+        off = (p.data_ptr() - m.flat_params.data_ptr()) // 4
+        assert bool((cover[off:off + p.numel()] == 1).all()), name
+    # bucket 0 (reduced while the text backward runs) must not contain text-encoder gradients
+    s0, e0 = ranges[0]
+    for name, p in m.named_parameters():
+        off = (p.data_ptr() - m.flat_params.data_ptr()) // 4
+        if name.startswith("lang_encoder.") or name.startswith("embeddings."):
+            assert not (s0 <= off < e0), name
