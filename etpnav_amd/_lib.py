@@ -135,6 +135,11 @@ def lib() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise EtpError(f"{LIB_PATH} is missing: the HIP extension is not built "
                        f"(run `python -m etpnav_amd.build`); there is no CPU fallback")
+    # torch bundles its own libamdhip64.so.7; load it FIRST so the extension binds to the same HIP runtime that
+    # owns torch's device pointers and streams (two runtimes in one process cannot see each other's allocations).
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (res, args) in _protos.items():

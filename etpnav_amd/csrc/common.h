@@ -103,10 +103,11 @@ struct GemmArgs {
   int ksplit;                         // split-K (needs out_mode 2)
   float alpha;
   const float* bias;                  // [N] fp32 or null
-  const void* R; long ldr;            // residual / grad-add operand (T) or null (non-batched only)
+  const void* R; long ldr;            // residual / grad-add operand (dtype of C) or null (non-batched only)
   void* Z; long ldz;                  // aux tensor (T): act 1 writes, act 3/4 reads
   int act;                            // ETP_ACT_*
   int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
+  int vec_epilogue;                   // set by launch_gemm: 16-byte epilogue accesses are legal
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
 void prof_enable(bool on);

@@ -72,27 +72,63 @@ template <typename T, bool TR, int ROWS> struct TileGeom {
   static_assert(CHUNKS % 256 == 0, "tile too small for 256 threads");
 };
 
-template <int N> struct Regs { uint4 v[N]; };
+template <int N> struct Regs { uint4 v[N]; unsigned okmask; };
 
-// global -> registers for one tile (zero-filled outside [rows_total) x [k_end))
+// 8 consecutive elements <-> float[8] through 16-byte vectors (bf16: one uint4, fp32: two)
+template <typename U> __device__ __forceinline__ void unpack8(const uint4* p, float (&f)[8]);
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const uint4* p, float (&f)[8]) {
+  const uint32_t w[4] = {p[0].x, p[0].y, p[0].z, p[0].w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack8<float>(const uint4* p, float (&f)[8]) {
+  f[0] = __uint_as_float(p[0].x); f[1] = __uint_as_float(p[0].y); f[2] = __uint_as_float(p[0].z); f[3] = __uint_as_float(p[0].w);
+  f[4] = __uint_as_float(p[1].x); f[5] = __uint_as_float(p[1].y); f[6] = __uint_as_float(p[1].z); f[7] = __uint_as_float(p[1].w);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// global -> registers for one tile (zero-filled outside [rows_total) x [k_end)).
+// Branch-free on purpose: a load inside a per-element `if` makes hipcc wait vmcnt(0) per element (one full
+// memory latency each); here every load is issued unconditionally from a clamped in-bounds address and the
+// out-of-range ones are zeroed with v_cndmask when they are written to LDS (after the MFMA block, so the
+// s_waitcnt for them sits behind the math).
 template <typename T, bool TR, int ROWS>
 __device__ __forceinline__ void tile_load(Regs<TileGeom<T, TR, ROWS>::PER_THREAD>& r, const T* __restrict__ base, long ld,
                                           int row0, int rows_total, int k0, int k_end, int tid) {
   using G = TileGeom<T, TR, ROWS>;
+  unsigned okmask = 0;
 #pragma unroll
   for (int j = 0; j < G::PER_THREAD; ++j) {
     const int q = tid + j * 256;
     const int lr = q / G::CPR, c = q % G::CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
+    bool ok;
+    const T* src;
     if constexpr (!TR) {
       const int row = row0 + lr, k = k0 + c * G::EPC;
-      if (row < rows_total && k < k_end) v = *reinterpret_cast<const uint4*>(base + (long)row * ld + k);
+      ok = row < rows_total && k < k_end;
+      const int rc = min(row, rows_total - 1), kc = min(k, (k_end - 1) / G::EPC * G::EPC);
+      src = base + (long)rc * ld + kc;
     } else {
       const int k = k0 + lr, row = row0 + c * G::EPC;
-      if (k < k_end && row < rows_total) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + row);
+      ok = k < k_end && row < rows_total;
+      const int kc = min(k, k_end - 1), rc = min(row, (rows_total - 1) / G::EPC * G::EPC);
+      src = base + (long)kc * ld + rc;
     }
-    r.v[j] = v;
+    r.v[j] = *reinterpret_cast<const uint4*>(src);   // consumed (and masked) only in tile_store, after the MFMAs
+    okmask |= (ok ? 1u : 0u) << j;
   }
+  r.okmask = okmask;
 }
 
 template <typename T, bool TR, int ROWS>
@@ -105,7 +141,10 @@ __device__ __forceinline__ void tile_store(const Regs<TileGeom<T, TR, ROWS>::PER
     int off;
     if constexpr (!TR) off = lr * 128 + ((c ^ (lr & 7)) << 4);
     else off = lr * G::PITCH + (c << 4);
-    *reinterpret_cast<uint4*>(lds + off) = r.v[j];
+    const bool ok = (r.okmask >> j) & 1u;
+    uint4 v = r.v[j];
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    *reinterpret_cast<uint4*>(lds + off) = v;
   }
 }
 
@@ -222,45 +261,151 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[row = 4*(lane>>4)+r][col = lane&15] of each 16x16 tile ----
+  // ---- epilogue ----------------------------------------------------------------------------------------
+  // The MFMA C layout (lane: row = 4*(lane>>4)+r, col = lane&15) gives 2-byte scattered stores, so the tile is
+  // staged through LDS as fp32 [BM][BN+4] and written back as whole 8-column chunks per thread: bias / residual /
+  // activation operands and the result all move as 16-byte vectors (coalesced 256 B per 16 threads).
   const int i = lane & 15, gq = lane >> 4;
-  const T* R = reinterpret_cast<const T*>(g.R);
+  constexpr int CP = BN + 4;
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
+  __syncthreads();
+  const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
   T* Z = reinterpret_cast<T*>(g.Z);
+  constexpr int CPRW = BN / 8;                     // 8-column chunks per tile row
+  constexpr int NCHUNK = BM * CPRW / 256;
+  if (g.vec_epilogue) {
+    // Phase A: issue every global read of the epilogue (residual / activation operand / old C) up front from
+    // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
+    constexpr int VPC = 8 * (int)sizeof(TC) / 16;  // 16-byte vectors per 8-element chunk of the C type (1 or 2)
+    constexpr int VPT = 8 * (int)sizeof(T) / 16;   // 16-byte vectors per 8-element chunk of T (bf16: 1, fp32: 2)
+    const bool has_r = g.R != nullptr, has_zr = (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD),
+               has_c = (g.out_mode == 1);
+    const bool has_bias = (g.bias != nullptr && ks == 0);
+    uint4 rr[NCHUNK][VPC], cc[NCHUNK][VPC], zz[NCHUNK][VPT];
+    const int col_last = (g.N - 1) / 8 * 8;
 #pragma unroll
-  for (int b = 0; b < NT; ++b) {
-    const int col = n0 + wc * (BN / 2) + b * 16 + i;
-    if (col >= g.N) continue;
-    const float bias = (g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f;
+    for (int jj = 0; jj < NCHUNK; ++jj) {
+      const int q = tid + jj * 256;
+      const int lr = q / CPRW, lc = (q % CPRW) * 8;
+      const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, col_last);
+      if (has_r) {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const TC*>(g.R) + (long)rowc * g.ldr + colc);
 #pragma unroll
-    for (int a = 0; a < MT; ++a) {
+        for (int u = 0; u < VPC; ++u) rr[jj][u] = p[u];
+      }
+      if (has_c) {
+        const uint4* p = reinterpret_cast<const uint4*>(C + (long)rowc * g.ldc + colc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * (BM / 2) + a * 16 + gq * 4 + r;
-        if (row >= g.M) continue;
-        float v = acc[a][b][r] * g.alpha + bias;
-        if (g.act == ETP_ACT_GELU) {
-          Elem<T>::st(Z + (long)row * g.ldz + col, v);
-          v = gelu_erf(v);
-        } else if (g.act == ETP_ACT_RELU) {
-          v = fmaxf(v, 0.f);
-        } else if (g.act == ETP_ACT_GELU_BWD) {
-          v *= gelu_erf_grad(Elem<T>::ld(Z + (long)row * g.ldz + col));
-        } else if (g.act == ETP_ACT_RELU_BWD) {
-          v = (Elem<T>::ld(Z + (long)row * g.ldz + col) > 0.f) ? v : 0.f;
-        }
-        if (R != nullptr) v += Elem<T>::ld(R + (long)row * g.ldr + col);
-        TC* dst = C + (long)row * g.ldc + col;
-        if constexpr (sizeof(TC) == 4) {
-          if (g.out_mode == 2) atomicAdd(reinterpret_cast<float*>(dst), v);
-          else if (g.out_mode == 1) *reinterpret_cast<float*>(dst) += v;
-          else *reinterpret_cast<float*>(dst) = v;
-        } else {
-          if (g.out_mode == 1) v += Elem<TC>::ld(dst);
-          Elem<TC>::st(dst, v);
-        }
+        for (int u = 0; u < VPC; ++u) cc[jj][u] = p[u];
+      }
+      if (has_zr) {
+        const uint4* p = reinterpret_cast<const uint4*>(Z + (long)rowc * g.ldz + colc);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) zz[jj][u] = p[u];
       }
     }
+    // Phase B: combine and store
+#pragma unroll
+    for (int jj = 0; jj < NCHUNK; ++jj) {
+      const int q = tid + jj * 256;
+      const int lr = q / CPRW, lc = (q % CPRW) * 8;
+      const int row = m0 + lr, col = n0 + lc;
+      const bool ok = row < g.M && col < g.N;
+      const int colc = min(col, col_last);
+      float v[8];
+      {
+        const float4 x0 = *reinterpret_cast<const float4*>(ct + lr * CP + lc);
+        const float4 x1 = *reinterpret_cast<const float4*>(ct + lr * CP + lc + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      }
+      if (has_bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + colc), b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+      }
+      if (g.act == ETP_ACT_GELU) {
+        if (ok) store8(Z + (long)row * g.ldz + col, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      } else if (g.act == ETP_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (has_zr) {
+        float zf[8];
+        unpack8<T>(zz[jj], zf);
+        if (g.act == ETP_ACT_GELU_BWD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(zf[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
+        }
+      }
+      if (has_r) {
+        float rf[8];
+        unpack8<TC>(rr[jj], rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+      TC* dst = C + (long)row * g.ldc + col;
+      if (g.out_mode == 2) {
+        if constexpr (sizeof(TC) == 4) {
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
+          }
+        }
+      } else {
+        if (has_c) {
+          float cf[8];
+          unpack8<TC>(cc[jj], cf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += cf[e];
+        }
+        if (ok) store8(dst, v);
+      }
+    }
+    return;
   }
+  // scalar fallback (odd leading dimensions / unaligned bases): one element per thread-iteration, row-major
+  for (int q = tid; q < BM * BN; q += 256) {
+    const int lr = q / BN, lc = q % BN;
+    const int row = m0 + lr, col = n0 + lc;
+    if (row >= g.M || col >= g.N) continue;
+    float v = ct[lr * CP + lc] * g.alpha + ((g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f);
+    if (g.act == ETP_ACT_GELU) {
+      Elem<T>::st(Z + (long)row * g.ldz + col, v);
+      v = gelu_erf(v);
+    } else if (g.act == ETP_ACT_RELU) {
+      v = fmaxf(v, 0.f);
+    } else if (g.act == ETP_ACT_GELU_BWD) {
+      v *= gelu_erf_grad(Elem<T>::ld(Z + (long)row * g.ldz + col));
+    } else if (g.act == ETP_ACT_RELU_BWD) {
+      v = (Elem<T>::ld(Z + (long)row * g.ldz + col) > 0.f) ? v : 0.f;
+    }
+    if (g.R != nullptr) v += Elem<TC>::ld(reinterpret_cast<const TC*>(g.R) + (long)row * g.ldr + col);
+    TC* dst = C + (long)row * g.ldc + col;
+    if constexpr (sizeof(TC) == 4) {
+      if (g.out_mode == 2) atomicAdd(reinterpret_cast<float*>(dst), v);
+      else if (g.out_mode == 1) *reinterpret_cast<float*>(dst) += v;
+      else *reinterpret_cast<float*>(dst) = v;
+    } else {
+      if (g.out_mode == 1) v += Elem<TC>::ld(dst);
+      Elem<TC>::st(dst, v);
+    }
+  }
+  (void)R;
 }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
@@ -305,7 +450,8 @@ template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   using GA = TileGeom<T, TA, BM>;
   using GB = TileGeom<T, TB, BN>;
-  constexpr int smem = 2 * (GA::BYTES + GB::BYTES);
+  constexpr int smem_loop = 2 * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
+  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
   static bool attr_set = false;
   auto kern = gemm_kernel<T, TC, TA, TB, BM, BN>;
   if (!attr_set) {
@@ -355,15 +501,27 @@ static int launch_trans(int ta, int tb, const GemmArgs& g, int nbatch, hipStream
   return fail(ETP_ERR_INVALID, "gemm: (A trans, B row) storage pairing is not used on this path");
 }
 
-int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g, int nbatch, hipStream_t st) {
-  ETP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && nbatch > 0 && g.ksplit >= 1 && g.nb_inner >= 1, "bad dims");
+int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, int nbatch, hipStream_t st) {
+  const GemmArgs& g0 = g_in;
+  ETP_REQUIRE(g0.M > 0 && g0.N > 0 && g0.K >= 0 && nbatch > 0 && g0.ksplit >= 1 && g0.nb_inner >= 1, "bad dims");
   const int epc = dtype == ETP_BF16 ? 8 : 4;
-  ETP_REQUIRE(g.lda % epc == 0 && g.ldb % epc == 0, "lda/ldb must be multiples of a 16-byte chunk");
-  ETP_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0), "A/B must be 16-byte aligned");
-  ETP_REQUIRE((g.sAo % epc == 0) && (g.sAi % epc == 0) && (g.sBo % epc == 0) && (g.sBi % epc == 0),
+  ETP_REQUIRE(g0.lda % epc == 0 && g0.ldb % epc == 0, "lda/ldb must be multiples of a 16-byte chunk");
+  ETP_REQUIRE(((uintptr_t)g0.A % 16 == 0) && ((uintptr_t)g0.B % 16 == 0), "A/B must be 16-byte aligned");
+  ETP_REQUIRE((g0.sAo % epc == 0) && (g0.sAi % epc == 0) && (g0.sBo % epc == 0) && (g0.sBi % epc == 0),
               "batch strides must keep 16-byte alignment");
-  ETP_REQUIRE(g.out_mode != 2 || c_dtype == ETP_F32, "atomic accumulation needs an fp32 C");
-  ETP_REQUIRE(g.ksplit == 1 || g.out_mode == 2, "split-K needs atomic accumulation");
+  ETP_REQUIRE(g0.out_mode != 2 || c_dtype == ETP_F32, "atomic accumulation needs an fp32 C");
+  ETP_REQUIRE(g0.ksplit == 1 || g0.out_mode == 2, "split-K needs atomic accumulation");
+  GemmArgs g = g_in;
+  {  // the vectorised epilogue needs 8-column chunks to stay in-bounds and 16-byte aligned
+    const size_t cs = dtype_size(c_dtype), ts = dtype_size(dtype);
+    bool ok = (g.ldc % 8 == 0) && (g.ldc >= round_up(g.N, 8)) && ((uintptr_t)g.C % 16 == 0) && ((g.sCo * cs) % 16 == 0) &&
+              ((g.sCi * cs) % 16 == 0);
+    if (g.bias) ok = ok && ((uintptr_t)g.bias % 16 == 0) && (g.N % 8 == 0);
+    if (g.R) ok = ok && (g.ldr % 8 == 0) && ((uintptr_t)g.R % 16 == 0) && (g.ldr >= round_up(g.N, 8));
+    if (g.Z) ok = ok && (g.ldz % 8 == 0) && ((uintptr_t)g.Z % 16 == 0) && (g.ldz >= round_up(g.N, 8));
+    (void)ts;
+    g.vec_epilogue = ok ? 1 : 0;
+  }
   if (dtype == ETP_F32) {
     ETP_REQUIRE(c_dtype == ETP_F32, "fp32 operands need an fp32 C");
     return launch_trans<float, float>(ta, tb, g, nbatch, st);
