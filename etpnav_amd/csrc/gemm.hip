@@ -21,6 +21,7 @@
 //     backward forms, residual add, fp32 accumulate / atomic split-K for wgrad.
 // The lane->k assignment is the same for every read mode (group g = lane>>4, element e:
 // k = 32*s + 8*g + e), so any A/B storage pairing is consistent.
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -61,10 +62,10 @@ __device__ __forceinline__ void mma_step(f32x4_t& acc, const Frag<float>& a, con
 }
 
 // ---- LDS geometry of one operand tile -------------------------------------------------
-template <typename T, bool TR, int ROWS> struct TileGeom {
+template <typename T, bool TR, int ROWS, int PAD = 32> struct TileGeom {
   static constexpr int BK = MmaTraits<T>::BK;
   static constexpr int EPC = MmaTraits<T>::EPC;
-  static constexpr int PITCH = TR ? (ROWS * (int)sizeof(T) + 32) : 128;      // bytes
+  static constexpr int PITCH = TR ? (ROWS * (int)sizeof(T) + PAD) : 128;     // bytes
   static constexpr int BYTES = TR ? BK * PITCH : ROWS * 128;
   static constexpr int CHUNKS = ROWS * 8;                                    // 16-B chunks per tile (both layouts)
   static constexpr int PER_THREAD = CHUNKS / 256;
@@ -73,6 +74,15 @@ template <typename T, bool TR, int ROWS> struct TileGeom {
 };
 
 template <int N> struct Regs { uint4 v[N]; unsigned okmask; };
+
+// 16-byte-chunk XOR swizzle of unpadded transposed tiles ([k][rows], LDS-DMA layout): the four k-rows one
+// ds_read_b64_tr_b16 lane group touches land on disjoint bank ranges (2*(k&3)), and the two groups of a 32-lane
+// half (k and k+8) on different 128-byte halves of a 256-byte row (8*((k>>3)&1), only when the row has >= 16 chunks).
+template <int CPR> __device__ __forceinline__ int tr_swz(int krow) {
+  int x = (krow & 3) << 1;
+  if constexpr (CPR >= 16) x ^= ((krow >> 3) & 1) << 3;
+  return x;
+}
 
 // 8 consecutive elements <-> float[8] through 16-byte vectors (bf16: one uint4, fp32: two)
 template <typename U> __device__ __forceinline__ void unpack8(const uint4* p, float (&f)[8]);
@@ -149,10 +159,10 @@ __device__ __forceinline__ void tile_store(const Regs<TileGeom<T, TR, ROWS>::PER
 }
 
 // LDS -> fragment: 8 k-values (k = 32*s + 8*g + e) of tile row `row` (i = lane&15 already added by caller)
-template <typename T, bool TR, int ROWS>
+template <typename T, bool TR, int ROWS, int PAD = 32>
 __device__ __forceinline__ void frag_load(Frag<T>& f, const char* lds, int row16 /*first row of the 16-row group*/, int s,
                                           int lane) {
-  using G = TileGeom<T, TR, ROWS>;
+  using G = TileGeom<T, TR, ROWS, PAD>;
   const int i = lane & 15, g = lane >> 4;
   if constexpr (!TR) {
     const int row = row16 + i;
@@ -169,20 +179,189 @@ __device__ __forceinline__ void frag_load(Frag<T>& f, const char* lds, int row16
       // ds_read_b64_tr_b16: within a 16-lane group, lane j supplies the address of 4 consecutive bf16 of
       // k-row (j>>2), columns 4*(j&3)..+3; lane i receives column i of that 4x16 block (k = 0..3).
       const int k0 = s * 32 + g * 8;
-      const char* p0 = lds + (k0 + (i >> 2)) * G::PITCH + (row16 + (i & 3) * 4) * 2;
+      const int kr = k0 + (i >> 2);
+      int coff = (row16 + (i & 3) * 4) * 2;                      // byte offset of this lane's 8 bytes inside the k-row
+      int coff_hi = coff;
+      if constexpr (PAD == 0) {                                  // LDS-DMA layout: chunk swizzle instead of padding
+        coff ^= tr_swz<G::CPR>(kr) << 4;
+        coff_hi ^= tr_swz<G::CPR>(kr + 4) << 4;
+      }
       typedef short4_t __attribute__((address_space(3))) * lds_s4;
-      short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
-      short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * G::PITCH));
+      short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + kr * G::PITCH + coff));
+      short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + (kr + 4) * G::PITCH + coff_hi));
       uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
       f.v = make_uint4(a.x, a.y, b.x, b.y);
     } else {
       const int k0 = g * 8;
-      const float* p = reinterpret_cast<const float*>(lds + k0 * G::PITCH) + row16 + i;
-      constexpr int PF = G::PITCH / 4;
-      f.lo = make_float4(p[0], p[PF], p[2 * PF], p[3 * PF]);
-      f.hi = make_float4(p[4 * PF], p[5 * PF], p[6 * PF], p[7 * PF]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int boff = (row16 + i) * 4;
+        if constexpr (PAD == 0) boff ^= tr_swz<G::CPR>(k0 + e) << 4;
+        v[e] = *reinterpret_cast<const float*>(lds + (k0 + e) * G::PITCH + boff);
+      }
+      f.lo = make_float4(v[0], v[1], v[2], v[3]);
+      f.hi = make_float4(v[4], v[5], v[6], v[7]);
     }
   }
+}
+
+// Epilogue shared by both GEMM kernels (register-staged and LDS-DMA main loops).
+template <typename T, typename TC, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], char* smem, const GemmArgs& g, TC* C, int m0,
+                                              int n0, int ks, int tid) {
+  constexpr int MT = BM / 32, NT = BN / 32;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // ---- epilogue ----------------------------------------------------------------------------------------
+  // The MFMA C layout (lane: row = 4*(lane>>4)+r, col = lane&15) gives 2-byte scattered stores, so the tile is
+  // staged through LDS as fp32 [BM][BN+4] and written back as whole 8-column chunks per thread: bias / residual /
+  // activation operands and the result all move as 16-byte vectors (coalesced 256 B per 16 threads).
+  const int i = lane & 15, gq = lane >> 4;
+  constexpr int CP = BN + 4;
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
+  __syncthreads();
+  const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
+  T* Z = reinterpret_cast<T*>(g.Z);
+  constexpr int CPRW = BN / 8;                     // 8-column chunks per tile row
+  constexpr int NCHUNK = BM * CPRW / 256;
+  if (g.vec_epilogue) {
+    // Phase A: issue every global read of the epilogue (residual / activation operand / old C) up front from
+    // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
+    constexpr int VPC = 8 * (int)sizeof(TC) / 16;  // 16-byte vectors per 8-element chunk of the C type (1 or 2)
+    constexpr int VPT = 8 * (int)sizeof(T) / 16;   // 16-byte vectors per 8-element chunk of T (bf16: 1, fp32: 2)
+    const bool has_r = g.R != nullptr, has_zr = (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD),
+               has_c = (g.out_mode == 1);
+    const bool has_bias = (g.bias != nullptr && ks == 0);
+    constexpr int HC = NCHUNK >= 4 ? NCHUNK / 4 : 1;       // chunks per pass (bounds the live epilogue registers)
+    const int col_last = (g.N - 1) / 8 * 8;
+#pragma unroll
+    for (int h0 = 0; h0 < NCHUNK; h0 += HC) {
+    uint4 rr[HC][VPC], cc[HC][VPC], zz[HC][VPT];
+#pragma unroll
+    for (int jh = 0; jh < HC; ++jh) {
+      const int jj = jh, q = tid + (h0 + jh) * 256;
+      const int lr = q / CPRW, lc = (q % CPRW) * 8;
+      const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, col_last);
+      if (has_r) {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const TC*>(g.R) + (long)rowc * g.ldr + colc);
+#pragma unroll
+        for (int u = 0; u < VPC; ++u) rr[jj][u] = p[u];
+      }
+      if (has_c) {
+        const uint4* p = reinterpret_cast<const uint4*>(C + (long)rowc * g.ldc + colc);
+#pragma unroll
+        for (int u = 0; u < VPC; ++u) cc[jj][u] = p[u];
+      }
+      if (has_zr) {
+        const uint4* p = reinterpret_cast<const uint4*>(Z + (long)rowc * g.ldz + colc);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) zz[jj][u] = p[u];
+      }
+    }
+    // Phase B: combine and store
+#pragma unroll
+    for (int jh = 0; jh < HC; ++jh) {
+      const int jj = jh, q = tid + (h0 + jh) * 256;
+      const int lr = q / CPRW, lc = (q % CPRW) * 8;
+      const int row = m0 + lr, col = n0 + lc;
+      const bool ok = row < g.M && col < g.N;
+      const int colc = min(col, col_last);
+      float v[8];
+      {
+        const float4 x0 = *reinterpret_cast<const float4*>(ct + lr * CP + lc);
+        const float4 x1 = *reinterpret_cast<const float4*>(ct + lr * CP + lc + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      }
+      if (has_bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + colc), b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+      }
+      if (g.act == ETP_ACT_GELU) {
+        if (ok) store8(Z + (long)row * g.ldz + col, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      } else if (g.act == ETP_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (has_zr) {
+        float zf[8];
+        unpack8<T>(zz[jj], zf);
+        if (g.act == ETP_ACT_GELU_BWD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(zf[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
+        }
+      }
+      if (has_r) {
+        float rf[8];
+        unpack8<TC>(rr[jj], rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+      TC* dst = C + (long)row * g.ldc + col;
+      if (g.out_mode == 2) {
+        if constexpr (sizeof(TC) == 4) {
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
+          }
+        }
+      } else {
+        if (has_c) {
+          float cf[8];
+          unpack8<TC>(cc[jj], cf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += cf[e];
+        }
+        if (ok) store8(dst, v);
+      }
+    }
+    }
+    return;
+  }
+  // scalar fallback (odd leading dimensions / unaligned bases): one element per thread-iteration, row-major
+  for (int q = tid; q < BM * BN; q += 256) {
+    const int lr = q / BN, lc = q % BN;
+    const int row = m0 + lr, col = n0 + lc;
+    if (row >= g.M || col >= g.N) continue;
+    float v = ct[lr * CP + lc] * g.alpha + ((g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f);
+    if (g.act == ETP_ACT_GELU) {
+      Elem<T>::st(Z + (long)row * g.ldz + col, v);
+      v = gelu_erf(v);
+    } else if (g.act == ETP_ACT_RELU) {
+      v = fmaxf(v, 0.f);
+    } else if (g.act == ETP_ACT_GELU_BWD) {
+      v *= gelu_erf_grad(Elem<T>::ld(Z + (long)row * g.ldz + col));
+    } else if (g.act == ETP_ACT_RELU_BWD) {
+      v = (Elem<T>::ld(Z + (long)row * g.ldz + col) > 0.f) ? v : 0.f;
+    }
+    if (g.R != nullptr) v += Elem<TC>::ld(reinterpret_cast<const TC*>(g.R) + (long)row * g.ldr + col);
+    TC* dst = C + (long)row * g.ldc + col;
+    if constexpr (sizeof(TC) == 4) {
+      if (g.out_mode == 2) atomicAdd(reinterpret_cast<float*>(dst), v);
+      else if (g.out_mode == 1) *reinterpret_cast<float*>(dst) += v;
+      else *reinterpret_cast<float*>(dst) = v;
+    } else {
+      if (g.out_mode == 1) v += Elem<TC>::ld(dst);
+      Elem<TC>::st(dst, v);
+    }
+  }
+  (void)R;
 }
 
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
@@ -261,151 +440,158 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------------
-  // The MFMA C layout (lane: row = 4*(lane>>4)+r, col = lane&15) gives 2-byte scattered stores, so the tile is
-  // staged through LDS as fp32 [BM][BN+4] and written back as whole 8-column chunks per thread: bias / residual /
-  // activation operands and the result all move as 16-byte vectors (coalesced 256 B per 16 threads).
-  const int i = lane & 15, gq = lane >> 4;
-  constexpr int CP = BN + 4;
-  float* ct = reinterpret_cast<float*>(smem);
+  __syncthreads();   // every wave is done reading the operand tiles before the C tile overwrites them
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
+}
+
+// =========================================================================================================
+// LDS-DMA main loop (global_load_lds_dwordx4, no VGPR staging, no ds_write pass), STAGES-deep LDS ring.
+//   Used when the reduction length is a multiple of the 128-byte slab (every linear layer of the planner);
+//   ragged reductions fall back to the register-staged kernel above.
+//   * each wave-instruction moves 1 KiB: LDS destination = wave-uniform base + lane*16 (lane-linear), so the
+//     XOR swizzle of row operands is applied to the per-lane SOURCE address (logical chunk = phys ^ (row&7)),
+//     the same involution frag_load applies on the read side;
+//   * out-of-range rows/columns are clamped to valid addresses (their products are never stored);
+//   * one barrier per slab; `s_waitcnt vmcnt(N)` leaves the younger slabs' DMA in flight across it.
+// =========================================================================================================
+template <typename T, bool TR, int ROWS>
+struct DmaPlan {
+  static constexpr int PER_WAVE = ROWS / 32;          // 1-KiB pieces per wave per slab
+  const T* src[PER_WAVE];                             // per-lane source address of piece j (advanced per slab)
+  int lds_off[PER_WAVE];                              // wave-uniform LDS byte offset of piece j within the tile
+};
+
+template <typename T, bool TR, int ROWS>
+__device__ __forceinline__ void dma_plan(DmaPlan<T, TR, ROWS>& p, const T* base, long ld, int row0, int rows_total, int k0,
+                                         int tid) {
+  using G = TileGeom<T, TR, ROWS, 0>;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < DmaPlan<T, TR, ROWS>::PER_WAVE; ++j) {
+    const int piece = j * 4 + wave;
+    const int idx = piece * 64 + lane;               // 16-byte chunk index inside the tile == LDS position
+    p.lds_off[j] = __builtin_amdgcn_readfirstlane(piece * 1024);
+    if constexpr (!TR) {
+      const int lr = idx >> 3, pch = idx & 7;
+      const int c = pch ^ (lr & 7);
+      const int rc = min(row0 + lr, rows_total - 1);
+      p.src[j] = base + (long)rc * ld + k0 + c * G::EPC;
+    } else {
+      const int kr = idx / G::CPR, cch = (idx % G::CPR) ^ tr_swz<G::CPR>(idx / G::CPR);
+      const int rc = min(row0 + cch * G::EPC, (rows_total - 1) / G::EPC * G::EPC);
+      p.src[j] = base + (long)(k0 + kr) * ld + rc;
+    }
+  }
+}
+
+// One LDS-DMA piece, issued from inline asm on purpose: with the builtin hipcc (ROCm 7.2) treats the DMA as a
+// pending LDS write that may alias the fragment reads and drains it with s_waitcnt vmcnt(0) before the first ds_read
+// of the slab, which removes all overlap.  Hidden in asm, the copy stays in flight under the MFMAs; completion is
+// tracked by our own counted s_waitcnt vmcnt(N) + barrier (cdna_hip_programming.md §5.7).  M0 = LDS byte address of
+// the piece (wave-uniform), written in the same statement that consumes it and restored afterwards.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+
+template <typename T, bool TR, int ROWS>
+__device__ __forceinline__ void dma_issue(DmaPlan<T, TR, ROWS>& p, unsigned lds_tile_addr, long ld) {
+  constexpr int BK = MmaTraits<T>::BK;
+#pragma unroll
+  for (int j = 0; j < DmaPlan<T, TR, ROWS>::PER_WAVE; ++j) {
+    glds16(p.src[j], lds_tile_addr + (unsigned)p.lds_off[j]);
+    if constexpr (!TR) p.src[j] += BK;
+    else p.src[j] += (long)BK * ld;
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
+  using GA = TileGeom<T, TA, BM, 0>;
+  using GB = TileGeom<T, TB, BN, 0>;
+  constexpr int BK = MmaTraits<T>::BK;
+  constexpr int KS = BK / 32;
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int STAGE = GA::BYTES + GB::BYTES;
+  constexpr int PER_SLAB = DmaPlan<T, TA, BM>::PER_WAVE + DmaPlan<T, TB, BN>::PER_WAVE;   // DMA instrs per wave per slab
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
+  const int zo = z / g.nb_inner, zi = z % g.nb_inner;
+  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+
+  int kbeg = 0, kend = g.K;
+  if (g.ksplit > 1) {
+    const int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
+    kbeg = ks * per;
+    kend = min(g.K, kbeg + per);
+  }
+  const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;     // host guarantees BK | (kend-kbeg)
+
+  f32x4_t acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  DmaPlan<T, TA, BM> pa;
+  DmaPlan<T, TB, BN> pb;
+  dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the ring
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) {
+      dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
+      dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
+    }
+
+  for (int t = 0; t < nk; ++t) {
+    // slab t must have landed; up to STAGES-2 younger slabs stay in flight across the barrier
+    if (STAGES > 2 && t + 1 < nk) wait_vmcnt<(STAGES - 2) * PER_SLAB>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of slab t are in LDS, (b) buffer (t-1)%STAGES is free
+    if (t + STAGES - 1 < nk) {
+      const unsigned dst = lds0 + ((t + STAGES - 1) % STAGES) * STAGE;
+      dma_issue<T, TA, BM>(pa, dst, g.lda);
+      dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);
+    }
+    const char* sa = smem + (t % STAGES) * STAGE;
+    const char* sb = sa + GA::BYTES;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      Frag<T> fa[MT], fb[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) frag_load<T, TA, BM, 0>(fa[a], sa, wr * (BM / 2) + a * 16, s, lane);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) frag_load<T, TB, BN, 0>(fb[b], sb, wc * (BN / 2) + b * 16, s, lane);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) mma_step(acc[a][b], fa[a], fb[b]);
+    }
+  }
+  wait_vmcnt<0>();
   __syncthreads();
-  const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
-  T* Z = reinterpret_cast<T*>(g.Z);
-  constexpr int CPRW = BN / 8;                     // 8-column chunks per tile row
-  constexpr int NCHUNK = BM * CPRW / 256;
-  if (g.vec_epilogue) {
-    // Phase A: issue every global read of the epilogue (residual / activation operand / old C) up front from
-    // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
-    constexpr int VPC = 8 * (int)sizeof(TC) / 16;  // 16-byte vectors per 8-element chunk of the C type (1 or 2)
-    constexpr int VPT = 8 * (int)sizeof(T) / 16;   // 16-byte vectors per 8-element chunk of T (bf16: 1, fp32: 2)
-    const bool has_r = g.R != nullptr, has_zr = (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD),
-               has_c = (g.out_mode == 1);
-    const bool has_bias = (g.bias != nullptr && ks == 0);
-    uint4 rr[NCHUNK][VPC], cc[NCHUNK][VPC], zz[NCHUNK][VPT];
-    const int col_last = (g.N - 1) / 8 * 8;
-#pragma unroll
-    for (int jj = 0; jj < NCHUNK; ++jj) {
-      const int q = tid + jj * 256;
-      const int lr = q / CPRW, lc = (q % CPRW) * 8;
-      const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, col_last);
-      if (has_r) {
-        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const TC*>(g.R) + (long)rowc * g.ldr + colc);
-#pragma unroll
-        for (int u = 0; u < VPC; ++u) rr[jj][u] = p[u];
-      }
-      if (has_c) {
-        const uint4* p = reinterpret_cast<const uint4*>(C + (long)rowc * g.ldc + colc);
-#pragma unroll
-        for (int u = 0; u < VPC; ++u) cc[jj][u] = p[u];
-      }
-      if (has_zr) {
-        const uint4* p = reinterpret_cast<const uint4*>(Z + (long)rowc * g.ldz + colc);
-#pragma unroll
-        for (int u = 0; u < VPT; ++u) zz[jj][u] = p[u];
-      }
-    }
-    // Phase B: combine and store
-#pragma unroll
-    for (int jj = 0; jj < NCHUNK; ++jj) {
-      const int q = tid + jj * 256;
-      const int lr = q / CPRW, lc = (q % CPRW) * 8;
-      const int row = m0 + lr, col = n0 + lc;
-      const bool ok = row < g.M && col < g.N;
-      const int colc = min(col, col_last);
-      float v[8];
-      {
-        const float4 x0 = *reinterpret_cast<const float4*>(ct + lr * CP + lc);
-        const float4 x1 = *reinterpret_cast<const float4*>(ct + lr * CP + lc + 4);
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      }
-      if (has_bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + colc), b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
-        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
-      }
-      if (g.act == ETP_ACT_GELU) {
-        if (ok) store8(Z + (long)row * g.ldz + col, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-      } else if (g.act == ETP_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (has_zr) {
-        float zf[8];
-        unpack8<T>(zz[jj], zf);
-        if (g.act == ETP_ACT_GELU_BWD) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(zf[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
-        }
-      }
-      if (has_r) {
-        float rf[8];
-        unpack8<TC>(rr[jj], rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-      }
-      TC* dst = C + (long)row * g.ldc + col;
-      if (g.out_mode == 2) {
-        if constexpr (sizeof(TC) == 4) {
-          if (ok) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
-          }
-        }
-      } else {
-        if (has_c) {
-          float cf[8];
-          unpack8<TC>(cc[jj], cf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += cf[e];
-        }
-        if (ok) store8(dst, v);
-      }
-    }
-    return;
-  }
-  // scalar fallback (odd leading dimensions / unaligned bases): one element per thread-iteration, row-major
-  for (int q = tid; q < BM * BN; q += 256) {
-    const int lr = q / BN, lc = q % BN;
-    const int row = m0 + lr, col = n0 + lc;
-    if (row >= g.M || col >= g.N) continue;
-    float v = ct[lr * CP + lc] * g.alpha + ((g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f);
-    if (g.act == ETP_ACT_GELU) {
-      Elem<T>::st(Z + (long)row * g.ldz + col, v);
-      v = gelu_erf(v);
-    } else if (g.act == ETP_ACT_RELU) {
-      v = fmaxf(v, 0.f);
-    } else if (g.act == ETP_ACT_GELU_BWD) {
-      v *= gelu_erf_grad(Elem<T>::ld(Z + (long)row * g.ldz + col));
-    } else if (g.act == ETP_ACT_RELU_BWD) {
-      v = (Elem<T>::ld(Z + (long)row * g.ldz + col) > 0.f) ? v : 0.f;
-    }
-    if (g.R != nullptr) v += Elem<TC>::ld(reinterpret_cast<const TC*>(g.R) + (long)row * g.ldr + col);
-    TC* dst = C + (long)row * g.ldc + col;
-    if constexpr (sizeof(TC) == 4) {
-      if (g.out_mode == 2) atomicAdd(reinterpret_cast<float*>(dst), v);
-      else if (g.out_mode == 1) *reinterpret_cast<float*>(dst) += v;
-      else *reinterpret_cast<float*>(dst) = v;
-    } else {
-      if (g.out_mode == 1) v += Elem<TC>::ld(dst);
-      Elem<TC>::st(dst, v);
-    }
-  }
-  (void)R;
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
 }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
@@ -446,14 +632,17 @@ int prof_report(etp_prof_entry* out, int cap) {
   return n;
 }
 
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES /*0 = register-staged kernel*/>
 static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
-  using GA = TileGeom<T, TA, BM>;
-  using GB = TileGeom<T, TB, BN>;
-  constexpr int smem_loop = 2 * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
+  constexpr int PAD = STAGES == 0 ? 32 : 0;
+  using GA = TileGeom<T, TA, BM, PAD>;
+  using GB = TileGeom<T, TB, BN, PAD>;
+  constexpr int smem_loop = (STAGES == 0 ? 2 : STAGES) * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
   constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
   static bool attr_set = false;
-  auto kern = gemm_kernel<T, TC, TA, TB, BM, BN>;
+  void (*kern)(const GemmArgs);
+  if constexpr (STAGES == 0) kern = gemm_kernel<T, TC, TA, TB, BM, BN>;
+  else kern = gemm_dma_kernel<T, TC, TA, TB, BM, BN, STAGES>;
   if (!attr_set) {
     ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -464,8 +653,8 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   const bool prof = g_prof_on;
   if (prof) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "gemm<%s,%s,%s%s,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
-             TA ? "T" : "N", TB ? "N" : "T", BM, BN);   // BLAS-style: opA,opB of C = opA(A) opB(B)
+    snprintf(nm, sizeof(nm), "gemm%s<%s,%s,%s%s,%dx%d>", STAGES ? "_dma" : "", sizeof(T) == 2 ? "bf16" : "f32",
+             sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN);   // BLAS-style opA,opB
     std::lock_guard<std::mutex> lk(g_prof_mu);
     rec.id = prof_id(nm);
     rec.flops = 2.0 * g.M * g.N * g.K * nbatch;
@@ -488,9 +677,29 @@ template <typename T, typename TC, bool TA, bool TB>
 static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   // Tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64 (fills 256 CUs on the
   // planner's small-M products and keeps batched attention tiles from wasting MFMA work).
+  constexpr int BK = MmaTraits<T>::BK;
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
-  if (g.M >= 128 && g.N >= 128 && t128 >= 192) return launch_one<T, TC, TA, TB, 128, 128>(g, nbatch, st);
-  return launch_one<T, TC, TA, TB, 64, 64>(g, nbatch, st);
+  bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
+  // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
+  bool dma = (g.K % BK == 0) && (g.K >= 2 * BK);
+  if (g.ksplit > 1) dma = dma && (((g.K + g.ksplit - 1) / g.ksplit) % BK == 0) && (g.K % g.ksplit == 0);
+  int stages = 2;
+  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r"
+  if (force && force[0]) {
+    big = force[0] == '1';
+    if (strchr(force, 'r')) dma = false;
+    if (strstr(force, "s3")) stages = 3;
+  }
+  if (!dma) {
+    if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
+    return launch_one<T, TC, TA, TB, 64, 64, 0>(g, nbatch, st);
+  }
+  if (big) {
+    if (stages == 3) return launch_one<T, TC, TA, TB, 128, 128, 3>(g, nbatch, st);
+    return launch_one<T, TC, TA, TB, 128, 128, 2>(g, nbatch, st);
+  }
+  if (stages == 3) return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
+  return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);
 }
 
 template <typename T, typename TC>
@@ -520,6 +729,7 @@ int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, in
     if (g.R) ok = ok && (g.ldr % 8 == 0) && ((uintptr_t)g.R % 16 == 0) && (g.ldr >= round_up(g.N, 8));
     if (g.Z) ok = ok && (g.ldz % 8 == 0) && ((uintptr_t)g.Z % 16 == 0) && (g.ldz >= round_up(g.N, 8));
     (void)ts;
+    if (g.out_mode == 2) ok = false;   // atomics: lane-consecutive fp32 columns (row-major scalar path) coalesce best
     g.vec_epilogue = ok ? 1 : 0;
   }
   if (dtype == ETP_F32) {

@@ -1,0 +1,60 @@
+"""GEMM micro-benchmark on the planner's real shapes (run on the GPU box).  python tools/gemm_bench.py [tile]"""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from etpnav_amd import _lib
+from etpnav_amd._lib import GemmDesc, check
+
+L = _lib.lib()
+dev = "cuda"
+
+def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
+    t = torch.bfloat16 if dtype == _lib.ETP_BF16 else torch.float32
+    d = GemmDesc()
+    if kind == "fwd":      # Y[M,N] = X[M,K] W[N,K]^T + b
+        A = torch.randn(M, K, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, N, device=dev, dtype=t)
+        d.trans_a, d.trans_b, d.c_dtype = 0, 0, dtype; d.lda, d.ldb, d.ldc = K, K, N; d.M, d.N, d.K = M, N, K
+        bias = torch.randn(N, device=dev); d.bias = bias.data_ptr()
+    elif kind == "dgrad":  # dX[M,K] = dY[M,N] W[N,K]
+        A = torch.randn(M, N, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, K, device=dev, dtype=t)
+        d.trans_a, d.trans_b, d.c_dtype = 0, 1, dtype; d.lda, d.ldb, d.ldc = N, K, K; d.M, d.N, d.K = M, K, N
+    else:                  # dW[N,K] += dY[M,N]^T X[M,K]
+        A = torch.randn(M, N, device=dev).to(t); B = torch.randn(M, K, device=dev).to(t); C = torch.zeros(N, K, device=dev)
+        d.trans_a, d.trans_b, d.c_dtype = 1, 1, _lib.ETP_F32; d.lda, d.ldb, d.ldc = N, K, K; d.M, d.N, d.K = N, K, M
+        d.ksplit = ksplit; d.out_mode = 2 if ksplit > 1 else 1
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.dtype = dtype; d.batch, d.batch_inner, d.alpha = 1, 1, 1.0
+    if d.ksplit == 0: d.ksplit = 1
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3): check(L.etp_gemm(ctypes.byref(d), s))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): check(L.etp_gemm(ctypes.byref(d), s))
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    fl = 2.0 * M * N * K
+    return us, fl / us / 1e6
+
+shapes = [("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
+          ("fwd", 1152, 2304, 768), ("fwd", 512, 768, 768), ("fwd", 512, 3072, 768),
+          ("dgrad", 2560, 2304, 768), ("dgrad", 2560, 768, 768), ("dgrad", 2560, 3072, 768), ("dgrad", 2560, 768, 3072),
+          ("dgrad", 512, 768, 768),
+          ("wgrad", 2560, 2304, 768), ("wgrad", 2560, 768, 768), ("wgrad", 2560, 3072, 768), ("wgrad", 2560, 768, 3072),
+          ("wgrad", 512, 768, 768), ("wgrad", 512, 3072, 768)]
+tiles = sys.argv[1:] or ["auto", "128", "64"]
+print(f"{'kind':6} {'M':>5} {'N':>5} {'K':>5} " + " ".join(f"{t+':us':>10} {'TF':>7}" for t in tiles))
+for kind, M, N, K in shapes:
+    row = f"{kind:6} {M:5d} {N:5d} {K:5d} "
+    for tl in tiles:
+        os.environ["ETP_GEMM_TILE"] = "" if tl == "auto" else tl
+        if kind == "wgrad":
+            best = None
+            for ks in (1, 2, 4, 8):
+                us, tf = run(kind, M, N, K, ksplit=ks)
+                if best is None or us < best[0]: best = (us, tf, ks)
+            row += f"{best[0]:10.1f} {best[1]:7.1f}(ks{best[2]})"
+        else:
+            us, tf = run(kind, M, N, K)
+            row += f"{us:10.1f} {tf:7.1f} "
+    print(row, flush=True)
