@@ -1,0 +1,446 @@
+// Fused small-sequence attention (head dim 64) forward / backward for gfx950.
+//
+//   ctx = softmax(alpha * Q K^T + keymask + (w*dist + b)) V        BertSelfAttention.forward vilmodel_cmt.py:103-141,
+//                                                                  BertOutAttention.forward :325-352,
+//                                                                  nn.MultiheadAttention (common/transformer.py:138)
+//
+// One 256-thread workgroup (4 wavefronts, 2x2) owns one (batch, head): Q, K, V (and dO, P, dS in backward) live in LDS
+// as padded row-major tiles for the whole kernel, every product is an MFMA tile product over those LDS tiles, and the
+// softmax never leaves the chip.  Replaces 3 (forward) / 6 (backward) launches of the batched-GEMM path and their
+// HBM round trips of the score matrix; used when Lq, Lk <= 128 (every R2R-CE shape of the planner).  Longer
+// sequences (RxR L=512) take the unfused path in planner.hip, which saves P in the same layout.
+//
+// LDS tiles are "natural": [rows][COLS elements] with a 32-byte row pad.  The same tile serves as a row operand
+// (ds_read_b128 of 8 consecutive k) and as a transposed operand (ds_read_b64_tr_b16 / ds_read_b32 down the k rows),
+// which is what lets P, dS, Q, K, dO be staged once and consumed by products that reduce over either of their axes.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace etp {
+
+template <typename T> struct AFrag;
+template <> struct AFrag<bf16_t> { uint4 v; };
+template <> struct AFrag<float> { float4 lo, hi; };
+
+__device__ __forceinline__ void amma(f32x4_t& acc, const AFrag<bf16_t>& a, const AFrag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void amma(f32x4_t& acc, const AFrag<float>& a, const AFrag<float>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
+}
+
+template <typename T, int COLS> struct Nat {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int CPR = COLS / EPC;
+  static constexpr int PITCH = COLS * (int)sizeof(T) + 32;
+};
+
+// global [rows_valid][cols_valid] (row stride ld) -> LDS natural tile [ROWS][COLS]; zero outside.  Branch-free loads.
+template <typename T, int ROWS, int COLS>
+__device__ __forceinline__ void nat_load(char* lds, const T* __restrict__ g, long ld, int rows_valid, int cols_valid, int tid) {
+  using N = Nat<T, COLS>;
+  constexpr int TOTAL = ROWS * N::CPR;
+  static_assert(TOTAL % 256 == 0, "tile chunk count must be a multiple of the block size");
+#pragma unroll
+  for (int j = 0; j < TOTAL / 256; ++j) {
+    const int q = tid + j * 256;
+    const int r = q / N::CPR, c = (q % N::CPR) * N::EPC;
+    const bool ok = r < rows_valid && c < cols_valid;
+    const int rc = min(r, rows_valid - 1), cc = min(c, cols_valid - N::EPC);
+    uint4 v = *reinterpret_cast<const uint4*>(g + (long)rc * ld + cc);
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    *reinterpret_cast<uint4*>(lds + r * N::PITCH + (q % N::CPR) * 16) = v;
+  }
+}
+
+// 8 k-values (k = k0 + 8*(lane>>4) + e) of tile row row16 + (lane&15)
+template <typename T, int PITCH>
+__device__ __forceinline__ void frag_row(AFrag<T>& f, const char* tile, int row16, int k0, int lane) {
+  const char* p = tile + (row16 + (lane & 15)) * PITCH + (k0 + (lane >> 4) * 8) * (int)sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    f.v = *reinterpret_cast<const uint4*>(p);
+  } else {
+    f.lo = *reinterpret_cast<const float4*>(p);
+    f.hi = *reinterpret_cast<const float4*>(p + 16);
+  }
+}
+// same 8 k-values of tile COLUMN col16 + (lane&15), k running down the tile rows
+template <typename T, int PITCH>
+__device__ __forceinline__ void frag_tr(AFrag<T>& f, const char* tile, int col16, int k0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (sizeof(T) == 2) {
+    const char* p = tile + (k0 + g * 8 + (i >> 2)) * PITCH + (col16 + (i & 3) * 4) * 2;
+    typedef short4_t __attribute__((address_space(3))) * lds_s4;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 4 * PITCH));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+    f.v = make_uint4(a.x, a.y, b.x, b.y);
+  } else {
+    const char* p = tile + (k0 + g * 8) * PITCH + (col16 + i) * 4;
+    f.lo = make_float4(*reinterpret_cast<const float*>(p), *reinterpret_cast<const float*>(p + PITCH),
+                       *reinterpret_cast<const float*>(p + 2 * PITCH), *reinterpret_cast<const float*>(p + 3 * PITCH));
+    f.hi = make_float4(*reinterpret_cast<const float*>(p + 4 * PITCH), *reinterpret_cast<const float*>(p + 5 * PITCH),
+                       *reinterpret_cast<const float*>(p + 6 * PITCH), *reinterpret_cast<const float*>(p + 7 * PITCH));
+  }
+}
+
+// acc[a][b] += sum_k A(a_row0 + 16a + ., k) * B(b_row0 + 16b + ., k);  TRx selects which tile axis is k
+template <typename T, int MT, int NT, int KSTEPS, bool TRA, bool TRB, int PA, int PB>
+__device__ __forceinline__ void tile_mma(f32x4_t (&acc)[MT][NT], const char* A, int a_row0, const char* B, int b_row0, int lane) {
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    AFrag<T> fa[MT], fb[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      if constexpr (TRA) frag_tr<T, PA>(fa[a], A, a_row0 + a * 16, s * 32, lane);
+      else frag_row<T, PA>(fa[a], A, a_row0 + a * 16, s * 32, lane);
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if constexpr (TRB) frag_tr<T, PB>(fb[b], B, b_row0 + b * 16, s * 32, lane);
+      else frag_row<T, PB>(fb[b], B, b_row0 + b * 16, s * 32, lane);
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) amma(acc[a][b], fa[a], fb[b]);
+  }
+}
+
+template <int MT, int NT> __device__ __forceinline__ void acc_zero(f32x4_t (&acc)[MT][NT]) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+// accumulators (C layout: row = 4*(lane>>4)+r, col = lane&15 per 16x16 tile) -> fp32 LDS tile [.][CP]
+template <int MT, int NT>
+__device__ __forceinline__ void acc_to_lds(const f32x4_t (&acc)[MT][NT], float* ct, int CP, int row0, int col0, float scale, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ct[(row0 + a * 16 + g * 4 + r) * CP + col0 + b * 16 + i] = acc[a][b][r] * scale;
+}
+
+// fp32 LDS tile [rows][68] -> global rows (64 columns each) as 16-byte vectors
+template <typename T, int ROWS>
+__device__ __forceinline__ void store_rows64(const float* ct, T* __restrict__ g, long ld, int rows_valid, int tid) {
+  constexpr int CP = 68;
+#pragma unroll
+  for (int j = 0; j < ROWS * 8 / 256; ++j) {
+    const int q = tid + j * 256;
+    const int r = q >> 3, c = (q & 7) * 8;
+    if (r < rows_valid) {
+      const float4 x0 = *reinterpret_cast<const float4*>(ct + r * CP + c), x1 = *reinterpret_cast<const float4*>(ct + r * CP + c + 4);
+      float o0[4] = {x0.x, x0.y, x0.z, x0.w}, o1[4] = {x1.x, x1.y, x1.z, x1.w};
+      store4(g + (long)r * ld + c, o0);
+      store4(g + (long)r * ld + c + 4, o1);
+    }
+  }
+}
+
+struct AttnKArgs {
+  const void *Q, *K, *V; long ldq, ldk, ldv;
+  void* P; int ldS;
+  void* ctx; long ldc;
+  int nh, Lq, Lk;
+  const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
+  float alpha;
+  // backward
+  const void* dctx; long ldd;
+  void *dQ, *dK, *dV; long lddq, lddk, lddv;
+  float *d_sp_w, *d_sp_b;
+};
+
+template <typename T, int BQ, int BKV> struct AttnFwdLds {
+  static constexpr int PQ = Nat<T, 64>::PITCH, PP = Nat<T, BKV>::PITCH;
+  static constexpr int QK_BYTES = (BQ + BKV) * PQ, P_BYTES = BQ * PP;
+  static constexpr int R0 = QK_BYTES > P_BYTES ? QK_BYTES : P_BYTES;   // q,k tiles; later aliased by the P tile
+  static constexpr int V_OFF = R0, CT_OFF = V_OFF + BKV * PQ;
+  static constexpr int CP = BKV + 4;
+  static constexpr int TOTAL = CT_OFF + BQ * CP * 4;
+};
+
+template <typename T, int BQ, int BKV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
+  using L = AttnFwdLds<T, BQ, BKV>;
+  constexpr int PQ = L::PQ, PP = L::PP, CP = L::CP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qt = smem; char* kt = smem + BQ * PQ; char* pt = smem; char* vt = smem + L::V_OFF;
+  float* ct = reinterpret_cast<float*>(smem + L::CT_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + (long)b * a.Lk * a.ldv + h * 64;
+  T* Pg = reinterpret_cast<T*>(a.P) + (long)blockIdx.x * a.Lq * a.ldS;
+  T* Cg = reinterpret_cast<T*>(a.ctx) + (long)b * a.Lq * a.ldc + h * 64;
+
+  nat_load<T, BQ, 64>(qt, Qg, a.ldq, a.Lq, 64, tid);
+  nat_load<T, BKV, 64>(kt, Kg, a.ldk, a.Lk, 64, tid);
+  nat_load<T, BKV, 64>(vt, Vg, a.ldv, a.Lk, 64, tid);
+  __syncthreads();
+  {  // S = alpha Q K^T
+    f32x4_t acc[BQ / 32][BKV / 32];
+    acc_zero(acc);
+    tile_mma<T, BQ / 32, BKV / 32, 2, false, false, PQ, PQ>(acc, qt, wr * (BQ / 2), kt, wc * (BKV / 2), lane);
+    acc_to_lds(acc, ct, CP, wr * (BQ / 2), wc * (BKV / 2), a.alpha, lane);
+  }
+  __syncthreads();   // scores complete; q/k tiles dead -> the P tile may overwrite them
+  const float w = a.sp_w ? a.sp_w[0] : 0.f, b0 = a.sp_b ? a.sp_b[0] : 0.f;
+  const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
+  for (int row = wave; row < BQ; row += 4) {
+    T* prow = reinterpret_cast<T*>(pt + row * PP);
+    if (row >= a.Lq) {   // zero the unused query rows of the P tile
+      for (int k = lane; k < BKV; k += 64) Elem<T>::st(prow + k, 0.f);
+      continue;
+    }
+    const float* d = a.dist ? a.dist + ((long)b * a.Lq + row) * a.Lk : nullptr;
+    float v[BKV / 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < BKV / 64; ++j) {
+      const int k = lane + j * 64;
+      float s = -INFINITY;
+      if (k < a.Lk) {
+        s = ct[row * CP + k];
+        if (km && !km[k]) s = a.mask_mode ? -INFINITY : s - 10000.0f;
+        if (d) s += w * d[k] + b0;
+      }
+      v[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < BKV / 64; ++j) {
+      v[j] = (lane + j * 64 < a.Lk) ? __expf(v[j] - mx) : 0.f;
+      sum += v[j];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < BKV / 64; ++j) {
+      const int k = lane + j * 64;
+      const float p = v[j] * inv;
+      Elem<T>::st(prow + k, p);
+      if (k < a.ldS) Elem<T>::st(Pg + (long)row * a.ldS + k, p);   // saved for backward (pad columns = 0)
+    }
+  }
+  __syncthreads();
+  {  // ctx = P V
+    f32x4_t acc[BQ / 32][2];
+    acc_zero(acc);
+    tile_mma<T, BQ / 32, 2, BKV / 32, false, true, PP, PQ>(acc, pt, wr * (BQ / 2), vt, wc * 32, lane);
+    acc_to_lds(acc, ct, 68, wr * (BQ / 2), wc * 32, 1.0f, lane);
+  }
+  __syncthreads();
+  store_rows64<T, BQ>(ct, Cg, a.ldc, a.Lq, tid);
+}
+
+template <typename T, int BQ, int BKV> struct AttnBwdLds {
+  static constexpr int PQ = Nat<T, 64>::PITCH, PP = Nat<T, BKV>::PITCH;
+  static constexpr int Q_OFF = 0, DO_OFF = BQ * PQ, K_OFF = 2 * BQ * PQ, V_OFF = K_OFF + BKV * PQ;
+  static constexpr int P_OFF = V_OFF + BKV * PQ, DS_OFF = P_OFF + BQ * PP, RD_OFF = DS_OFF + BQ * PP;
+  static constexpr int TOTAL = RD_OFF + 2 * BQ * 4 + 64;
+  static constexpr int STAGE_ROWS = BQ > BKV ? BQ : BKV;
+  static_assert(STAGE_ROWS * 68 * 4 <= P_OFF, "output staging must fit in the q/dO/k/v region");
+};
+
+template <typename T, int BQ, int BKV>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
+  using L = AttnBwdLds<T, BQ, BKV>;
+  constexpr int PQ = L::PQ, PP = L::PP;
+  constexpr int MTq = BQ / 32, MTk = BKV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *qt = smem + L::Q_OFF, *dot = smem + L::DO_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *pt = smem + L::P_OFF,
+       *dst = smem + L::DS_OFF;
+  float* rowdot = reinterpret_cast<float*>(smem + L::RD_OFF);   // [2][BQ]
+  float* red = rowdot + 2 * BQ;                                  // [16] block reduction of the sprel gradients
+  float* ct = reinterpret_cast<float*>(smem);                    // output staging (aliases q/dO/k/v once they are dead)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + (long)b * a.Lk * a.ldv + h * 64;
+  const T* Pg = reinterpret_cast<const T*>(a.P) + (long)blockIdx.x * a.Lq * a.ldS;
+  const T* Dg = reinterpret_cast<const T*>(a.dctx) + (long)b * a.Lq * a.ldd + h * 64;
+
+  nat_load<T, BQ, 64>(qt, Qg, a.ldq, a.Lq, 64, tid);
+  nat_load<T, BQ, 64>(dot, Dg, a.ldd, a.Lq, 64, tid);
+  nat_load<T, BKV, 64>(kt, Kg, a.ldk, a.Lk, 64, tid);
+  nat_load<T, BKV, 64>(vt, Vg, a.ldv, a.Lk, 64, tid);
+  nat_load<T, BQ, BKV>(pt, Pg, a.ldS, a.Lq, a.ldS, tid);
+  __syncthreads();
+
+  // dP = dO V^T, then dS = P * (dP - rowsum(dP*P)) without leaving the registers
+  f32x4_t dp[MTq][MTk];
+  acc_zero(dp);
+  tile_mma<T, MTq, MTk, 2, false, false, PQ, PQ>(dp, dot, wr * (BQ / 2), vt, wc * (BKV / 2), lane);
+  float pv[MTq][MTk][4];
+  float part[MTq][4];
+#pragma unroll
+  for (int m = 0; m < MTq; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < MTk; ++n) {
+        const int col = wc * (BKV / 2) + n * 16 + i;
+        const float p = Elem<T>::ld(reinterpret_cast<const T*>(pt + row * PP) + col);
+        pv[m][n][r] = p;
+        s += p * dp[m][n][r];
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+      part[m][r] = s;
+      if (i == 0) rowdot[wc * BQ + row] = s;
+    }
+  __syncthreads();
+  float aw = 0.f, ab = 0.f;
+#pragma unroll
+  for (int m = 0; m < MTq; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      const float dsum = rowdot[row] + rowdot[BQ + row];
+      const float* d = (a.dist && row < a.Lq) ? a.dist + ((long)b * a.Lq + row) * a.Lk : nullptr;
+#pragma unroll
+      for (int n = 0; n < MTk; ++n) {
+        const int col = wc * (BKV / 2) + n * 16 + i;
+        const float ds = pv[m][n][r] * (dp[m][n][r] - dsum);
+        Elem<T>::st(reinterpret_cast<T*>(dst + row * PP) + col, ds);
+        if (d && col < a.Lk) { aw += ds * d[col]; ab += ds; }
+      }
+    }
+  (void)part;
+  __syncthreads();
+
+  // dV = P^T dO, dK = alpha dS^T Q (rows = keys), dQ = alpha dS K (rows = queries)
+  f32x4_t dv[MTk][2], dk[MTk][2], dq[MTq][2];
+  acc_zero(dv); acc_zero(dk); acc_zero(dq);
+  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dv, pt, wr * (BKV / 2), dot, wc * 32, lane);
+  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dk, dst, wr * (BKV / 2), qt, wc * 32, lane);
+  tile_mma<T, MTq, 2, BKV / 32, false, true, PP, PQ>(dq, dst, wr * (BQ / 2), kt, wc * 32, lane);
+  __syncthreads();   // every operand tile is dead: reuse the front of LDS as the fp32 staging tile
+
+  T* dQg = reinterpret_cast<T*>(a.dQ) + (long)b * a.Lq * a.lddq + h * 64;
+  T* dKg = reinterpret_cast<T*>(a.dK) + (long)b * a.Lk * a.lddk + h * 64;
+  T* dVg = reinterpret_cast<T*>(a.dV) + (long)b * a.Lk * a.lddv + h * 64;
+  acc_to_lds(dv, ct, 68, wr * (BKV / 2), wc * 32, 1.0f, lane);
+  __syncthreads();
+  store_rows64<T, BKV>(ct, dVg, a.lddv, a.Lk, tid);
+  __syncthreads();
+  acc_to_lds(dk, ct, 68, wr * (BKV / 2), wc * 32, a.alpha, lane);
+  __syncthreads();
+  store_rows64<T, BKV>(ct, dKg, a.lddk, a.Lk, tid);
+  __syncthreads();
+  acc_to_lds(dq, ct, 68, wr * (BQ / 2), wc * 32, a.alpha, lane);
+  __syncthreads();
+  store_rows64<T, BQ>(ct, dQg, a.lddq, a.Lq, tid);
+
+  if (a.d_sp_w != nullptr) {   // d sprel_linear.{weight,bias} (vilmodel_cmt.py:732-736)
+    aw = wave_sum(aw); ab = wave_sum(ab);
+    if (lane == 0) { red[wave] = aw; red[4 + wave] = ab; }
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(a.d_sp_w, red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(a.d_sp_b, red[4] + red[5] + red[6] + red[7]);
+    }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static bool fused_enabled() {
+  const char* e = getenv("ETP_ATTN_FUSED");
+  return !(e && e[0] == '0');
+}
+bool attn_fused_ok(int dt, const AttnBuf& a, long ldc) {
+  if (!fused_enabled()) return false;
+  if (a.Lq > 128 || a.Lk > 128 || a.Lq < 1 || a.Lk < 1) return false;
+  if (dt == ETP_F32 && (a.Lq > 64 || a.Lk > 64)) return false;        // fp32 tiles of 128 rows do not fit 160 KB of LDS
+  const int epc = dt == ETP_BF16 ? 8 : 4;
+  if (a.ldq % epc || a.ldk % epc || a.ldv % epc || ldc % epc || a.ldS % epc) return false;
+  if (((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V) % 16) return false;
+  return true;
+}
+
+template <typename T, int BQ, int BKV> static int launch_fwd(const AttnKArgs& k, int blocks, hipStream_t st) {
+  constexpr int smem = AttnFwdLds<T, BQ, BKV>::TOTAL;
+  static bool attr = false;
+  auto kern = attn_fwd_kernel<T, BQ, BKV>;
+  if (!attr) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, st, k);
+  ETP_CHECK_LAUNCH("attn_fwd");
+  return ETP_OK;
+}
+template <typename T, int BQ, int BKV> static int launch_bwd(const AttnKArgs& k, int blocks, hipStream_t st) {
+  constexpr int smem = AttnBwdLds<T, BQ, BKV>::TOTAL;
+  static bool attr = false;
+  auto kern = attn_bwd_kernel<T, BQ, BKV>;
+  if (!attr) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, st, k);
+  ETP_CHECK_LAUNCH("attn_bwd");
+  return ETP_OK;
+}
+
+static AttnKArgs make_args(int nh, const AttnBuf& a, float alpha) {
+  AttnKArgs k;
+  memset(&k, 0, sizeof(k));
+  k.Q = a.Q; k.K = a.K; k.V = a.V; k.ldq = a.ldq; k.ldk = a.ldk; k.ldv = a.ldv;
+  k.ldS = a.ldS; k.nh = nh; k.Lq = a.Lq; k.Lk = a.Lk;
+  k.keymask = a.keymask; k.mask_mode = a.mask_mode; k.dist = a.dist; k.sp_w = a.sp_w; k.sp_b = a.sp_b; k.alpha = alpha;
+  return k;
+}
+
+int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
+  AttnKArgs k = make_args(nh, a, alpha);
+  k.P = P; k.ctx = ctx; k.ldc = ldc;
+  const int blocks = a.B * nh;
+  const bool bq = a.Lq > 64, bk = a.Lk > 64;
+  if (dt == ETP_BF16) {
+    if (bq && bk) return launch_fwd<bf16_t, 128, 128>(k, blocks, st);
+    if (bq) return launch_fwd<bf16_t, 128, 64>(k, blocks, st);
+    if (bk) return launch_fwd<bf16_t, 64, 128>(k, blocks, st);
+    return launch_fwd<bf16_t, 64, 64>(k, blocks, st);
+  }
+  return launch_fwd<float, 64, 64>(k, blocks, st);
+}
+
+int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK,
+                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st) {
+  AttnKArgs k = make_args(nh, a, alpha);
+  k.P = const_cast<void*>(P); k.dctx = dctx; k.ldd = ldd;
+  k.dQ = dQ; k.dK = dK; k.dV = dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv; k.d_sp_w = d_sp_w; k.d_sp_b = d_sp_b;
+  const int blocks = a.B * nh;
+  const bool bq = a.Lq > 64, bk = a.Lk > 64;
+  if (dt == ETP_BF16) {
+    if (bq && bk) return launch_bwd<bf16_t, 128, 128>(k, blocks, st);
+    if (bq) return launch_bwd<bf16_t, 128, 64>(k, blocks, st);
+    if (bk) return launch_bwd<bf16_t, 64, 128>(k, blocks, st);
+    return launch_bwd<bf16_t, 64, 64>(k, blocks, st);
+  }
+  return launch_bwd<float, 64, 64>(k, blocks, st);
+}
+
+}  // namespace etp

@@ -108,8 +108,10 @@ struct GemmArgs {
   int act;                            // ETP_ACT_*
   int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
   int vec_epilogue;                   // set by launch_gemm: 16-byte epilogue accesses are legal
+  float* a_colsum;                    // TN (wgrad) only: a_colsum[m] += sum_k A[m,k]  (bias gradient), LDS-DMA kernel only
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
+bool gemm_uses_dma(int dtype, int K, int ksplit);   // true when launch_gemm will take the LDS-DMA kernel for this reduction
 void prof_enable(bool on);
 void prof_reset();
 int prof_report(etp_prof_entry* out, int cap);

@@ -87,31 +87,46 @@ template <int NCH> __device__ __forceinline__ void row_ln_bwd(Row<NCH>& d, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) d.v[c][e] = rstd * (d.v[c][e] - c1 - xhat.v[c][e] * c2);
 }
-// LDS accumulate: acc[col] += a*b (used for dgamma = dy*xhat etc.)
-template <int NCH> __device__ __forceinline__ void lds_acc_mul(float* acc, const Row<NCH>& a, const Row<NCH>& b, int lane) {
+// Per-lane register accumulators for the parameter gradients that reduce over rows (dgamma = sum dy*xhat, ...).
+// Each wave accumulates over the rows it owns; block_flush then sums the block's 4 waves through a [4][H] LDS
+// scratch and issues ONE global atomic per column per block.  (LDS float atomics were measured 60x slower here.)
+template <int NCH> __device__ __forceinline__ void row_zero(Row<NCH>& a) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(acc + c * 256 + lane * 4 + e, a.v[c][e] * b.v[c][e]);
+    for (int e = 0; e < 4; ++e) a.v[c][e] = 0.f;
 }
-template <int NCH> __device__ __forceinline__ void lds_acc(float* acc, const Row<NCH>& a, float s, int lane) {
+template <int NCH> __device__ __forceinline__ void acc_mul(Row<NCH>& acc, const Row<NCH>& a, const Row<NCH>& b) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(acc + c * 256 + lane * 4 + e, a.v[c][e] * s);
+    for (int e = 0; e < 4; ++e) acc.v[c][e] += a.v[c][e] * b.v[c][e];
+}
+template <int NCH> __device__ __forceinline__ void acc_scaled(Row<NCH>& acc, const Row<NCH>& a, float s) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc.v[c][e] += a.v[c][e] * s;
+}
+// dst[col*stride + off] += sum over the block's waves of acc[col];  scratch: 4*H floats of LDS
+template <int NCH> __device__ __forceinline__ void block_flush(float* scratch, const Row<NCH>& acc, float* dst, int stride,
+                                                               int off) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) scratch[wave * H + c * 256 + lane * 4 + e] = acc.v[c][e];
+  __syncthreads();
+  for (int col = threadIdx.x; col < H; col += 256)
+    atomicAdd(dst + (long)col * stride + off, scratch[col] + scratch[H + col] + scratch[2 * H + col] + scratch[3 * H + col]);
+  __syncthreads();
 }
 template <int NCH> __device__ __forceinline__ void global_acc(float* dst, const Row<NCH>& a, int lane) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicAdd(dst + c * 256 + lane * 4 + e, a.v[c][e]);
-}
-__device__ __forceinline__ void lds_zero(float* p, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
-  __syncthreads();
-}
-__device__ __forceinline__ void lds_flush(float* dst, const float* src, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(dst + i, src[i]);
 }
 
 // --------------------------------------------------------------------------------------
@@ -150,8 +165,9 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict
                                                              float* __restrict__ dpos, float* __restrict__ dtype0,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int L) {
   constexpr int H = NCH * 256;
-  __shared__ float acc[3 * H];  // dgamma, dbeta, dtype0
-  lds_zero(acc, 3 * H);
+  __shared__ float scratch[4 * H];
+  Row<NCH> a_g, a_b, a_t;   // dgamma, dbeta, dtype0
+  row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_t);
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const long id = ids[row];
@@ -168,17 +184,16 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) x.v[c][e] = (x.v[c][e] - mean) * rstd;
     row_load<NCH>(d, dy + (long)row * H, lane);
-    lds_acc_mul<NCH>(acc, d, x, lane);
-    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    acc_mul<NCH>(a_g, d, x);
+    acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
-    lds_acc<NCH>(acc + 2 * H, d, 1.0f, lane);
+    acc_scaled<NCH>(a_t, d, 1.0f);
     if (id != 0) global_acc<NCH>(dword + id * H, d, lane);
     global_acc<NCH>(dpos + (long)l * H, d, lane);
   }
-  __syncthreads();
-  lds_flush(dgamma, acc, H);
-  lds_flush(dbeta, acc + H, H);
-  lds_flush(dtype0, acc + 2 * H, H);
+  block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
+  block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
+  block_flush<NCH>(scratch, a_t, dtype0, 1, 0);
 }
 
 // --------------------------------------------------------------------------------------
@@ -245,12 +260,12 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict
                                                              PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
                                                              T* __restrict__ dd, int M) {
   constexpr int H = NCH * 256;
-  // LDS accumulators: g/b x {img,dep,loc,out} (8H) + nav_emb (2H) + type1 (H) + bias_loc (H) + w_loc (4H) = 16H
-  extern __shared__ __attribute__((aligned(16))) float acc[];
-  lds_zero(acc, 16 * H);
-  float *A_gi = acc, *A_bi = acc + H, *A_gd = acc + 2 * H, *A_bd = acc + 3 * H, *A_gl = acc + 4 * H, *A_bl = acc + 5 * H,
-        *A_go = acc + 6 * H, *A_bo = acc + 7 * H, *A_nav = acc + 8 * H, *A_ty = acc + 10 * H, *A_lb = acc + 11 * H,
-        *A_lw = acc + 12 * H;
+  // register accumulators: g/b x {img,dep,loc,out} + nav_emb[0..1] + type1 + bias_loc + w_loc[.,0..3] = 16 rows
+  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
+  Row<NCH> A_gi, A_bi, A_gd, A_bd, A_gl, A_bl, A_go, A_bo, A_nav0, A_nav1, A_ty, A_lb, A_lw0, A_lw1, A_lw2, A_lw3;
+  row_zero<NCH>(A_gi); row_zero<NCH>(A_bi); row_zero<NCH>(A_gd); row_zero<NCH>(A_bd); row_zero<NCH>(A_gl); row_zero<NCH>(A_bl);
+  row_zero<NCH>(A_go); row_zero<NCH>(A_bo); row_zero<NCH>(A_nav0); row_zero<NCH>(A_nav1); row_zero<NCH>(A_ty); row_zero<NCH>(A_lb);
+  row_zero<NCH>(A_lw0); row_zero<NCH>(A_lw1); row_zero<NCH>(A_lw2); row_zero<NCH>(A_lw3);
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const float* st = stats + (long)row * 8;
@@ -289,27 +304,22 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict
       for (int k = 0; k < 4; ++k) e.v[c][k] = (e.v[c][k] - st[6]) * st[7];
     // outer LN backward
     row_load<NCH>(de, dy + (long)row * H, lane);
-    lds_acc_mul<NCH>(A_go, de, e, lane);
-    lds_acc<NCH>(A_bo, de, 1.0f, lane);
+    acc_mul<NCH>(A_go, de, e);
+    acc_scaled<NCH>(A_bo, de, 1.0f);
     row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);   // de = grad wrt the branch sum
-    lds_acc<NCH>(A_nav + nv * H, de, 1.0f, lane);
-    lds_acc<NCH>(A_ty, de, 1.0f, lane);
+    acc_scaled<NCH>(A_nav0, de, nv == 0 ? 1.0f : 0.0f);
+    acc_scaled<NCH>(A_nav1, de, nv == 0 ? 0.0f : 1.0f);
+    acc_scaled<NCH>(A_ty, de, 1.0f);
     // loc branch (x still holds its xhat)
     t = de;
-    lds_acc_mul<NCH>(A_gl, t, x, lane);
-    lds_acc<NCH>(A_bl, t, 1.0f, lane);
+    acc_mul<NCH>(A_gl, t, x);
+    acc_scaled<NCH>(A_bl, t, 1.0f);
     row_ln_bwd<NCH>(t, x, p.g_loc, st[5], lane);
-    lds_acc<NCH>(A_lb, t, 1.0f, lane);
+    acc_scaled<NCH>(A_lb, t, 1.0f);
     {
       const float* l4 = loc + (long)row * 4;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int col = c * 256 + lane * 4 + k;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(A_lw + col * 4 + j, t.v[c][k] * l4[j]);
-        }
+      acc_scaled<NCH>(A_lw0, t, l4[0]); acc_scaled<NCH>(A_lw1, t, l4[1]);
+      acc_scaled<NCH>(A_lw2, t, l4[2]); acc_scaled<NCH>(A_lw3, t, l4[3]);
     }
     // img branch
     row_load<NCH>(x, a + (long)row * H, lane);
@@ -318,8 +328,8 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict
 #pragma unroll
       for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
     t = de;
-    lds_acc_mul<NCH>(A_gi, t, x, lane);
-    lds_acc<NCH>(A_bi, t, 1.0f, lane);
+    acc_mul<NCH>(A_gi, t, x);
+    acc_scaled<NCH>(A_bi, t, 1.0f);
     row_ln_bwd<NCH>(t, x, p.g_img, st[1], lane);
     row_store<NCH>(t, da + (long)row * H, lane);
     if (d != nullptr) {
@@ -329,21 +339,21 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
       t = de;
-      lds_acc_mul<NCH>(A_gd, t, x, lane);
-      lds_acc<NCH>(A_bd, t, 1.0f, lane);
+      acc_mul<NCH>(A_gd, t, x);
+      acc_scaled<NCH>(A_bd, t, 1.0f);
       row_ln_bwd<NCH>(t, x, p.g_dep, st[3], lane);
       row_store<NCH>(t, dd + (long)row * H, lane);
     }
   }
-  __syncthreads();
-  lds_flush(g.g_img, A_gi, H); lds_flush(g.b_img, A_bi, H);
-  if (d != nullptr) { lds_flush(g.g_dep, A_gd, H); lds_flush(g.b_dep, A_bd, H); }
-  lds_flush(g.g_loc, A_gl, H); lds_flush(g.b_loc, A_bl, H);
-  lds_flush(g.g_out, A_go, H); lds_flush(g.b_out, A_bo, H);
-  lds_flush(g.nav_emb, A_nav, 2 * H);
-  lds_flush(g.type1, A_ty, H);
-  lds_flush(g.bias_loc, A_lb, H);
-  lds_flush(g.w_loc, A_lw, 4 * H);
+  block_flush<NCH>(scratch, A_gi, g.g_img, 1, 0); block_flush<NCH>(scratch, A_bi, g.b_img, 1, 0);
+  if (d != nullptr) { block_flush<NCH>(scratch, A_gd, g.g_dep, 1, 0); block_flush<NCH>(scratch, A_bd, g.b_dep, 1, 0); }
+  block_flush<NCH>(scratch, A_gl, g.g_loc, 1, 0); block_flush<NCH>(scratch, A_bl, g.b_loc, 1, 0);
+  block_flush<NCH>(scratch, A_go, g.g_out, 1, 0); block_flush<NCH>(scratch, A_bo, g.b_out, 1, 0);
+  block_flush<NCH>(scratch, A_nav0, g.nav_emb, 1, 0); block_flush<NCH>(scratch, A_nav1, g.nav_emb + H, 1, 0);
+  block_flush<NCH>(scratch, A_ty, g.type1, 1, 0);
+  block_flush<NCH>(scratch, A_lb, g.bias_loc, 1, 0);
+  block_flush<NCH>(scratch, A_lw0, g.w_loc, 4, 0); block_flush<NCH>(scratch, A_lw1, g.w_loc, 4, 1);
+  block_flush<NCH>(scratch, A_lw2, g.w_loc, 4, 2); block_flush<NCH>(scratch, A_lw3, g.w_loc, 4, 3);
 }
 
 // --------------------------------------------------------------------------------------
@@ -397,8 +407,11 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const T* __restrict
                                                              float* __restrict__ d_w_pos, float* __restrict__ d_b_pos,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
   constexpr int H = NCH * 256;
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // dgamma, dbeta, d_b_pos, d_w_pos[PK]
-  lds_zero(acc, (3 + PK) * H);
+  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
+  Row<NCH> a_g, a_b, a_bp, a_w[PK];                                  // dgamma, dbeta, d_b_pos, d_w_pos[.,j]
+  row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_bp);
+#pragma unroll
+  for (int j = 0; j < PK; ++j) row_zero<NCH>(a_w[j]);
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     Row<NCH> t, d;
@@ -410,25 +423,19 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const T* __restrict
       for (int e = 0; e < 4; ++e) t.v[c][e] = (t.v[c][e] - mean) * rstd;
     row_load<NCH>(d, dx + (long)row * H, lane);
     global_acc<NCH>(d_step_emb + step_ids[row] * H, d, lane);
-    lds_acc_mul<NCH>(acc, d, t, lane);
-    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    acc_mul<NCH>(a_g, d, t);
+    acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, t, gamma, rstd, lane);
-    lds_acc<NCH>(acc + 2 * H, d, 1.0f, lane);
+    acc_scaled<NCH>(a_bp, d, 1.0f);
     const float* pr = pos + (long)row * PK;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int col = c * 256 + lane * 4 + e;
-#pragma unroll
-        for (int j = 0; j < PK; ++j) atomicAdd(acc + 3 * H + col * PK + j, d.v[c][e] * pr[j]);
-      }
+    for (int j = 0; j < PK; ++j) acc_scaled<NCH>(a_w[j], d, pr[j]);
   }
-  __syncthreads();
-  lds_flush(dgamma, acc, H);
-  lds_flush(dbeta, acc + H, H);
-  lds_flush(d_b_pos, acc + 2 * H, H);
-  lds_flush(d_w_pos, acc + 3 * H, PK * H);
+  block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
+  block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
+  block_flush<NCH>(scratch, a_bp, d_b_pos, 1, 0);
+#pragma unroll
+  for (int j = 0; j < PK; ++j) block_flush<NCH>(scratch, a_w[j], d_w_pos, PK, j);
 }
 
 // --------------------------------------------------------------------------------------
@@ -469,8 +476,11 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
                                                            float* __restrict__ dbeta, float* __restrict__ dw2,
                                                            float* __restrict__ db2, int M) {
   constexpr int H = NCH * 256;
-  __shared__ float acc[3 * H + 4];
-  lds_zero(acc, 3 * H + 4);
+  __shared__ float scratch[4 * H];
+  __shared__ float sb2[4];
+  Row<NCH> a_g, a_b, a_w;   // dgamma, dbeta, dw2
+  row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_w);
+  float a_b2 = 0.f;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const bool masked = (visited && visited[row]) || (valid && !valid[row]);
@@ -483,15 +493,15 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) x.v[c][e] = (rr.v[c][e] - mean) * rstd;
     row_affine<NCH>(n, x, gamma, beta, lane);
-    lds_acc<NCH>(acc + 2 * H, n, dl, lane);          // dw2 += dl * n
-    if (lane == 0) atomicAdd(acc + 3 * H, dl);       // db2
+    acc_scaled<NCH>(a_w, n, dl);                     // dw2 += dl * n
+    a_b2 += dl;                                      // db2 (same value on every lane)
     row_load<NCH>(d, w2, lane);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) d.v[c][e] *= dl;
-    lds_acc_mul<NCH>(acc, d, x, lane);
-    lds_acc<NCH>(acc + H, d, 1.0f, lane);
+    acc_mul<NCH>(a_g, d, x);
+    acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -499,11 +509,11 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) d.v[c][e] = rr.v[c][e] > 0.f ? d.v[c][e] : 0.f;
     row_store<NCH>(d, dz + (long)row * H, lane);
   }
-  __syncthreads();
-  lds_flush(dgamma, acc, H);
-  lds_flush(dbeta, acc + H, H);
-  lds_flush(dw2, acc + 2 * H, H);
-  if (threadIdx.x == 0) atomicAdd(db2, acc[3 * H]);
+  if (lane == 0) sb2[threadIdx.x >> 6] = a_b2;
+  block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
+  block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
+  block_flush<NCH>(scratch, a_w, dw2, 1, 0);
+  if (threadIdx.x == 0) atomicAdd(db2, sb2[0] + sb2[1] + sb2[2] + sb2[3]);
 }
 
 // --------------------------------------------------------------------------------------
@@ -668,8 +678,8 @@ int pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, cons
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
                    hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
-  const int grid = row_grid(M, 64);
-  const size_t smem = 16 * (size_t)H * sizeof(float);
+  const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
+  const size_t smem = 4 * (size_t)H * sizeof(float);
   if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M)); }
   else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, (const float*)dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M)); }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
@@ -692,7 +702,7 @@ int gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const flo
                    float* dbeta, int M, int H, int PK, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
   const int grid = row_grid(M, 64);
-  const size_t smem = (3 + 7) * (size_t)H * sizeof(float);
+  const size_t smem = 4 * (size_t)H * sizeof(float);
   if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
   else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, (const float*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
   ETP_CHECK_LAUNCH("gmap_embed_bwd");

@@ -551,6 +551,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
+  float colsum_acc = 0.f;
   DmaPlan<T, TA, BM> pa;
   DmaPlan<T, TB, BN> pb;
   dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
@@ -576,6 +578,19 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
     }
     const char* sa = smem + (t % STAGES) * STAGE;
     const char* sb = sa + GA::BYTES;
+    if constexpr (TA) {
+      // fused bias gradient: blocks of the first tile column also sum the A tile ([k][rows]) over k
+      if (do_colsum) {
+        constexpr int KQ = 256 / BM, RPT = BK / KQ;
+        const int col = tid % BM, kq = tid / BM;
+        const int chunk = col / GA::EPC, within = (col % GA::EPC) * (int)sizeof(T);
+#pragma unroll 4
+        for (int e = 0; e < RPT; ++e) {
+          const int kr = kq * RPT + e;
+          colsum_acc += Elem<T>::ld(reinterpret_cast<const T*>(sa + kr * GA::PITCH + ((chunk ^ tr_swz<GA::CPR>(kr)) << 4) + within));
+        }
+      }
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       Frag<T> fa[MT], fb[NT];
@@ -590,6 +605,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
     }
   }
   wait_vmcnt<0>();
+  if constexpr (TA) {
+    if (do_colsum && m0 + (tid % BM) < g.M) atomicAdd(g.a_colsum + m0 + (tid % BM), colsum_acc);
+  }
   __syncthreads();
   gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
 }
@@ -673,6 +691,16 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   return ETP_OK;
 }
 
+static bool dma_ok(int bk, int K, int ksplit) {
+  // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
+  bool dma = (K % bk == 0) && (K >= 2 * bk);
+  if (ksplit > 1) dma = dma && (K % ksplit == 0) && ((K / ksplit) % bk == 0);
+  const char* force = getenv("ETP_GEMM_TILE");
+  if (force && strchr(force, 'r')) dma = false;
+  return dma;
+}
+bool gemm_uses_dma(int dtype, int K, int ksplit) { return dma_ok(dtype == ETP_BF16 ? 64 : 32, K, ksplit); }
+
 template <typename T, typename TC, bool TA, bool TB>
 static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   // Tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64 (fills 256 CUs on the
@@ -680,14 +708,11 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   constexpr int BK = MmaTraits<T>::BK;
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
   bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
-  // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
-  bool dma = (g.K % BK == 0) && (g.K >= 2 * BK);
-  if (g.ksplit > 1) dma = dma && (((g.K + g.ksplit - 1) / g.ksplit) % BK == 0) && (g.K % g.ksplit == 0);
+  bool dma = dma_ok(BK, g.K, g.ksplit);
   int stages = 2;
   const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r"
   if (force && force[0]) {
     big = force[0] == '1';
-    if (strchr(force, 'r')) dma = false;
     if (strstr(force, "s3")) stages = 3;
   }
   if (!dma) {
@@ -720,6 +745,8 @@ int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, in
               "batch strides must keep 16-byte alignment");
   ETP_REQUIRE(g0.out_mode != 2 || c_dtype == ETP_F32, "atomic accumulation needs an fp32 C");
   ETP_REQUIRE(g0.ksplit == 1 || g0.out_mode == 2, "split-K needs atomic accumulation");
+  ETP_REQUIRE(g0.a_colsum == nullptr || (ta && tb && gemm_uses_dma(dtype, g0.K, g0.ksplit)),
+              "a_colsum needs the TN LDS-DMA kernel (check gemm_uses_dma first)");
   GemmArgs g = g_in;
   {  // the vectorised epilogue needs 8-column chunks to stay in-bounds and 16-byte aligned
     const size_t cs = dtype_size(c_dtype), ts = dtype_size(dtype);

@@ -56,6 +56,11 @@ struct AttnBuf {
   int B, Lq, Lk, ldS;
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
 };
+// fused single-kernel variants (attn.hip) for Lq, Lk <= 128
+bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);
+int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st);
+int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK,
+                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st);
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st);
 int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
                   void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st);

@@ -138,7 +138,7 @@ static int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* 
 template <typename T>
 static int ln_bwd_t(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                     float* dgamma, float* dbeta, int M, int H, hipStream_t st) {
-  const int grid = (int)std::min<long>((M + 3) / 4, 256);
+  const int grid = (int)std::min<long>((M + 7) / 8, 128);   // 2 rows per wave minimum; each block flushes 2*H atomics
   switch (H / 256) {
     case 1: hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
     case 2: hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;

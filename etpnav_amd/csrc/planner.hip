@@ -260,8 +260,10 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
   int ks = (tiles <= 144 && M >= 2048 && M % (4 * bk) == 0) ? 4 : 1;
   g.ksplit = ks;
   g.out_mode = ks > 1 ? 2 : 1;
+  const bool fuse_bias = bi >= 0 && gemm_uses_dma(c.dt, M, ks);     // bias gradient rides in the wgrad kernel
+  if (fuse_bias) g.a_colsum = c.pl->gf(bi);
   ETP_TRY(launch_gemm(c.dt, ETP_F32, 1, 1, g, 1, c.st));
-  if (bi >= 0) ETP_TRY(colsum(c.dt, dY, ldy, c.pl->gf(bi), M, N, c.st));
+  if (bi >= 0 && !fuse_bias) ETP_TRY(colsum(c.dt, dY, ldy, c.pl->gf(bi), M, N, c.st));
   return ETP_OK;
 }
 
@@ -271,6 +273,7 @@ static inline void* offs(void* p, long elems, size_t es) { return reinterpret_ca
 
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
   const int dh = 64;
+  if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st);
   GemmArgs g = base_args();
   // S = alpha * Q K^T
   g.A = a.Q; g.lda = a.ldq; g.sAo = (long)a.Lq * a.ldq; g.sAi = dh;
@@ -291,6 +294,11 @@ int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc
 int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
                   void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st) {
   const int dh = 64;
+  {
+    const int epc = dt == ETP_BF16 ? 8 : 4;
+    if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
+      return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st);
+  }
   const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;
   // dP = dctx V^T
   GemmArgs g = base_args();
