@@ -98,7 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="issue kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a captured hipGraph (one side stream) instead of eager three-stream issue; measured "
+                         "slower on MI355X: the step is not launch-bound (DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
     args = ap.parse_args()
@@ -126,14 +128,14 @@ def main():
     model.init_weights(seed=0)                                   # same weights on every rank (DDP's broadcast)
     batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
                        seed=1234 + rank)                          # each rank owns its episodes
-    step = PlannerStep(model, batch)
+    use_graph = args.graph
+    step = PlannerStep(model, batch, overlap="s2" if use_graph else True)
     reducer = None
     if world > 1:
         ranges, sparse = dp.planner_buckets(model)
         reducer = dp.GradReducer(model.flat_grads, ranges,
                                  comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
                                  sparse_rows=sparse)
-    use_graph = not args.no_graph
     if use_graph:
         step.capture(split_text_bwd=world > 1)
 
@@ -144,7 +146,7 @@ def main():
         if use_graph:
             step.replay(part=0)
         else:
-            step.enqueue_main(model._engine.stream())
+            step.enqueue_main(model._engine.stream(), True, join_pano=True)
         reducer.reduce_bucket(0)                                 # non-text matrices: overlaps the text backward
         if use_graph:
             step.replay(part=1)
@@ -209,7 +211,7 @@ def main():
         fl = flops_per_step(w, cfg)
         out = {
             "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
-            "value": round(world * 1.0 / (ms_per_step * 1e-3), 3) if False else round(args.steps / elapsed * world, 3),
+            "value": round(args.steps / elapsed * world, 3),
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -202,6 +202,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
   __syncthreads();   // scores complete; q/k tiles dead -> the P tile may overwrite them
   const float w = a.sp_w ? a.sp_w[0] : 0.f, b0 = a.sp_b ? a.sp_b[0] : 0.f;
   const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
+  float kadd[BKV / 64];   // additive key mask of this lane's keys, loaded once (not once per row)
+#pragma unroll
+  for (int j = 0; j < BKV / 64; ++j) {
+    const int k = lane + j * 64;
+    kadd[j] = (km && k < a.Lk && !km[k]) ? (a.mask_mode ? -INFINITY : -10000.0f) : 0.f;
+  }
   for (int row = wave; row < BQ; row += 4) {
     T* prow = reinterpret_cast<T*>(pt + row * PP);
     if (row >= a.Lq) {   // zero the unused query rows of the P tile
@@ -216,8 +222,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
       const int k = lane + j * 64;
       float s = -INFINITY;
       if (k < a.Lk) {
-        s = ct[row * CP + k];
-        if (km && !km[k]) s = a.mask_mode ? -INFINITY : s - 10000.0f;
+        s = ct[row * CP + k] + kadd[j];
         if (d) s += w * d[k] + b0;
       }
       v[j] = s;

@@ -1,6 +1,8 @@
 // extern "C" surface of libetpnav_hip.so: per-operator entry points, hipGraph helpers, error state.
 #include <string.h>
 
+#include <vector>
+
 #include "kernels.h"
 
 namespace etp {
@@ -170,6 +172,21 @@ int etp_stream_create(etp_stream_t* out) {
 }
 int etp_stream_destroy(etp_stream_t s) { ETP_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return ETP_OK; }
 int etp_stream_sync(etp_stream_t s) { ETP_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return ETP_OK; }
+int etp_stream_after(etp_stream_t from, etp_stream_t to) {
+  // order `to` after everything enqueued so far on `from`; capturable (becomes a graph edge and pulls `to` into the capture)
+  static std::vector<hipEvent_t> pool;
+  static size_t next = 0;
+  if (from == to) return ETP_OK;
+  if (pool.empty()) {
+    pool.resize(64);
+    for (auto& e : pool) ETP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipEvent_t e = pool[next];
+  next = (next + 1) % pool.size();
+  ETP_CHECK_HIP(hipEventRecord(e, (hipStream_t)from));
+  ETP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)to, e, 0));
+  return ETP_OK;
+}
 int etp_graph_begin(etp_stream_t s) {
   ETP_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
   return ETP_OK;

@@ -45,6 +45,19 @@ struct etp_planner {
   int sap0_w, sap0_b, sap2_g, sap2_b, sap4_w, sap4_b;
   // bound arenas
   float* P = nullptr; void* S = nullptr; float* G = nullptr;
+  // optional second stream: weight-gradient GEMMs (leaves of the backward graph) run beside the dgrad chain
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  hipEvent_t next_event() {
+    if (events.empty()) {
+      events.resize(256);
+      for (auto& e : events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+    hipEvent_t e = events[ev_next];
+    ev_next = (ev_next + 1) % events.size();
+    return e;
+  }
 
   long off(int i) const { return params[i].offset; }
   const float* pf(int i) const { return P + params[i].offset; }          // fp32 parameter
@@ -213,13 +226,25 @@ struct Bump {
 struct Ctx {
   etp_planner* pl; hipStream_t st; int dt; size_t es;  // element size of T
   int H, I, nh;
+  hipStream_t sw;                                      // stream of the weight-gradient launches (== st when no aux stream)
 };
 static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
   Ctx c;
   c.pl = pl; c.st = reinterpret_cast<hipStream_t>(s); c.dt = pl->cfg.dtype; c.es = dtype_size(c.dt);
+  c.sw = (pl->aux != nullptr && pl->aux != c.st) ? pl->aux : c.st;
   c.H = pl->cfg.hidden; c.I = pl->cfg.inter; c.nh = pl->cfg.heads;
   return c;
 }
+
+// order `to` after everything enqueued so far on `from` (capturable: becomes a graph edge)
+static int stream_after(etp_planner* pl, hipStream_t from, hipStream_t to) {
+  if (from == to) return ETP_OK;
+  hipEvent_t e = pl->next_event();
+  ETP_CHECK_HIP(hipEventRecord(e, from));
+  ETP_CHECK_HIP(hipStreamWaitEvent(to, e, 0));
+  return ETP_OK;
+}
+static int join_wgrads(const Ctx& c) { return stream_after(c.pl, c.sw, c.st); }
 
 static GemmArgs base_args() {
   GemmArgs g;
@@ -262,8 +287,10 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
   g.out_mode = ks > 1 ? 2 : 1;
   const bool fuse_bias = bi >= 0 && gemm_uses_dma(c.dt, M, ks);     // bias gradient rides in the wgrad kernel
   if (fuse_bias) g.a_colsum = c.pl->gf(bi);
-  ETP_TRY(launch_gemm(c.dt, ETP_F32, 1, 1, g, 1, c.st));
-  if (bi >= 0 && !fuse_bias) ETP_TRY(colsum(c.dt, dY, ldy, c.pl->gf(bi), M, N, c.st));
+  // weight gradients are leaves of the backward graph: issue them on the side stream, after dY's producer
+  ETP_TRY(stream_after(c.pl, c.st, c.sw));
+  ETP_TRY(launch_gemm(c.dt, ETP_F32, 1, 1, g, 1, c.sw));
+  if (bi >= 0 && !fuse_bias) ETP_TRY(colsum(c.dt, dY, ldy, c.pl->gf(bi), M, N, c.sw));
   return ETP_OK;
 }
 
@@ -463,6 +490,11 @@ int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads) 
   p->P = params; p->S = shadow; p->G = grads;
   return ETP_OK;
 }
+int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux) {
+  ETP_REQUIRE(p, "null planner");
+  p->aux = reinterpret_cast<hipStream_t>(aux);
+  return ETP_OK;
+}
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P, "planner not bound");
   if (p->cfg.dtype != ETP_BF16) return ETP_OK;
@@ -476,10 +508,11 @@ int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L) {
   plan_txt(p, b, B, L);
   return (int64_t)b.off + 256;
 }
+// Scratch of ONE backward sub-block.  Every sub-block gets a fresh set (HBM is plentiful) so that weight-gradient
+// GEMMs still running on the side stream never see their dY operand overwritten by a later layer.
 static BwdWs plan_ws(Bump& b, size_t es, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
   BwdWs w;
   memset(&w, 0, sizeof(w));
-  w.g = b.take(M * H * es);
   w.t1 = b.take(M * H * es);
   w.t2 = b.take(M * H * es);
   w.dI = b.take(M * I * es);
@@ -490,7 +523,9 @@ static BwdWs plan_ws(Bump& b, size_t es, long M, int Bn, int nh, int Lq, int ldS
 int64_t etp_txt_ws_bytes(const etp_planner* p, int B, int L) {
   if (!p) return 0;
   Bump b(nullptr);
-  plan_ws(b, dtype_size(p->cfg.dtype), (long)B * L, B, p->cfg.heads, L, (int)round_up(L, 8), p->cfg.hidden, p->cfg.inter);
+  b.take((size_t)B * L * p->cfg.hidden * dtype_size(p->cfg.dtype));
+  for (int l = 0; l < 2 * p->cfg.n_l; ++l)
+    plan_ws(b, dtype_size(p->cfg.dtype), (long)B * L, B, p->cfg.heads, L, (int)round_up(L, 8), p->cfg.hidden, p->cfg.inter);
   return (int64_t)b.off + 256;
 }
 
@@ -523,16 +558,19 @@ int etp_txt_bwd(etp_planner* p, const void* dout, const int64_t* ids, const uint
   TxtStash t = plan_txt(p, b, B, L);
   Bump wb(ws);
   const int H = c.H, M = B * L;
-  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
-  ETP_CHECK_HIP(hipMemcpyAsync(w.g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  void* g = wb.take((size_t)M * H * c.es);
+  ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
   for (int l = p->cfg.n_l - 1; l >= 0; --l) {
     const void* x = l == 0 ? t.x0 : t.ffn[l - 1].y;
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, w.g, w.t1, w.dI));
-    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, w.g, w.t1,
-                         w.t2, w.dqkv, w.dP));
+    BwdWs wf = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf.t1, wf.dI));
+    BwdWs wa = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa.t1,
+                         wa.t2, wa.dqkv, wa.dP));
   }
-  return text_embed_bwd(c.dt, w.g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
-                        p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st);
+  ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
+                         p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st));
+  return join_wgrads(c);
 }
 
 // ======================================================================================
@@ -614,8 +652,13 @@ int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V) {
 int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V) {
   if (!p) return 0;
   Bump b(nullptr);
-  plan_ws(b, dtype_size(p->cfg.dtype), (long)B * V, B, p->cfg.heads, V, (int)round_up(V, 8), p->cfg.hidden, p->cfg.inter);
-  b.take((size_t)B * V * p->cfg.hidden * dtype_size(p->cfg.dtype));   // second [M,H] gradient (depth branch)
+  const size_t mh = (size_t)B * V * p->cfg.hidden * dtype_size(p->cfg.dtype);
+  b.take(mh);
+  for (int l = 0; l < p->cfg.n_p + 1; ++l) {
+    plan_ws(b, dtype_size(p->cfg.dtype), (long)B * V, B, p->cfg.heads, V, (int)round_up(V, 8), p->cfg.hidden, p->cfg.inter);
+    b.take(mh);
+  }
+  b.take(mh);   // second [M,H] gradient (depth branch)
   return (int64_t)b.off + 256;
 }
 
@@ -669,24 +712,25 @@ int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float
   const etp_config& cf = p->cfg;
   const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
   Bump wb(ws);
-  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
-  void* g2 = wb.take((size_t)M * H * c.es);
+  void* g = wb.take((size_t)M * H * c.es);
   if (cf.n_p > 0) {
     const void* xin = s.layers[cf.n_p - 1].x2;
-    ETP_TRY(ln_bwd(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, w.g, p->gf(p->pn_g), p->gf(p->pn_b), M, H, c.st));
+    ETP_TRY(ln_bwd(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g, p->gf(p->pn_g), p->gf(p->pn_b), M, H, c.st));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(w.g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+    ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
   }
   for (int l = cf.n_p - 1; l >= 0; --l) {
     const PanoLayerP& q = p->pano[l];
     const PanoLayerStash& t = s.layers[l];
     const void* x = l == 0 ? s.x0 : s.layers[l - 1].x2;
+    BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
+    void* gout = wb.take((size_t)M * H * c.es);   // g itself feeds a weight-gradient GEMM: the layer writes dx elsewhere
     // FFN: x2 = x1 + W2 gelu(W1 LN2(x1))
-    ETP_TRY(linear_wgrad(c, w.g, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
-    ETP_TRY(linear_dgrad(c, w.g, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
+    ETP_TRY(linear_wgrad(c, g, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
+    ETP_TRY(linear_dgrad(c, g, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
     ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
     ETP_TRY(linear_dgrad(c, w.dI, I, q.l1_w, w.t1, H, M, I, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t1 = df
-    ETP_TRY(ln_bwd(c.dt, w.t1, t.x1, t.st2, p->pf(q.n2_g), w.g, w.t2, p->gf(q.n2_g), p->gf(q.n2_b), M, H, c.st)); // t2 = dx1
+    ETP_TRY(ln_bwd(c.dt, w.t1, t.x1, t.st2, p->pf(q.n2_g), g, w.t2, p->gf(q.n2_g), p->gf(q.n2_b), M, H, c.st));   // t2 = dx1
     // attention: x1 = x + Wo attn(LN1(x))
     ETP_TRY(linear_wgrad(c, w.t2, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
     ETP_TRY(linear_dgrad(c, w.t2, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
@@ -696,16 +740,20 @@ int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float
                           offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
     ETP_TRY(linear_dgrad(c, w.dqkv, 3 * H, q.in_w, w.t1, H, M, 3 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));  // t1 = da
-    ETP_TRY(ln_bwd(c.dt, w.t1, x, t.st1, p->pf(q.n1_g), w.t2, w.g, p->gf(q.n1_g), p->gf(q.n1_b), M, H, c.st));    // g = dx
+    ETP_TRY(ln_bwd(c.dt, w.t1, x, t.st1, p->pf(q.n1_g), w.t2, gout, p->gf(q.n1_g), p->gf(q.n1_b), M, H, c.st));   // dx
+    g = gout;
   }
   // embedding fuse backward -> da (t1), dd (g2)
-  ETP_TRY(pano_embed_bwd(c.dt, w.g, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, g2, M, H, c.st));
+  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
+  wb.take((size_t)M * H * c.es);
+  void* g2 = wb.take((size_t)M * H * c.es);
+  ETP_TRY(pano_embed_bwd(c.dt, g, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, g2, M, H, c.st));
   const void* rgbT = c.dt == ETP_BF16 ? s.rgbT : (const void*)rgb;
   const void* depT = c.dt == ETP_BF16 ? s.depT : (const void*)dep;
   ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
   if (cf.use_depth) ETP_TRY(linear_wgrad(c, g2, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
   if (d_rgb) ETP_TRY(linear_dgrad(c, w.t1, H, p->img_w, d_rgb, cf.img_feat, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
-  return ETP_OK;
+  return join_wgrads(c);
 }
 
 // ======================================================================================
@@ -743,16 +791,26 @@ NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
   s.str = (float*)b.take(Mg * 2 * sizeof(float));
   return s;
 }
-struct NavWs { BwdWs w; void *dq, *dkv, *dPx; };
+struct NavCrossWs { BwdWs w; void *dq, *dkv, *dPx; };
+struct NavWs { void* g; BwdWs head; std::vector<BwdWs> ffn, self; std::vector<NavCrossWs> cross; };
 NavWs plan_nav_ws(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
   const etp_config& c = pl->cfg;
   const size_t es = dtype_size(c.dtype);
   const long Mg = (long)Bn * G, Mt = (long)Bn * L;
+  const int ldG = (int)round_up(G, 8);
   NavWs n;
-  n.w = plan_ws(b, es, Mg, Bn, c.heads, G, (int)round_up(G, 8), c.hidden, c.inter);
-  n.dq = b.take(Mg * c.hidden * es);
-  n.dkv = b.take(Mt * 2 * c.hidden * es);
-  n.dPx = b.take((size_t)Bn * c.heads * G * round_up(L, 8) * es);
+  n.g = b.take(Mg * c.hidden * es);
+  n.head = plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
+  for (int l = 0; l < c.n_x; ++l) {   // fresh scratch per sub-block (see plan_ws)
+    n.ffn.push_back(plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
+    n.self.push_back(plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
+    NavCrossWs x;
+    x.w = plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
+    x.dq = b.take(Mg * c.hidden * es);
+    x.dkv = b.take(Mt * 2 * c.hidden * es);
+    x.dPx = b.take((size_t)Bn * c.heads * G * round_up(L, 8) * es);
+    n.cross.push_back(x);
+  }
   return n;
 }
 }  // namespace
@@ -823,7 +881,7 @@ int etp_nav_bwd(etp_planner* p, const void* d_embeds, const float* d_logits, con
   NavStash s = plan_nav(p, b, B, L, G);
   Bump wb(ws);
   NavWs n = plan_nav_ws(p, wb, B, L, G);
-  BwdWs& w = n.w;
+  void* g = n.g;
   const etp_config& cf = p->cfg;
   const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
@@ -833,39 +891,43 @@ int etp_nav_bwd(etp_planner* p, const void* d_embeds, const float* d_logits, con
   // head (gmap_embeds = output of the last x-layer, owned by the caller)
   if (d_logits) {
     ETP_TRY(sap_tail_bwd(c.dt, d_logits, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), s.str, visited, gmask,
-                         w.t1, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
-    ETP_TRY(linear_wgrad(c, w.t1, H, gmap_embeds, H, p->sap0_w, p->sap0_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, w.t1, H, p->sap0_w, w.g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, d_embeds, H));
+                         n.head.t1, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
+    ETP_TRY(linear_wgrad(c, n.head.t1, H, gmap_embeds, H, p->sap0_w, p->sap0_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, n.head.t1, H, p->sap0_w, g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, d_embeds, H));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(w.g, d_embeds, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+    ETP_CHECK_HIP(hipMemcpyAsync(g, d_embeds, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
   }
   if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * c.es, c.st));
   for (int l = cf.n_x - 1; l >= 0; --l) {
     const XLayerP& q = p->xl[l];
     const XStash& t = s.layers[l];
     const void* x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
-    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, w.g, w.t1, w.dI));
-    ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, w.g,
-                         w.t1, w.t2, w.dqkv, w.dP));
+    const BwdWs& wf = n.ffn[l];
+    const BwdWs& wsf = n.self[l];
+    const NavCrossWs& xc = n.cross[l];
+    const BwdWs& w = xc.w;
+    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, wf.t1, wf.dI));
+    ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, g,
+                         wsf.t1, wsf.t2, wsf.dqkv, wsf.dP));
     // cross attention backward
-    ETP_TRY(ln_bwd(c.dt, w.g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1, p->gf(q.xln_g), p->gf(q.xln_b), Mg, H, c.st));
+    ETP_TRY(ln_bwd(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1, p->gf(q.xln_g), p->gf(q.xln_b), Mg, H, c.st));
     ETP_TRY(linear_wgrad(c, w.t1, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
     ETP_TRY(linear_dgrad(c, w.t1, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, n.dPx, n.dq, H, n.dkv, 2L * H, offs(n.dkv, H, c.es), 2L * H, 0.125f,
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, xc.dkv, 2L * H, offs(xc.dkv, H, c.es), 2L * H, 0.125f,
                           nullptr, nullptr, c.st));
-    ETP_TRY(linear_wgrad(c, n.dq, H, x, H, q.q_w, q.q_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, n.dq, H, q.q_w, w.g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, w.t1, H));
-    ETP_TRY(linear_wgrad(c, n.dkv, 2 * H, txt, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
-    ETP_TRY(linear_dgrad(c, n.dkv, 2 * H, q.kv_w, d_txt, H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0,
+    ETP_TRY(linear_wgrad(c, xc.dq, H, x, H, q.q_w, q.q_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, xc.dq, H, q.q_w, g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, w.t1, H));
+    ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txt, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
+    ETP_TRY(linear_dgrad(c, xc.dkv, 2 * H, q.kv_w, d_txt, H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0,
                          l == cf.n_x - 1 ? 0 : 1));
   }
-  ETP_TRY(gmap_embed_bwd(c.dt, w.g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
+  ETP_TRY(gmap_embed_bwd(c.dt, g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));
-  ETP_CHECK_HIP(hipMemcpyAsync(d_img, w.g, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
-  return ETP_OK;
+  ETP_CHECK_HIP(hipMemcpyAsync(d_img, g, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  return join_wgrads(c);
 }
 
 }  // extern "C"

@@ -50,7 +50,7 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
 
 
 class PlannerStep:
-    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor]):
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True):
         self.model = model
         eng = self.eng = model._engine
         eng.require_gpu()
@@ -83,16 +83,33 @@ class PlannerStep:
         self.st_txt = eng.buf(self.L.etp_txt_stash_bytes(h, B, Lt))
         self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, B, V))
         self.st_nav = eng.buf(self.L.etp_nav_stash_bytes(h, B, Lt, G))
-        ws = max(self.L.etp_txt_ws_bytes(h, B, Lt), self.L.etp_pano_ws_bytes(h, B, V), self.L.etp_nav_ws_bytes(h, B, Lt, G))
-        self.ws = eng.buf(ws)
+        # separate backward workspaces: the three backward passes may run on parallel streams
+        self.ws_txt = eng.buf(self.L.etp_txt_ws_bytes(h, B, Lt))
+        self.ws_pano = eng.buf(self.L.etp_pano_ws_bytes(h, B, V))
+        self.ws_nav = eng.buf(self.L.etp_nav_ws_bytes(h, B, Lt, G))
+        # side streams: `aux` carries the weight-gradient GEMMs, `s2` the panorama branch (independent of the text branch)
+        self.overlap = overlap
+        self.aux = self.s2 = None
+        if overlap in (True, "aux", "both"):
+            a = ctypes.c_void_p()
+            check(self.L.etp_stream_create(ctypes.byref(a)), "stream_create")
+            self.aux = a.value
+        if overlap in (True, "s2", "both"):
+            b2 = ctypes.c_void_p()
+            check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
+            self.s2 = b2.value
+        check(self.L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
+        self._pano_pending = False
         self.graph = None
         self.graphs = []
         self.stream = None
 
     # ------------------------------------------------------------------------------------------
-    def enqueue_main(self, s: int, backward: bool = True):
+    def enqueue_main(self, s: int, backward: bool = True, join_pano: bool = True):
         """Everything except the text-encoder backward: weight refresh, zero grads, the three forwards, loss and the
-        navigation + panorama backward (their gradients are complete when this returns to the stream)."""
+        navigation + panorama backward.  The panorama branch (forward and backward) runs on a second stream beside the
+        text branch; with join_pano=False its backward is left running and joined by enqueue_txt_bwd."""
+        s2 = self.s2 if self.s2 is not None else s
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
         dt = eng.cconf.dtype
@@ -100,9 +117,11 @@ class PlannerStep:
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
         if backward:
             check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s), "memset grads")
+        check(L.etp_stream_after(s, s2), "fork")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), B, V,
-                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s), "pano_fwd")
+                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
+        check(L.etp_stream_after(s2, s), "join")
         pf, xf, wf = self.csr_f
         check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
         check(L.etp_nav_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
@@ -114,22 +133,30 @@ class PlannerStep:
             return
         check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.gemb), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
-                            ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws), s), "nav_bwd")
+                            ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
         pb, xb, wb = self.csr_b
         check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), B * V, H, 0, s),
               "node assembly bwd")
+        check(L.etp_stream_after(s, s2), "fork")
         check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), B, V, None,
-                             ptr(self.st_pano), ptr(self.ws), s), "pano_bwd")
+                             ptr(self.st_pano), ptr(self.ws_pano), s2), "pano_bwd")
+        if join_pano:
+            check(L.etp_stream_after(s2, s), "join")
+        else:
+            self._pano_pending = True
 
     def enqueue_txt_bwd(self, s: int):
         L, eng, i = self.L, self.eng, self.inp
         check(L.etp_txt_bwd(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
-                            ptr(self.st_txt), ptr(self.ws), s), "txt_bwd")
+                            ptr(self.st_txt), ptr(self.ws_txt), s), "txt_bwd")
+        if self._pano_pending:
+            check(L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
+            self._pano_pending = False
 
     def run_eager(self, stream: Optional[int] = None, backward: bool = True):
         """Enqueue one step on `stream` (default: torch's current stream)."""
         s = stream if stream is not None else self.eng.stream()
-        self.enqueue_main(s, backward)
+        self.enqueue_main(s, backward, join_pano=not backward)   # panorama backward overlaps the text backward
         if backward:
             self.enqueue_txt_bwd(s)
 
@@ -148,6 +175,10 @@ class PlannerStep:
         """Warm up eagerly (sets kernel attributes), then capture the step into hipGraph(s) on a private stream.
         With split_text_bwd the text-encoder backward is a second graph so that a gradient all-reduce of everything
         else can be issued between the two (data-parallel overlap)."""
+        if self.aux is not None and self.s2 is not None:
+            raise _lib.EtpError("hipGraph capture with two side streams crashes hipStreamEndCapture on ROCm 7.2; "
+                                "build the PlannerStep with overlap='s2', 'aux' or False for graph replay "
+                                "(measured on MI355X: eager two-stream issue is the fastest mode anyway)")
         torch.cuda.synchronize()
         self.run_eager(backward=backward)
         torch.cuda.synchronize()
@@ -188,3 +219,8 @@ class PlannerStep:
         self.graphs, self.graph = [], None
         if self.stream is not None:
             self.L.etp_stream_destroy(self.stream); self.stream = None
+        self.L.etp_planner_set_aux_stream(self.eng.handle, None)
+        for st in (self.aux, self.s2):
+            if st is not None:
+                self.L.etp_stream_destroy(st)
+        self.aux = self.s2 = None

@@ -188,6 +188,10 @@ int64_t etp_planner_arena_elems(const etp_planner* p);       /* total fp32 eleme
 int64_t etp_planner_matrix_elems(const etp_planner* p);      /* leading region holding the GEMM weights */
 /* params: fp32 master arena; shadow: bf16 copy of the matrix region (NULL in fp32 mode); grads: fp32 arena. */
 int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads);
+/* Optional second stream for the backward entry points: weight-gradient GEMMs (leaves of the autograd graph) are issued
+ * on `aux` after their dY producer and joined back before the call returns to `stream`, so they overlap the dgrad
+ * chain (works eagerly and under hipGraph capture: the fork/join become graph edges).  NULL = single stream. */
+int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
 /* bf16 mode: refresh the bf16 shadow of the GEMM weights from the fp32 masters (autocast's per-step weight cast). */
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
 
@@ -226,6 +230,8 @@ typedef struct etp_graph etp_graph;
 int etp_stream_create(etp_stream_t* out);
 int etp_stream_destroy(etp_stream_t s);
 int etp_stream_sync(etp_stream_t s);
+/* make `to` wait for the work enqueued so far on `from` (fork / join of parallel branches; capturable) */
+int etp_stream_after(etp_stream_t from, etp_stream_t to);
 int etp_graph_begin(etp_stream_t s);
 int etp_graph_end(etp_stream_t s, etp_graph** out);
 int etp_graph_launch(etp_graph* g, etp_stream_t s);

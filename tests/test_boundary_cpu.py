@@ -93,3 +93,16 @@ def test_argument_validation_without_launching():
     assert L.etp_ln_fwd(0, None, None, None, None, None, 4, 768, 1e-12, None) == -1
     cfg = _lib.Config()
     assert not L.etp_planner_create(ctypes.byref(cfg))
+
+
+def test_policy_api_and_checkpoint_remap_cpu(tmp_path):
+    """get_vlnbert_models / ETP keep the reference surface (vlnbert_init.py:13-66, Policy_ViewSelection_ETP.py:157-170)."""
+    from types import SimpleNamespace
+    from etpnav_amd.vlnbert_init import get_vlnbert_models, remap_checkpoint_keys
+    from etpnav_amd.ops import gen_seq_masks, extend_neg_masks, pad_tensors_wgrad
+    assert remap_checkpoint_keys({"module.bert.embeddings.LayerNorm.weight": 1, "global_sap_head.net.0.bias": 2}) == {
+        "embeddings.LayerNorm.weight": 1, "global_sap_head.net.0.bias": 2}
+    m = gen_seq_masks(torch.tensor([1, 3]))
+    assert m.tolist() == [[True, False, False], [True, True, True]]
+    assert extend_neg_masks(m).shape == (2, 1, 1, 3) and float(extend_neg_masks(m)[0, 0, 0, 1]) == -10000.0
+    assert pad_tensors_wgrad([torch.ones(2, 4), torch.ones(3, 4)]).shape == (2, 3, 4)

@@ -113,10 +113,12 @@ def test_fp32_step_vs_oracle_fresh_inputs_and_graph_replay():
         assert err < 2e-4 + 2e-3 * g.abs().max().item(), f"{k}: {err}"
     eager_loss = got["loss"].item()
     eager_grad = model.flat_grads.clone()
+    step.close()
+    step = PlannerStep(model, batch, overlap="s2")   # graph replay: one side stream (see PlannerStep.capture)
     step.capture()
     step.replay(); step.replay()
     step.sync()
-    assert abs(step.loss.item() - eager_loss) < 1e-6
+    assert abs(step.loss.item() - eager_loss) < 2e-6
     # atomically-accumulated sums may differ in the last bits between runs
     assert (model.flat_grads - eager_grad).abs().max().item() < 1e-4
     step.close()
