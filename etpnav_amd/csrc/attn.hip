@@ -167,21 +167,27 @@ struct AttnKArgs {
 
 template <typename T, int BQ, int BKV> struct AttnFwdLds {
   static constexpr int PQ = Nat<T, 64>::PITCH, PP = Nat<T, BKV>::PITCH;
-  static constexpr int QK_BYTES = (BQ + BKV) * PQ, P_BYTES = BQ * PP;
-  static constexpr int R0 = QK_BYTES > P_BYTES ? QK_BYTES : P_BYTES;   // q,k tiles; later aliased by the P tile
-  static constexpr int V_OFF = R0, CT_OFF = V_OFF + BKV * PQ;
-  static constexpr int CP = BKV + 4;
-  static constexpr int TOTAL = CT_OFF + BQ * CP * 4;
+  static constexpr int QK_BYTES = (BQ + BKV) * PQ, P_BYTES = BQ * PP, O_BYTES = BQ * 68 * 4;
+  static constexpr int R01 = QK_BYTES > P_BYTES ? QK_BYTES : P_BYTES;
+  static constexpr int R0 = R01 > O_BYTES ? R01 : O_BYTES;   // q,k tiles -> P tile -> fp32 output staging
+  static constexpr int V_OFF = R0, RS_OFF = V_OFF + BKV * PQ;
+  static constexpr int TOTAL = RS_OFF + 4 * BQ * 4;          // + row max / row sum exchange [2][2][BQ]
 };
 
+// scores never leave the registers: the softmax runs on the MFMA accumulators (row statistics by 16-lane shuffles and a
+// tiny LDS exchange between the two wave columns), P is written straight into the LDS tile that feeds P.V.
 template <typename T, int BQ, int BKV>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
   using L = AttnFwdLds<T, BQ, BKV>;
-  constexpr int PQ = L::PQ, PP = L::PP, CP = L::CP;
+  constexpr int PQ = L::PQ, PP = L::PP;
+  constexpr int MT = BQ / 32, NT = BKV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qt = smem; char* kt = smem + BQ * PQ; char* pt = smem; char* vt = smem + L::V_OFF;
-  float* ct = reinterpret_cast<float*>(smem + L::CT_OFF);
+  float* rmax = reinterpret_cast<float*>(smem + L::RS_OFF);   // [2][BQ]
+  float* rsum = rmax + 2 * BQ;                                 // [2][BQ]
+  float* ct = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
   const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
   const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
@@ -192,65 +198,87 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
   nat_load<T, BQ, 64>(qt, Qg, a.ldq, a.Lq, 64, tid);
   nat_load<T, BKV, 64>(kt, Kg, a.ldk, a.Lk, 64, tid);
   nat_load<T, BKV, 64>(vt, Vg, a.ldv, a.Lk, 64, tid);
-  __syncthreads();
-  {  // S = alpha Q K^T
-    f32x4_t acc[BQ / 32][BKV / 32];
-    acc_zero(acc);
-    tile_mma<T, BQ / 32, BKV / 32, 2, false, false, PQ, PQ>(acc, qt, wr * (BQ / 2), kt, wc * (BKV / 2), lane);
-    acc_to_lds(acc, ct, CP, wr * (BQ / 2), wc * (BKV / 2), a.alpha, lane);
-  }
-  __syncthreads();   // scores complete; q/k tiles dead -> the P tile may overwrite them
-  const float w = a.sp_w ? a.sp_w[0] : 0.f, b0 = a.sp_b ? a.sp_b[0] : 0.f;
+  // additive key mask / validity of this lane's NT columns (one per 16-column tile), loaded once
   const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
-  float kadd[BKV / 64];   // additive key mask of this lane's keys, loaded once (not once per row)
+  float kadd[NT];
 #pragma unroll
-  for (int j = 0; j < BKV / 64; ++j) {
-    const int k = lane + j * 64;
-    kadd[j] = (km && k < a.Lk && !km[k]) ? (a.mask_mode ? -INFINITY : -10000.0f) : 0.f;
+  for (int n = 0; n < NT; ++n) {
+    const int col = wc * (BKV / 2) + n * 16 + i;
+    float v = 0.f;
+    if (col >= a.Lk) v = -INFINITY;
+    else if (km && !km[col]) v = a.mask_mode ? -INFINITY : -10000.0f;
+    kadd[n] = v;
   }
-  for (int row = wave; row < BQ; row += 4) {
-    T* prow = reinterpret_cast<T*>(pt + row * PP);
-    if (row >= a.Lq) {   // zero the unused query rows of the P tile
-      for (int k = lane; k < BKV; k += 64) Elem<T>::st(prow + k, 0.f);
-      continue;
-    }
-    const float* d = a.dist ? a.dist + ((long)b * a.Lq + row) * a.Lk : nullptr;
-    float v[BKV / 64];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < BKV / 64; ++j) {
-      const int k = lane + j * 64;
-      float s = -INFINITY;
-      if (k < a.Lk) {
-        s = ct[row * CP + k] + kadd[j];
-        if (d) s += w * d[k] + b0;
-      }
-      v[j] = s;
-      mx = fmaxf(mx, s);
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < BKV / 64; ++j) {
-      v[j] = (lane + j * 64 < a.Lk) ? __expf(v[j] - mx) : 0.f;
-      sum += v[j];
-    }
-    const float inv = 1.0f / wave_sum(sum);
-#pragma unroll
-    for (int j = 0; j < BKV / 64; ++j) {
-      const int k = lane + j * 64;
-      const float p = v[j] * inv;
-      Elem<T>::st(prow + k, p);
-      if (k < a.ldS) Elem<T>::st(Pg + (long)row * a.ldS + k, p);   // saved for backward (pad columns = 0)
-    }
-  }
+  const float w = a.sp_w ? a.sp_w[0] : 0.f, b0 = a.sp_b ? a.sp_b[0] : 0.f;
   __syncthreads();
-  {  // ctx = P V
-    f32x4_t acc[BQ / 32][2];
-    acc_zero(acc);
-    tile_mma<T, BQ / 32, 2, BKV / 32, false, true, PP, PQ>(acc, pt, wr * (BQ / 2), vt, wc * 32, lane);
-    acc_to_lds(acc, ct, 68, wr * (BQ / 2), wc * 32, 1.0f, lane);
+  f32x4_t sc[MT][NT];
+  acc_zero(sc);
+  tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (BQ / 2), kt, wc * (BKV / 2), lane);
+  // scores + masks, row max over this wave's half of the keys
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      const float* d = (a.dist && row < a.Lq) ? a.dist + ((long)b * a.Lq + row) * a.Lk : nullptr;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int col = wc * (BKV / 2) + n * 16 + i;
+        float v = sc[m][n][r] * a.alpha + kadd[n];
+        if (d && col < a.Lk) v += w * d[col] + b0;
+        sc[m][n][r] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if (i == 0) rmax[wc * BQ + row] = mx;
+    }
+  __syncthreads();   // also: every wave is done with the q/k tiles, the P tile may overwrite them
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      const float mx = fmaxf(rmax[row], rmax[BQ + row]);
+      float sum = 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float e = __expf(sc[m][n][r] - mx);
+        sc[m][n][r] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      if (i == 0) rsum[wc * BQ + row] = sum;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      const float inv = (row < a.Lq) ? 1.0f / (rsum[row] + rsum[BQ + row]) : 0.f;   // unused query rows -> P = 0
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int col = wc * (BKV / 2) + n * 16 + i;
+        Elem<T>::st(reinterpret_cast<T*>(pt + row * PP) + col, sc[m][n][r] * inv);
+      }
+    }
+  __syncthreads();
+  {  // save P for backward: [Lq][ldS] rows copied out of the LDS tile as 16-byte vectors (pad columns are 0)
+    using N = Nat<T, BKV>;
+    for (int q = tid; q < BQ * N::CPR; q += 256) {
+      const int r = q / N::CPR, c = (q % N::CPR) * N::EPC;
+      if (r < a.Lq && c < a.ldS)
+        *reinterpret_cast<uint4*>(Pg + (long)r * a.ldS + c) = *reinterpret_cast<const uint4*>(pt + r * PP + (q % N::CPR) * 16);
+    }
   }
+  f32x4_t oc[MT][2];
+  acc_zero(oc);
+  tile_mma<T, MT, 2, BKV / 32, false, true, PP, PQ>(oc, pt, wr * (BQ / 2), vt, wc * 32, lane);
+  __syncthreads();   // P tile dead -> fp32 output staging
+  acc_to_lds(oc, ct, 68, wr * (BQ / 2), wc * 32, 1.0f, lane);
   __syncthreads();
   store_rows64<T, BQ>(ct, Cg, a.ldc, a.Lq, tid);
 }
