@@ -58,6 +58,16 @@ int etp_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, con
   ETP_REQUIRE(dy && x && stats && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)), "null pointer");
   return ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma, dbeta, M, H, (hipStream_t)s);
 }
+int etp_ln_stream_fwd(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* y_lp, float* stats, int M,
+                      int H, float eps, etp_stream_t s) {
+  ETP_REQUIRE(x && gamma && beta && (y || y_lp), "null pointer");
+  return ln_fwd_s(dtype, x, gamma, beta, y, y_lp, stats, M, H, eps, (hipStream_t)s);
+}
+int etp_ln_stream_bwd(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
+                      float* dx, void* dx_lp, float* dgamma, float* dbeta, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(dy && x && stats && gamma && (dx || dx_lp) && ((dgamma == nullptr) == (dbeta == nullptr)), "null pointer");
+  return ln_bwd_s(dtype, dy, x, stats, gamma, add, dx, dx_lp, dgamma, dbeta, M, H, (hipStream_t)s);
+}
 int etp_softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
                     int heads, int Lq, int Lk, int ldS, int mask_mode, etp_stream_t s) {
   ETP_REQUIRE(S, "null pointer");
@@ -86,11 +96,11 @@ int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t s) {
 }
 
 int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                       const float* beta, void* y, float* stats, int B, int L, int H, float eps, etp_stream_t s) {
+                       const float* beta, float* y, void* y_lp, float* stats, int B, int L, int H, float eps, etp_stream_t s) {
   ETP_REQUIRE(ids && word && pos && type0 && gamma && beta && y && stats, "null pointer");
-  return text_embed_fwd(dtype, ids, word, pos, type0, gamma, beta, y, stats, B, L, H, eps, (hipStream_t)s);
+  return text_embed_fwd(dtype, ids, word, pos, type0, gamma, beta, y, y_lp, stats, B, L, H, eps, (hipStream_t)s);
 }
-int etp_text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+int etp_text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma,
                        float* dbeta, int B, int L, int H, etp_stream_t s) {
   ETP_REQUIRE(dy && ids && word && pos && type0 && gamma && stats && dword && dpos && dtype0 && dgamma && dbeta, "null pointer");
@@ -102,11 +112,11 @@ static PanoEmbedParams to_params(const float* const* p) {
   return q;
 }
 int etp_pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const float* const* params,
-                       void* y, float* stats, int M, int H, etp_stream_t s) {
+                       float* y, float* stats, int M, int H, etp_stream_t s) {
   ETP_REQUIRE(a && loc && nav && params && y && stats, "null pointer");
   return pano_embed_fwd(dtype, a, d, loc, nav, to_params(params), y, stats, M, H, (hipStream_t)s);
 }
-int etp_pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+int etp_pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                        const float* stats, const float* const* params, float* const* grads, void* da, void* dd, int M, int H,
                        etp_stream_t s) {
   ETP_REQUIRE(dy && a && loc && nav && stats && params && grads && da && (d == nullptr || dd != nullptr), "null pointer");
@@ -114,13 +124,13 @@ int etp_pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, 
                    grads[11]};
   return pano_embed_bwd(dtype, dy, a, d, loc, nav, stats, to_params(params), g, da, dd, M, H, (hipStream_t)s);
 }
-int etp_gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
-                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
-                       int H, int pos_dim, etp_stream_t s) {
+int etp_gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, float* x, void* x_lp,
+                       float* stats, int M, int H, int pos_dim, etp_stream_t s) {
   ETP_REQUIRE(img && step_ids && pos && step_emb && w_pos && b_pos && gamma && beta && x && stats, "null pointer");
-  return gmap_embed_fwd(dtype, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, stats, M, H, pos_dim, (hipStream_t)s);
+  return gmap_embed_fwd(dtype, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, x_lp, stats, M, H, pos_dim, (hipStream_t)s);
 }
-int etp_gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+int etp_gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
                        const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
                        float* dbeta, int M, int H, int pos_dim, etp_stream_t s) {
   ETP_REQUIRE(dx && step_ids && pos && w_pos && b_pos && gamma && stats && d_step_emb && d_w_pos && d_b_pos && dgamma && dbeta,

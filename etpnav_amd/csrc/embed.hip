@@ -136,7 +136,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                              const float* __restrict__ pos, const float* __restrict__ type0,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             T* __restrict__ y, float* __restrict__ stats, int M, int L, float eps) {
+                                                             float* __restrict__ y, T* __restrict__ yt, float* __restrict__ stats,
+                                                             int M, int L, float eps) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
@@ -152,13 +153,14 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
     row_normalize<NCH>(x, eps, mean, rstd);
     row_affine<NCH>(t, x, gamma, beta, lane);
     row_store<NCH>(t, y + (long)row * H, lane);
+    if (yt != nullptr) row_store<NCH>(t, yt + (long)row * H, lane);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
   }
 }
 
 // backward: scatter-add into word rows (padding_idx 0 gets none: vilmodel_cmt.py:53), pos rows, type row 0
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids,
                                                              const float* __restrict__ word, const float* __restrict__ pos,
                                                              const float* __restrict__ type0, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, float* __restrict__ dword,
@@ -218,7 +220,7 @@ template <int NCH> __device__ __forceinline__ void loc_project(Row<NCH>& t, cons
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict__ a, const T* __restrict__ d,
                                                              const float* __restrict__ loc, const int64_t* __restrict__ nav,
-                                                             PanoEmbedParams p, T* __restrict__ y, float* __restrict__ stats,
+                                                             PanoEmbedParams p, float* __restrict__ y, float* __restrict__ stats,
                                                              int M) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict
 }
 
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a,
+__global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ a,
                                                              const T* __restrict__ d, const float* __restrict__ loc,
                                                              const int64_t* __restrict__ nav, const float* __restrict__ stats,
                                                              PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
@@ -377,11 +379,12 @@ template <int NCH, int PK> __device__ __forceinline__ void pos_project(Row<NCH>&
 }
 
 template <typename T, int NCH, int PK>
-__global__ __launch_bounds__(256) void gmap_embed_fwd_kernel(const T* __restrict__ img, const int64_t* __restrict__ step_ids,
+__global__ __launch_bounds__(256) void gmap_embed_fwd_kernel(const float* __restrict__ img, const int64_t* __restrict__ step_ids,
                                                              const float* __restrict__ pos, const float* __restrict__ step_emb,
                                                              const float* __restrict__ w_pos, const float* __restrict__ b_pos,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             T* __restrict__ x, float* __restrict__ stats, int M) {
+                                                             float* __restrict__ x, T* __restrict__ xt, float* __restrict__ stats,
+                                                             int M) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
@@ -395,12 +398,13 @@ __global__ __launch_bounds__(256) void gmap_embed_fwd_kernel(const T* __restrict
     row_load<NCH>(u, img + (long)row * H, lane);
     row_add<NCH>(o, u);
     row_store<NCH>(o, x + (long)row * H, lane);
+    if (xt != nullptr) row_store<NCH>(o, xt + (long)row * H, lane);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
   }
 }
 
 template <typename T, int NCH, int PK>
-__global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ step_ids,
+__global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ step_ids,
                                                              const float* __restrict__ pos, const float* __restrict__ w_pos,
                                                              const float* __restrict__ b_pos, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, float* __restrict__ d_step_emb,
@@ -643,68 +647,70 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, l
 
 static inline int row_grid(int M, int cap) { return (int)std::min<long>(((long)M + 3) / 4, cap); }
 
+// Activations that cross kernels of the "residual stream" are fp32 (y / dy below); `yt` / `xt` are optional copies in
+// the GEMM operand dtype `dtype` (NULL in fp32 mode, where the fp32 tensor itself is the operand).
 int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                   const float* beta, void* y, float* stats, int B, int L, int H, float eps, hipStream_t st) {
+                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   const int M = B * L, grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, (bf16_t*)y, stats, M, L, eps)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, (float*)y, stats, M, L, eps)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (bf16_t*)yt, stats, M, L, eps)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (float*)yt, stats, M, L, eps)); }
   ETP_CHECK_LAUNCH("text_embed_fwd");
   return ETP_OK;
 }
 
-int text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
                    const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
                    int B, int L, int H, hipStream_t st) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
+  (void)dtype;
   const int M = B * L, grid = row_grid(M, 128);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L)); }
+  ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L));
   ETP_CHECK_LAUNCH("text_embed_bwd");
   return ETP_OK;
 }
 
 int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
-                   void* y, float* stats, int M, int H, hipStream_t st) {
+                   float* y, float* stats, int M, int H, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, (bf16_t*)y, stats, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, (float*)y, stats, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, y, stats, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, y, stats, M)); }
   ETP_CHECK_LAUNCH("pano_embed_fwd");
   return ETP_OK;
 }
 
-int pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
                    hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, (const float*)dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M)); }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }
 
-int gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
-                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
-                   int H, int PK, hipStream_t st) {
+int gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, float* x, void* xt, float* stats,
+                   int M, int H, int PK, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), 0, st, (const bf16_t*)img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, (bf16_t*)x, stats, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), 0, st, (const float*)img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, (float*)x, stats, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (bf16_t*)xt, stats, M)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (float*)xt, stats, M)); }
   ETP_CHECK_LAUNCH("gmap_embed_fwd");
   return ETP_OK;
 }
 
-int gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
                    const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
                    float* dbeta, int M, int H, int PK, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
+  (void)dtype;
   const int grid = row_grid(M, 64);
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, (const float*)dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M)); }
+  ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M));
   ETP_CHECK_LAUNCH("gmap_embed_bwd");
   return ETP_OK;
 }

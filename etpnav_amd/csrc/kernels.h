@@ -15,25 +15,29 @@ int ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void
            hipStream_t st);
 int ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
            float* dgamma, float* dbeta, int M, int H, hipStream_t st);
+int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,
+             float eps, hipStream_t st);
+int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st);
 int softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
                 int nh, int Lq, int Lk, int ldS, int mask_mode, hipStream_t st);
 int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int nh, int Lq,
                 int Lk, int ldS, hipStream_t st);
 
 int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                   const float* beta, void* y, float* stats, int B, int L, int H, float eps, hipStream_t st);
-int text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st);
+int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
                    const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
                    int B, int L, int H, hipStream_t st);
 int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
-                   void* y, float* stats, int M, int H, hipStream_t st);
-int pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                   float* y, float* stats, int M, int H, hipStream_t st);
+int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
                    hipStream_t st);
-int gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
-                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats, int M,
-                   int H, int PK, hipStream_t st);
-int gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
+int gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                   const float* w_pos, const float* b_pos, const float* gamma, const float* beta, float* x, void* xt, float* stats,
+                   int M, int H, int PK, hipStream_t st);
+int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const float* pos, const float* w_pos, const float* b_pos,
                    const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
                    float* dbeta, int M, int H, int PK, hipStream_t st);
 int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,

@@ -150,6 +150,140 @@ static int ln_bwd_t(const void* dy, const void* x, const float* stats, const flo
   return ETP_OK;
 }
 
+// ---- "stream" LayerNorm: the residual stream is always fp32 (as under the reference's autocast, where LayerNorm and
+// the residual adds stay fp32); y/dx are the fp32 results, yt/dxt optional copies in the GEMM operand dtype T.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_s_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y, T* __restrict__ yt,
+                                                       float* __restrict__ stats, int M, float eps) {
+  constexpr int H = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    float v[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      load4(x + (long)row * H + c * 256 + lane * 4, v[c]);
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[c][e] -= mean; q += v[c][e] * v[c][e]; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
+      const float4 bt = *reinterpret_cast<const float4*>(beta + col);
+      float o[4] = {v[c][0] * rstd * gm.x + bt.x, v[c][1] * rstd * gm.y + bt.y, v[c][2] * rstd * gm.z + bt.z,
+                    v[c][3] * rstd * gm.w + bt.w};
+      if (y != nullptr) store4(y + (long)row * H + col, o);
+      if (yt != nullptr) store4(yt + (long)row * H + col, o);
+    }
+    if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ add, float* __restrict__ dx, T* __restrict__ dxt,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+  constexpr int H = NCH * 256;
+  __shared__ float red[4][2][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NCH][4], ab[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[NCH][4], gy[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      float xv[4], dv[4];
+      load4(x + (long)row * H + col, xv);
+      load4(dy + (long)row * H + col, dv);
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
+      const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[c][e] = (xv[e] - mean) * rstd;
+        gy[c][e] = dv[e] * gmv[e];
+        s1 += gy[c][e];
+        s2 += gy[c][e] * xh[c][e];
+        ag[c][e] += dv[e] * xh[c][e];
+        ab[c][e] += dv[e];
+      }
+    }
+    s1 = wave_sum(s1) * (1.0f / H);
+    s2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - s1 - xh[c][e] * s2);
+      if (add != nullptr) {
+        float av[4];
+        load4(add + (long)row * H + col, av);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += av[e];
+      }
+      if (dx != nullptr) store4(dx + (long)row * H + col, o);
+      if (dxt != nullptr) store4(dxt + (long)row * H + col, o);
+    }
+  }
+  if (dgamma == nullptr) return;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][0][c * 256 + lane * 4 + e] = ag[c][e];
+      red[wave][1][c * 256 + lane * 4 + e] = ab[c][e];
+    }
+  __syncthreads();
+  for (int col = threadIdx.x; col < H; col += 256) {
+    atomicAdd(dgamma + col, red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col]);
+    atomicAdd(dbeta + col, red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col]);
+  }
+}
+
+#define ETP_LN_DISPATCH(KERN, T, GRID, ...)                                                                         \
+  switch (H / 256) {                                                                                                 \
+    case 1: hipLaunchKernelGGL((KERN<T, 1>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 2: hipLaunchKernelGGL((KERN<T, 2>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 3: hipLaunchKernelGGL((KERN<T, 3>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 4: hipLaunchKernelGGL((KERN<T, 4>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    default: return fail(ETP_ERR_INVALID, "layer norm: hidden size must be 256, 512, 768 or 1024");                 \
+  }
+
+// yt / dxt: copy in the operand dtype `dtype` (ignored when NULL; pass NULL in fp32 mode where y itself is the operand)
+int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,
+             float eps, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0 && (y || yt), "bad arguments");
+  const int grid = (int)std::min<long>((M + 3) / 4, 4096);
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_fwd_s_kernel, bf16_t, grid, x, gamma, beta, y, (bf16_t*)yt, stats, M, eps) }
+  else { ETP_LN_DISPATCH(ln_fwd_s_kernel, float, grid, x, gamma, beta, y, (float*)yt, stats, M, eps) }
+  ETP_CHECK_LAUNCH("ln_fwd_s");
+  return ETP_OK;
+}
+int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st) {
+  ETP_REQUIRE(M > 0 && H % 256 == 0 && (dx || dxt), "bad arguments");
+  const int grid = (int)std::min<long>((M + 7) / 8, 128);
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, M) }
+  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, M) }
+  ETP_CHECK_LAUNCH("ln_bwd_s");
+  return ETP_OK;
+}
+
 int ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int H, float eps,
            hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");

@@ -272,6 +272,24 @@ static int linear_dgrad(const Ctx& c, const void* dY, long ldy, int wi, void* dX
   g.act = act; g.Z = Z; g.ldz = ldz; g.R = R; g.ldr = ldr; g.out_mode = out_mode;
   return launch_gemm(c.dt, c.dt, 0, 1, g, 1, c.st);
 }
+// stream-output variants: C (and the residual R) are fp32 whatever the operand dtype -- the residual stream never
+// drops to bf16 (mirrors autocast: half-precision GEMMs, fp32 residual adds and LayerNorms)
+static int linear_fwd_s(const Ctx& c, const void* X, long ldx, int wi, int bi, float* Y, int M, int N, int K, const float* R) {
+  GemmArgs g = base_args();
+  g.A = X; g.lda = ldx; g.B = c.pl->pw(wi); g.ldb = K; g.C = Y; g.ldc = N;
+  g.M = M; g.N = N; g.K = K;
+  g.bias = bi >= 0 ? c.pl->pf(bi) : nullptr;
+  g.R = R; g.ldr = N;
+  return launch_gemm(c.dt, ETP_F32, 0, 0, g, 1, c.st);
+}
+static int linear_dgrad_s(const Ctx& c, const void* dY, long ldy, int wi, float* dX, int M, int N, int K, const float* R,
+                          int out_mode = 0) {
+  GemmArgs g = base_args();
+  g.A = dY; g.lda = ldy; g.B = c.pl->pw(wi); g.ldb = K; g.C = dX; g.ldc = K;
+  g.M = M; g.N = K; g.K = N;
+  g.R = R; g.ldr = K; g.out_mode = out_mode;
+  return launch_gemm(c.dt, ETP_F32, 0, 1, g, 1, c.st);
+}
 // dW[N,K] += dY[M,N]^T . X[M,K] ; db[N] += colsum(dY)
 static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, long ldx, int wi, int bi, int M, int N, int K) {
   GemmArgs g = base_args();
@@ -359,96 +377,122 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   return launch_gemm(dt, dt, 1, 1, k, a.B * nh, st);
 }
 
-// ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
-struct SelfAttStash { void *qkv, *P, *ctx, *s; float* st; void* y; };
-struct FfnStash { void *z, *h, *s; float* st; void* y; };
-struct CrossStash { void *q, *kv, *P, *ctx, *s; float* st; void* y; };
+// ---- activations on the residual stream: fp32 tensor + (bf16 mode) a copy in the GEMM operand dtype -----------------
+struct Act { float* f; void* t; };
+static Act take_act(Bump& b, int dt, long n) {
+  Act a;
+  a.f = (float*)b.take((size_t)n * 4);
+  a.t = dt == ETP_BF16 ? b.take((size_t)n * 2) : (void*)a.f;
+  return a;
+}
+static inline void* lp(const Act& a, int dt) { return dt == ETP_BF16 ? a.t : nullptr; }   // second kernel output (or none)
 
-static SelfAttStash plan_self(Bump& b, size_t es, long M, int Bn, int nh, int L, int ldS, int H, bool own_y) {
+// ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
+struct SelfAttStash { void *qkv, *P, *ctx; float* s; float* st; Act y; };
+struct FfnStash { void *z, *h; float* s; float* st; Act y; };
+struct CrossStash { void *q, *kv, *P, *ctx; float* s; float* st; Act y; };
+
+static SelfAttStash plan_self(Bump& b, int dt, long M, int Bn, int nh, int L, int ldS, int H) {
+  const size_t es = dtype_size(dt);
   SelfAttStash s;
   s.qkv = b.take(M * 3 * H * es);
   s.P = b.take((size_t)Bn * nh * L * ldS * es);
   s.ctx = b.take(M * H * es);
-  s.s = b.take(M * H * es);
+  s.s = (float*)b.take(M * H * 4);
   s.st = (float*)b.take(M * 2 * sizeof(float));
-  s.y = own_y ? b.take(M * H * es) : nullptr;
+  s.y = take_act(b, dt, M * H);
   return s;
 }
-static FfnStash plan_ffn(Bump& b, size_t es, long M, int H, int I, bool own_y) {
+static FfnStash plan_ffn(Bump& b, int dt, long M, int H, int I) {
+  const size_t es = dtype_size(dt);
   FfnStash f;
   f.z = b.take(M * I * es);
   f.h = b.take(M * I * es);
-  f.s = b.take(M * H * es);
+  f.s = (float*)b.take(M * H * 4);
   f.st = (float*)b.take(M * 2 * sizeof(float));
-  f.y = own_y ? b.take(M * H * es) : nullptr;
+  f.y = take_act(b, dt, M * H);
   return f;
 }
 
+// Scratch of ONE backward sub-block.  Every sub-block gets a fresh set (HBM is plentiful) so that weight-gradient
+// GEMMs still running on the side stream never see their dY operand overwritten by a later layer.
+struct BwdWs { Act t1; void *t2, *dI, *dqkv, *dP; };
+static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
+  const size_t es = dtype_size(dt);
+  BwdWs w;
+  w.t1 = take_act(b, dt, M * H);
+  w.t2 = b.take(M * H * es);
+  w.dI = b.take(M * I * es);
+  w.dqkv = b.take(M * 3 * H * es);
+  w.dP = b.take((size_t)Bn * nh * Lq * ldS * es);
+  return w;
+}
+
 // y = LN(dense(attn(x)) + x)
-static int self_att_fwd(const Ctx& c, const AttnP& p, const void* x, SelfAttStash& s, int Bn, int L, const uint8_t* keymask,
+static int self_att_fwd(const Ctx& c, const AttnP& p, const Act& x, SelfAttStash& s, int Bn, int L, const uint8_t* keymask,
                         const float* dist, const float* sp_w, const float* sp_b, float eps) {
   const int H = c.H, M = Bn * L;
-  ETP_TRY(linear_fwd(c, x, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+  ETP_TRY(linear_fwd(c, x.t, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st));
-  ETP_TRY(linear_fwd(c, s.ctx, H, p.o_w, p.o_b, s.s, H, M, H, H, ETP_ACT_NONE, nullptr, x, H));
-  return ln_fwd(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y, s.st, M, H, eps, c.st);
+  ETP_TRY(linear_fwd_s(c, s.ctx, H, p.o_w, p.o_b, s.s, M, H, H, x.f));
+  return ln_fwd_s(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y.f, lp(s.y, c.dt), s.st, M, H, eps, c.st);
 }
-// g: in = dL/dy, out = dL/dx (same buffer); t1,t2: [M,H] scratch; dqkv: [M,3H]; dP: like P
-static int self_att_bwd(const Ctx& c, const AttnP& p, const void* x, const SelfAttStash& s, int Bn, int L,
+// g (fp32): in = dL/dy, out = dL/dx (same buffer)
+static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAttStash& s, int Bn, int L,
                         const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, float* d_sp_w,
-                        float* d_sp_b, void* g, void* t1, void* t2, void* dqkv, void* dP) {
+                        float* d_sp_b, float* g, const BwdWs& w) {
   const int H = c.H, M = Bn * L;
   etp_planner* pl = c.pl;
-  ETP_TRY(ln_bwd(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, t1, pl->gf(p.ln_g), pl->gf(p.ln_b), M, H, c.st));  // t1 = ds
-  ETP_TRY(linear_wgrad(c, t1, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
-  ETP_TRY(linear_dgrad(c, t1, H, p.o_w, t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));                   // t2 = dctx
+  ETP_TRY(ln_bwd_s(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp(w.t1, c.dt), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
+                   c.st));                                                                                    // t1 = ds
+  ETP_TRY(linear_wgrad(c, w.t1.t, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
+  ETP_TRY(linear_dgrad(c, w.t1.t, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));        // t2 = dctx
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
-  ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, t2, H, dP, dqkv, 3L * H, offs(dqkv, H, c.es), 3L * H, offs(dqkv, 2 * H, c.es),
-                        3L * H, 0.125f, d_sp_w, d_sp_b, c.st));
-  ETP_TRY(linear_wgrad(c, dqkv, 3 * H, x, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
-  return linear_dgrad(c, dqkv, 3 * H, p.qkv_w, g, H, M, 3 * H, H, ETP_ACT_NONE, nullptr, 0, t1, H);               // g = dx
+  ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, w.t2, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
+                        offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st));
+  ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
+  return linear_dgrad_s(c, w.dqkv, 3 * H, p.qkv_w, g, M, 3 * H, H, w.t1.f);                                  // g = dx
 }
 
-static int ffn_fwd(const Ctx& c, const FfnP& p, const void* x, FfnStash& f, int M, float eps) {
+static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M, float eps) {
   const int H = c.H, I = c.I;
-  ETP_TRY(linear_fwd(c, x, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU, f.z, nullptr, 0));
-  ETP_TRY(linear_fwd(c, f.h, I, p.o_w, p.o_b, f.s, H, M, H, I, ETP_ACT_NONE, nullptr, x, H));
-  return ln_fwd(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y, f.st, M, H, eps, c.st);
+  ETP_TRY(linear_fwd(c, x.t, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU, f.z, nullptr, 0));
+  ETP_TRY(linear_fwd_s(c, f.h, I, p.o_w, p.o_b, f.s, M, H, I, x.f));
+  return ln_fwd_s(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y.f, lp(f.y, c.dt), f.st, M, H, eps, c.st);
 }
-static int ffn_bwd(const Ctx& c, const FfnP& p, const void* x, const FfnStash& f, int M, void* g, void* t1, void* dI) {
+static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f, int M, float* g, const BwdWs& w) {
   const int H = c.H, I = c.I;
   etp_planner* pl = c.pl;
-  ETP_TRY(ln_bwd(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, t1, pl->gf(p.ln_g), pl->gf(p.ln_b), M, H, c.st));   // t1 = ds
-  ETP_TRY(linear_wgrad(c, t1, H, f.h, I, p.o_w, p.o_b, M, H, I));
-  ETP_TRY(linear_dgrad(c, t1, H, p.o_w, dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));                    // dI = dz
-  ETP_TRY(linear_wgrad(c, dI, I, x, H, p.i_w, p.i_b, M, I, H));
-  return linear_dgrad(c, dI, I, p.i_w, g, H, M, I, H, ETP_ACT_NONE, nullptr, 0, t1, H);                            // g = dx
+  ETP_TRY(ln_bwd_s(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp(w.t1, c.dt), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
+                   c.st));                                                                                    // t1 = ds
+  ETP_TRY(linear_wgrad(c, w.t1.t, H, f.h, I, p.o_w, p.o_b, M, H, I));
+  ETP_TRY(linear_dgrad(c, w.t1.t, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));        // dI = dz
+  ETP_TRY(linear_wgrad(c, w.dI, I, x.t, H, p.i_w, p.i_b, M, I, H));
+  return linear_dgrad_s(c, w.dI, I, p.i_w, g, M, I, H, w.t1.f);                                               // g = dx
 }
 
 // ======================================================================================
 // forward_txt
 // ======================================================================================
 struct TxtStash {
-  void* x0; float* st0;
+  Act x0; float* st0;
   std::vector<SelfAttStash> att; std::vector<FfnStash> ffn;
 };
 static TxtStash plan_txt(const etp_planner* pl, Bump& b, int Bn, int L) {
-  const size_t es = dtype_size(pl->cfg.dtype);
-  const int H = pl->cfg.hidden;
+  const int dt = pl->cfg.dtype, H = pl->cfg.hidden;
   const long M = (long)Bn * L;
   TxtStash t;
-  t.x0 = b.take(M * H * es);
+  t.x0 = take_act(b, dt, M * H);
   t.st0 = (float*)b.take(M * 2 * sizeof(float));
   for (int l = 0; l < pl->cfg.n_l; ++l) {
-    t.att.push_back(plan_self(b, es, M, Bn, pl->cfg.heads, L, (int)round_up(L, 8), H, true));
-    t.ffn.push_back(plan_ffn(b, es, M, H, pl->cfg.inter, l + 1 < pl->cfg.n_l));   // last y = caller's output
+    t.att.push_back(plan_self(b, dt, M, Bn, pl->cfg.heads, L, (int)round_up(L, 8), H));
+    t.ffn.push_back(plan_ffn(b, dt, M, H, pl->cfg.inter));
   }
   return t;
 }
-struct BwdWs { void *g, *t1, *t2, *dI, *dqkv, *dP, *dq, *dkv, *dP2; };
 
 }  // namespace etp
 
@@ -508,28 +552,16 @@ int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L) {
   plan_txt(p, b, B, L);
   return (int64_t)b.off + 256;
 }
-// Scratch of ONE backward sub-block.  Every sub-block gets a fresh set (HBM is plentiful) so that weight-gradient
-// GEMMs still running on the side stream never see their dY operand overwritten by a later layer.
-static BwdWs plan_ws(Bump& b, size_t es, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
-  BwdWs w;
-  memset(&w, 0, sizeof(w));
-  w.t1 = b.take(M * H * es);
-  w.t2 = b.take(M * H * es);
-  w.dI = b.take(M * I * es);
-  w.dqkv = b.take(M * 3 * H * es);
-  w.dP = b.take((size_t)Bn * nh * Lq * ldS * es);
-  return w;
-}
 int64_t etp_txt_ws_bytes(const etp_planner* p, int B, int L) {
   if (!p) return 0;
   Bump b(nullptr);
-  b.take((size_t)B * L * p->cfg.hidden * dtype_size(p->cfg.dtype));
+  b.take((size_t)B * L * p->cfg.hidden * 4);
   for (int l = 0; l < 2 * p->cfg.n_l; ++l)
-    plan_ws(b, dtype_size(p->cfg.dtype), (long)B * L, B, p->cfg.heads, L, (int)round_up(L, 8), p->cfg.hidden, p->cfg.inter);
+    plan_ws(b, p->cfg.dtype, (long)B * L, B, p->cfg.heads, L, (int)round_up(L, 8), p->cfg.hidden, p->cfg.inter);
   return (int64_t)b.off + 256;
 }
 
-int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, int L, void* out, void* stash,
+int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, int L, float* out, void* stash,
                 etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && ids && mask && out && stash && B > 0 && L > 0 && L <= p->cfg.max_pos, "bad arguments");
   Ctx c = make_ctx(p, stream);
@@ -537,20 +569,19 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
   TxtStash t = plan_txt(p, b, B, L);
   const int H = c.H, M = B * L;
   const float eps = p->cfg.ln_eps;
-  ETP_TRY(text_embed_fwd(c.dt, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), p->pf(p->emb_b), t.x0,
-                         t.st0, B, L, H, eps, c.st));
-  const void* x = t.x0;
+  ETP_TRY(text_embed_fwd(c.dt, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), p->pf(p->emb_b), t.x0.f,
+                         lp(t.x0, c.dt), t.st0, B, L, H, eps, c.st));
+  Act x = t.x0;
   for (int l = 0; l < p->cfg.n_l; ++l) {
-    if (l + 1 == p->cfg.n_l) t.ffn[l].y = out;
     ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps));
     ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps));
     x = t.ffn[l].y;
   }
-  if (p->cfg.n_l == 0) ETP_CHECK_HIP(hipMemcpyAsync(out, t.x0, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  ETP_CHECK_HIP(hipMemcpyAsync(out, x.f, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
   return ETP_OK;
 }
 
-int etp_txt_bwd(etp_planner* p, const void* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
+int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
                 etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && p->G && dout && ids && mask && stash && ws && B > 0 && L > 0, "bad arguments");
   Ctx c = make_ctx(p, stream);
@@ -558,15 +589,14 @@ int etp_txt_bwd(etp_planner* p, const void* dout, const int64_t* ids, const uint
   TxtStash t = plan_txt(p, b, B, L);
   Bump wb(ws);
   const int H = c.H, M = B * L;
-  void* g = wb.take((size_t)M * H * c.es);
-  ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  float* g = (float*)wb.take((size_t)M * H * 4);
+  ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
   for (int l = p->cfg.n_l - 1; l >= 0; --l) {
-    const void* x = l == 0 ? t.x0 : t.ffn[l - 1].y;
-    BwdWs wf = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf.t1, wf.dI));
-    BwdWs wa = plan_ws(wb, c.es, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
-    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa.t1,
-                         wa.t2, wa.dqkv, wa.dP));
+    const Act x = l == 0 ? t.x0 : t.ffn[l - 1].y;
+    BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf));
+    BwdWs wa = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa));
   }
   ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
                          p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st));
@@ -577,9 +607,9 @@ int etp_txt_bwd(etp_planner* p, const void* dout, const int64_t* ids, const uint
 // forward_panorama
 // ======================================================================================
 namespace {
-struct PanoLayerStash { void* a; float* st1; void *qkv, *P, *ctx, *x1, *f; float* st2; void *z, *h, *x2; };
+struct PanoLayerStash { void* a; float* st1; void *qkv, *P, *ctx; float* x1; void* f; float* st2; void *z, *h; float* x2; };
 struct PanoStash {
-  void *rgbT, *depT, *a, *d; float* est; void* x0; uint8_t* mask;
+  void *rgbT, *depT, *a, *d; float* est; float* x0; uint8_t* mask;
   std::vector<PanoLayerStash> layers;
   float* stn;
 };
@@ -594,7 +624,7 @@ PanoStash plan_pano(const etp_planner* pl, Bump& b, int Bn, int V) {
   s.a = b.take(M * H * es);
   s.d = c.use_depth ? b.take(M * H * es) : nullptr;
   s.est = (float*)b.take(M * 8 * sizeof(float));
-  s.x0 = b.take(M * H * es);
+  s.x0 = (float*)b.take(M * H * 4);
   s.mask = (uint8_t*)b.take(M);
   for (int l = 0; l < c.n_p; ++l) {
     PanoLayerStash q;
@@ -603,12 +633,12 @@ PanoStash plan_pano(const etp_planner* pl, Bump& b, int Bn, int V) {
     q.qkv = b.take(M * 3 * H * es);
     q.P = b.take((size_t)Bn * c.heads * V * ldS * es);
     q.ctx = b.take(M * H * es);
-    q.x1 = b.take(M * H * es);
+    q.x1 = (float*)b.take(M * H * 4);
     q.f = b.take(M * H * es);
     q.st2 = (float*)b.take(M * 2 * sizeof(float));
     q.z = b.take(M * I * es);
     q.h = b.take(M * I * es);
-    q.x2 = b.take(M * H * es);
+    q.x2 = (float*)b.take(M * H * 4);
     s.layers.push_back(q);
   }
   s.stn = (float*)b.take(M * 2 * sizeof(float));
@@ -641,6 +671,20 @@ PanoEmbedGrads pano_grads(const etp_planner* p) {
   q.g_out = p->gf(p->pe_g); q.b_out = p->gf(p->pe_b);
   return q;
 }
+// per-layer backward scratch of the pre-LN panorama layer
+struct PanoWs { Act g; float* t1f; Act t2; void *dI, *t1, *dqkv, *dP; };
+PanoWs plan_pano_ws(Bump& b, int dt, long M, int Bn, int nh, int V, int ldS, int H, int I) {
+  const size_t es = dtype_size(dt);
+  PanoWs w;
+  w.g = take_act(b, dt, M * H);          // dx of this layer (fp32 stream + operand copy: it feeds a weight gradient)
+  w.t1f = (float*)b.take(M * H * 4);
+  w.t2 = take_act(b, dt, M * H);
+  w.dI = b.take(M * I * es);
+  w.t1 = b.take(M * H * es);
+  w.dqkv = b.take(M * 3 * H * es);
+  w.dP = b.take((size_t)Bn * nh * V * ldS * es);
+  return w;
+}
 }  // namespace
 
 int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V) {
@@ -652,18 +696,13 @@ int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V) {
 int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V) {
   if (!p) return 0;
   Bump b(nullptr);
-  const size_t mh = (size_t)B * V * p->cfg.hidden * dtype_size(p->cfg.dtype);
-  b.take(mh);
-  for (int l = 0; l < p->cfg.n_p + 1; ++l) {
-    plan_ws(b, dtype_size(p->cfg.dtype), (long)B * V, B, p->cfg.heads, V, (int)round_up(V, 8), p->cfg.hidden, p->cfg.inter);
-    b.take(mh);
-  }
-  b.take(mh);   // second [M,H] gradient (depth branch)
+  for (int l = 0; l < p->cfg.n_p + 2; ++l)
+    plan_pano_ws(b, p->cfg.dtype, (long)B * V, B, p->cfg.heads, V, (int)round_up(V, 8), p->cfg.hidden, p->cfg.inter);
   return (int64_t)b.off + 256;
 }
 
 int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float* loc, const int64_t* nav,
-                 const int64_t* view_lens, int B, int V, void* out, uint8_t* out_mask, void* stash, etp_stream_t stream) {
+                 const int64_t* view_lens, int B, int V, float* out, uint8_t* out_mask, void* stash, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && rgb && loc && nav && view_lens && out && stash && B > 0 && V > 0, "bad arguments");
   ETP_REQUIRE(!p->cfg.use_depth || dep, "depth features required");
   Ctx c = make_ctx(p, stream);
@@ -682,29 +721,31 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
   ETP_TRY(linear_fwd(c, rgbT, cf.img_feat, p->img_w, p->img_b, s.a, H, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
   if (cf.use_depth)
     ETP_TRY(linear_fwd(c, depT, cf.dep_feat, p->dep_w, p->dep_b, s.d, H, M, H, cf.dep_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
-  void* x0 = cf.n_p == 0 ? out : s.x0;
+  float* x0 = cf.n_p == 0 ? out : s.x0;
   ETP_TRY(pano_embed_fwd(c.dt, s.a, s.d, loc, nav, pano_params(p), x0, s.est, M, H, c.st));
-  const void* x = x0;
+  const float* x = x0;
   for (int l = 0; l < cf.n_p; ++l) {   // TransformerEncoderLayer.forward_pre common/transformer.py:170-182
     const PanoLayerP& q = p->pano[l];
     PanoLayerStash& t = s.layers[l];
-    ETP_TRY(ln_fwd(c.dt, x, p->pf(q.n1_g), p->pf(q.n1_b), t.a, t.st1, M, H, 1e-5f, c.st));
+    ETP_TRY(ln_fwd_s(c.dt, x, p->pf(q.n1_g), p->pf(q.n1_b), c.dt == ETP_BF16 ? nullptr : (float*)t.a,
+                     c.dt == ETP_BF16 ? t.a : nullptr, t.st1, M, H, 1e-5f, c.st));
     ETP_TRY(linear_fwd(c, t.a, H, q.in_w, q.in_b, t.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st));
-    ETP_TRY(linear_fwd(c, t.ctx, H, q.out_w, q.out_b, t.x1, H, M, H, H, ETP_ACT_NONE, nullptr, x, H));
-    ETP_TRY(ln_fwd(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), t.f, t.st2, M, H, 1e-5f, c.st));
+    ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x));
+    ETP_TRY(ln_fwd_s(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), c.dt == ETP_BF16 ? nullptr : (float*)t.f,
+                     c.dt == ETP_BF16 ? t.f : nullptr, t.st2, M, H, 1e-5f, c.st));
     ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU, t.z, nullptr, 0));
-    ETP_TRY(linear_fwd(c, t.h, I, q.l2_w, q.l2_b, t.x2, H, M, H, I, ETP_ACT_NONE, nullptr, t.x1, H));
+    ETP_TRY(linear_fwd_s(c, t.h, I, q.l2_w, q.l2_b, t.x2, M, H, I, t.x1));
     x = t.x2;
   }
-  if (cf.n_p > 0) ETP_TRY(ln_fwd(c.dt, x, p->pf(p->pn_g), p->pf(p->pn_b), out, s.stn, M, H, 1e-12f, c.st));
+  if (cf.n_p > 0) ETP_TRY(ln_fwd_s(c.dt, x, p->pf(p->pn_g), p->pf(p->pn_b), out, nullptr, s.stn, M, H, 1e-12f, c.st));
   return ETP_OK;
 }
 
-int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float* dep, const float* loc, const int64_t* nav,
-                 int B, int V, void* d_rgb, void* stash, void* ws, etp_stream_t stream) {
+int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const float* dep, const float* loc, const int64_t* nav,
+                 int B, int V, float* d_rgb, void* stash, void* ws, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && p->G && dout && rgb && loc && nav && stash && ws && B > 0 && V > 0, "bad arguments");
   Ctx c = make_ctx(p, stream);
   Bump b(stash);
@@ -712,47 +753,48 @@ int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float
   const etp_config& cf = p->cfg;
   const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
   Bump wb(ws);
-  void* g = wb.take((size_t)M * H * c.es);
+  PanoWs w0 = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
+  Act g = w0.g;
   if (cf.n_p > 0) {
-    const void* xin = s.layers[cf.n_p - 1].x2;
-    ETP_TRY(ln_bwd(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g, p->gf(p->pn_g), p->gf(p->pn_b), M, H, c.st));
+    const float* xin = s.layers[cf.n_p - 1].x2;
+    ETP_TRY(ln_bwd_s(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g.f, lp(g, c.dt), p->gf(p->pn_g), p->gf(p->pn_b), M, H,
+                     c.st));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * c.es, hipMemcpyDeviceToDevice, c.st));
+    ETP_CHECK_HIP(hipMemcpyAsync(g.f, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
   }
   for (int l = cf.n_p - 1; l >= 0; --l) {
     const PanoLayerP& q = p->pano[l];
     const PanoLayerStash& t = s.layers[l];
-    const void* x = l == 0 ? s.x0 : s.layers[l - 1].x2;
-    BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
-    void* gout = wb.take((size_t)M * H * c.es);   // g itself feeds a weight-gradient GEMM: the layer writes dx elsewhere
+    const float* x = l == 0 ? s.x0 : s.layers[l - 1].x2;
+    PanoWs w = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
     // FFN: x2 = x1 + W2 gelu(W1 LN2(x1))
-    ETP_TRY(linear_wgrad(c, g, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
-    ETP_TRY(linear_dgrad(c, g, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
+    ETP_TRY(linear_wgrad(c, g.t, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
+    ETP_TRY(linear_dgrad(c, g.t, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
     ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
-    ETP_TRY(linear_dgrad(c, w.dI, I, q.l1_w, w.t1, H, M, I, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t1 = df
-    ETP_TRY(ln_bwd(c.dt, w.t1, t.x1, t.st2, p->pf(q.n2_g), g, w.t2, p->gf(q.n2_g), p->gf(q.n2_b), M, H, c.st));   // t2 = dx1
+    ETP_TRY(linear_dgrad_s(c, w.dI, I, q.l1_w, w.t1f, M, I, H, nullptr));                                         // t1f = df
+    ETP_TRY(ln_bwd_s(c.dt, w.t1f, t.x1, t.st2, p->pf(q.n2_g), g.f, w.t2.f, lp(w.t2, c.dt), p->gf(q.n2_g), p->gf(q.n2_b), M, H,
+                     c.st));                                                                                        // t2 = dx1
     // attention: x1 = x + Wo attn(LN1(x))
-    ETP_TRY(linear_wgrad(c, w.t2, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
-    ETP_TRY(linear_dgrad(c, w.t2, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
+    ETP_TRY(linear_wgrad(c, w.t2.t, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
+    ETP_TRY(linear_dgrad(c, w.t2.t, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));         // t1 = dctx
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
                           offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
-    ETP_TRY(linear_dgrad(c, w.dqkv, 3 * H, q.in_w, w.t1, H, M, 3 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));  // t1 = da
-    ETP_TRY(ln_bwd(c.dt, w.t1, x, t.st1, p->pf(q.n1_g), w.t2, gout, p->gf(q.n1_g), p->gf(q.n1_b), M, H, c.st));   // dx
-    g = gout;
+    ETP_TRY(linear_dgrad_s(c, w.dqkv, 3 * H, q.in_w, w.t1f, M, 3 * H, H, nullptr));                               // t1f = da
+    ETP_TRY(ln_bwd_s(c.dt, w.t1f, x, t.st1, p->pf(q.n1_g), w.t2.f, w.g.f, lp(w.g, c.dt), p->gf(q.n1_g), p->gf(q.n1_b), M, H,
+                     c.st));                                                                                        // dx
+    g = w.g;
   }
-  // embedding fuse backward -> da (t1), dd (g2)
-  BwdWs w = plan_ws(wb, c.es, M, B, c.nh, V, ldS, H, I);
-  wb.take((size_t)M * H * c.es);
-  void* g2 = wb.take((size_t)M * H * c.es);
-  ETP_TRY(pano_embed_bwd(c.dt, g, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, g2, M, H, c.st));
+  // embedding fuse backward -> da (t1), dd (dI reused as [M,H])
+  PanoWs w = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
+  ETP_TRY(pano_embed_bwd(c.dt, g.f, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, w.dI, M, H, c.st));
   const void* rgbT = c.dt == ETP_BF16 ? s.rgbT : (const void*)rgb;
   const void* depT = c.dt == ETP_BF16 ? s.depT : (const void*)dep;
   ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
-  if (cf.use_depth) ETP_TRY(linear_wgrad(c, g2, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
-  if (d_rgb) ETP_TRY(linear_dgrad(c, w.t1, H, p->img_w, d_rgb, cf.img_feat, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+  if (cf.use_depth) ETP_TRY(linear_wgrad(c, w.dI, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
+  if (d_rgb) ETP_TRY(linear_dgrad_s(c, w.t1, H, p->img_w, d_rgb, M, H, cf.img_feat, nullptr));
   return join_wgrads(c);
 }
 
@@ -762,17 +804,20 @@ int etp_pano_bwd(etp_planner* p, const void* dout, const float* rgb, const float
 namespace {
 struct XStash { CrossStash cross; SelfAttStash self; FfnStash ffn; };
 struct NavStash {
-  void* x0; float* st0;
+  void* txtT;                  // text embeddings in the operand dtype (K/V projections)
+  Act x0; float* st0;
   std::vector<XStash> layers;
   void* r; float* str;
 };
 NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
   const etp_config& c = pl->cfg;
-  const size_t es = dtype_size(c.dtype);
+  const int dt = c.dtype;
+  const size_t es = dtype_size(dt);
   const long Mg = (long)Bn * G, Mt = (long)Bn * L;
   const int H = c.hidden, ldL = (int)round_up(L, 8), ldG = (int)round_up(G, 8);
   NavStash s;
-  s.x0 = b.take(Mg * H * es);
+  s.txtT = dt == ETP_BF16 ? b.take(Mt * H * es) : nullptr;
+  s.x0 = take_act(b, dt, Mg * H);
   s.st0 = (float*)b.take(Mg * 2 * sizeof(float));
   for (int l = 0; l < c.n_x; ++l) {
     XStash x;
@@ -780,11 +825,11 @@ NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
     x.cross.kv = b.take(Mt * 2 * H * es);
     x.cross.P = b.take((size_t)Bn * c.heads * G * ldL * es);
     x.cross.ctx = b.take(Mg * H * es);
-    x.cross.s = b.take(Mg * H * es);
+    x.cross.s = (float*)b.take(Mg * H * 4);
     x.cross.st = (float*)b.take(Mg * 2 * sizeof(float));
-    x.cross.y = b.take(Mg * H * es);
-    x.self = plan_self(b, es, Mg, Bn, c.heads, G, ldG, H, true);
-    x.ffn = plan_ffn(b, es, Mg, H, c.inter, l + 1 < c.n_x);
+    x.cross.y = take_act(b, dt, Mg * H);
+    x.self = plan_self(b, dt, Mg, Bn, c.heads, G, ldG, H);
+    x.ffn = plan_ffn(b, dt, Mg, H, c.inter);
     s.layers.push_back(x);
   }
   s.r = b.take(Mg * H * es);
@@ -792,20 +837,21 @@ NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
   return s;
 }
 struct NavCrossWs { BwdWs w; void *dq, *dkv, *dPx; };
-struct NavWs { void* g; BwdWs head; std::vector<BwdWs> ffn, self; std::vector<NavCrossWs> cross; };
+struct NavWs { float* g; BwdWs head; std::vector<BwdWs> ffn, self; std::vector<NavCrossWs> cross; };
 NavWs plan_nav_ws(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
   const etp_config& c = pl->cfg;
-  const size_t es = dtype_size(c.dtype);
+  const int dt = c.dtype;
+  const size_t es = dtype_size(dt);
   const long Mg = (long)Bn * G, Mt = (long)Bn * L;
   const int ldG = (int)round_up(G, 8);
   NavWs n;
-  n.g = b.take(Mg * c.hidden * es);
-  n.head = plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
+  n.g = (float*)b.take(Mg * c.hidden * 4);
+  n.head = plan_ws(b, dt, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
   for (int l = 0; l < c.n_x; ++l) {   // fresh scratch per sub-block (see plan_ws)
-    n.ffn.push_back(plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
-    n.self.push_back(plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
+    n.ffn.push_back(plan_ws(b, dt, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
+    n.self.push_back(plan_ws(b, dt, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter));
     NavCrossWs x;
-    x.w = plan_ws(b, es, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
+    x.w = plan_ws(b, dt, Mg, Bn, c.heads, G, ldG, c.hidden, c.inter);
     x.dq = b.take(Mg * c.hidden * es);
     x.dkv = b.take(Mt * 2 * c.hidden * es);
     x.dPx = b.take((size_t)Bn * c.heads * G * round_up(L, 8) * es);
@@ -828,9 +874,9 @@ int64_t etp_nav_ws_bytes(const etp_planner* p, int B, int L, int G) {
   return (int64_t)b.off + 256;
 }
 
-int etp_nav_fwd(etp_planner* p, const void* txt, const uint8_t* txt_mask, const int64_t* step_ids, const void* img,
+int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
                 const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
-                void* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
+                float* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && txt && txt_mask && step_ids && img && pos && gmask && visited && out_embeds && out_logits && stash &&
                   B > 0 && L > 0 && G > 0,
               "bad arguments");
@@ -841,92 +887,93 @@ int etp_nav_fwd(etp_planner* p, const void* txt, const uint8_t* txt_mask, const 
   const etp_config& cf = p->cfg;
   const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
   const float eps = cf.ln_eps;
-  void* x0 = cf.n_x == 0 ? out_embeds : s.x0;
+  const void* txtT = txt;
+  if (c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, s.txtT, (long)Mt * H, c.st)); txtT = s.txtT; }
   ETP_TRY(gmap_embed_fwd(c.dt, img, step_ids, pos, p->pf(p->step_emb), p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g),
-                         p->pf(p->gpos_bb), x0, s.st0, Mg, H, cf.ang_feat + 3, c.st));
+                         p->pf(p->gpos_bb), s.x0.f, lp(s.x0, c.dt), s.st0, Mg, H, cf.ang_feat + 3, c.st));
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
   const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
-  const void* x = x0;
+  Act x = s.x0;
   for (int l = 0; l < cf.n_x; ++l) {   // GraphLXRTXLayer.forward vilmodel_cmt.py:383-398
     const XLayerP& q = p->xl[l];
     XStash& t = s.layers[l];
-    if (l + 1 == cf.n_x) t.ffn.y = out_embeds;
     // cross attention nodes -> text (BertXAttention :360-363)
-    ETP_TRY(linear_fwd(c, x, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
-    ETP_TRY(linear_fwd(c, txt, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st));
-    ETP_TRY(linear_fwd(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, H, Mg, H, H, ETP_ACT_NONE, nullptr, x, H));
-    ETP_TRY(ln_fwd(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y, t.cross.st, Mg, H, eps, c.st));
+    ETP_TRY(linear_fwd_s(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, Mg, H, H, x.f));
+    ETP_TRY(ln_fwd_s(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y.f, lp(t.cross.y, c.dt), t.cross.st, Mg, H, eps,
+                     c.st));
     // graph self attention with the pairwise-distance bias (:391-393)
     ETP_TRY(self_att_fwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, eps));
     ETP_TRY(ffn_fwd(c, q.ffn, t.self.y, t.ffn, Mg, eps));
     x = t.ffn.y;
   }
+  ETP_CHECK_HIP(hipMemcpyAsync(out_embeds, x.f, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   // SAP head: Linear -> ReLU (GEMM epilogue) -> LN -> Linear(H->1) -> masks
-  ETP_TRY(linear_fwd(c, x, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
+  ETP_TRY(linear_fwd(c, x.t, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
   return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
                       out_logits, s.str, Mg, H, c.st);
 }
 
-int etp_nav_bwd(etp_planner* p, const void* d_embeds, const float* d_logits, const void* gmap_embeds, const void* txt,
-                const uint8_t* txt_mask, const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited,
-                const float* dists, int B, int L, int G, void* d_txt, void* d_img, void* stash, void* ws, etp_stream_t stream) {
-  ETP_REQUIRE(p && p->P && p->G && gmap_embeds && txt && txt_mask && step_ids && pos && gmask && visited && d_txt && d_img &&
-                  stash && ws && B > 0 && L > 0 && G > 0 && (d_embeds || d_logits),
+int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, const float* txt, const uint8_t* txt_mask,
+                const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B,
+                int L, int G, float* d_txt, float* d_img, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && txt && txt_mask && step_ids && pos && gmask && visited && d_txt && d_img && stash && ws &&
+                  B > 0 && L > 0 && G > 0 && (d_embeds || d_logits),
               "bad arguments");
   Ctx c = make_ctx(p, stream);
   Bump b(stash);
   NavStash s = plan_nav(p, b, B, L, G);
   Bump wb(ws);
   NavWs n = plan_nav_ws(p, wb, B, L, G);
-  void* g = n.g;
   const etp_config& cf = p->cfg;
   const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
   const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
   float* dspw = cf.use_sprels ? p->gf(p->sp_w) : nullptr;
   float* dspb = cf.use_sprels ? p->gf(p->sp_b) : nullptr;
-  // head (gmap_embeds = output of the last x-layer, owned by the caller)
+  const void* txtT = c.dt == ETP_BF16 ? s.txtT : (const void*)txt;
+  const Act xlast = cf.n_x == 0 ? s.x0 : s.layers[cf.n_x - 1].ffn.y;
+  float* g = n.g;
   if (d_logits) {
     ETP_TRY(sap_tail_bwd(c.dt, d_logits, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), s.str, visited, gmask,
-                         n.head.t1, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
-    ETP_TRY(linear_wgrad(c, n.head.t1, H, gmap_embeds, H, p->sap0_w, p->sap0_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, n.head.t1, H, p->sap0_w, g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, d_embeds, H));
+                         n.head.t2, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
+    ETP_TRY(linear_wgrad(c, n.head.t2, H, xlast.t, H, p->sap0_w, p->sap0_b, Mg, H, H));
+    ETP_TRY(linear_dgrad_s(c, n.head.t2, H, p->sap0_w, g, Mg, H, H, d_embeds));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(g, d_embeds, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+    ETP_CHECK_HIP(hipMemcpyAsync(g, d_embeds, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   }
-  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * c.es, c.st));
+  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
   for (int l = cf.n_x - 1; l >= 0; --l) {
     const XLayerP& q = p->xl[l];
     const XStash& t = s.layers[l];
-    const void* x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
-    const BwdWs& wf = n.ffn[l];
-    const BwdWs& wsf = n.self[l];
+    const Act x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
     const NavCrossWs& xc = n.cross[l];
     const BwdWs& w = xc.w;
-    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, wf.t1, wf.dI));
+    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, n.ffn[l]));
     ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, g,
-                         wsf.t1, wsf.t2, wsf.dqkv, wsf.dP));
+                         n.self[l]));
     // cross attention backward
-    ETP_TRY(ln_bwd(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1, p->gf(q.xln_g), p->gf(q.xln_b), Mg, H, c.st));
-    ETP_TRY(linear_wgrad(c, w.t1, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, w.t1, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+    ETP_TRY(ln_bwd_s(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1.f, lp(w.t1, c.dt), p->gf(q.xln_g),
+                     p->gf(q.xln_b), Mg, H, c.st));
+    ETP_TRY(linear_wgrad(c, w.t1.t, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, w.t1.t, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, xc.dkv, 2L * H, offs(xc.dkv, H, c.es), 2L * H, 0.125f,
-                          nullptr, nullptr, c.st));
-    ETP_TRY(linear_wgrad(c, xc.dq, H, x, H, q.q_w, q.q_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, xc.dq, H, q.q_w, g, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, w.t1, H));
-    ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txt, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
-    ETP_TRY(linear_dgrad(c, xc.dkv, 2 * H, q.kv_w, d_txt, H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0,
-                         l == cf.n_x - 1 ? 0 : 1));
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, xc.dkv, 2L * H, offs(xc.dkv, H, c.es), 2L * H,
+                          0.125f, nullptr, nullptr, c.st));
+    ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
+    ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, g, Mg, H, H, w.t1.f));
+    ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
+    ETP_TRY(linear_dgrad_s(c, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
   }
   ETP_TRY(gmap_embed_bwd(c.dt, g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));
-  ETP_CHECK_HIP(hipMemcpyAsync(d_img, g, (size_t)Mg * H * c.es, hipMemcpyDeviceToDevice, c.st));
+  ETP_CHECK_HIP(hipMemcpyAsync(d_img, g, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   return join_wgrads(c);
 }
 

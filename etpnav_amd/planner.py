@@ -11,8 +11,9 @@ the shared object (or without a GPU) the compute methods raise.
 
 Numerics modes (same kernels): ``dtype=torch.float32`` = parity mode (fp32 MFMA,
 matches the fp32 reference to ~1e-5); ``dtype=torch.bfloat16`` = performance mode
-(bf16 operands/activations, fp32 accumulation, statistics, logits and gradients —
-the MI355X counterpart of the reference's fp16 autocast, ss_trainer_ETP.py:502).
+(bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream, LayerNorm,
+softmax statistics, logits and gradients — the MI355X counterpart of the reference's
+fp16 autocast, ss_trainer_ETP.py:502).  Tensors crossing the API are fp32 in both modes.
 Dropout layers of the reference are identity here (eval semantics) — see DESIGN.md.
 """
 from __future__ import annotations
@@ -147,7 +148,7 @@ class _TxtFn(torch.autograd.Function):
     def forward(ctx, anchor, eng: Engine, txt_ids, txt_masks):
         B, L = txt_ids.shape
         H = eng.cconf.hidden
-        out = torch.empty(B, L, H, dtype=eng.tdtype, device=eng.device)
+        out = torch.empty(B, L, H, dtype=torch.float32, device=eng.device)
         stash = eng.buf(eng.L.etp_txt_stash_bytes(eng.handle, B, L))
         check(eng.L.etp_txt_fwd(eng.handle, ptr(txt_ids), ptr(txt_masks), B, L, ptr(out), ptr(stash), eng.stream()),
               "etp_txt_fwd")
@@ -159,7 +160,7 @@ class _TxtFn(torch.autograd.Function):
     def backward(ctx, dout):
         eng, (B, L) = ctx.eng, ctx.dims
         txt_ids, txt_masks = ctx.saved_tensors
-        dout = dout.to(eng.tdtype).contiguous()
+        dout = dout.float().contiguous()
         ws = eng.ws(("txt", B, L), eng.L.etp_txt_ws_bytes(eng.handle, B, L))
         check(eng.L.etp_txt_bwd(eng.handle, ptr(dout), ptr(txt_ids), ptr(txt_masks), B, L, ptr(ctx.stash), ptr(ws),
                                 eng.stream()), "etp_txt_bwd")
@@ -171,7 +172,7 @@ class _PanoFn(torch.autograd.Function):
     def forward(ctx, anchor, eng: Engine, rgb, dep, loc, nav_types, view_lens):
         B, V, _ = rgb.shape
         H = eng.cconf.hidden
-        out = torch.empty(B, V, H, dtype=eng.tdtype, device=eng.device)
+        out = torch.empty(B, V, H, dtype=torch.float32, device=eng.device)
         masks = torch.empty(B, V, dtype=torch.bool, device=eng.device)
         stash = eng.buf(eng.L.etp_pano_stash_bytes(eng.handle, B, V))
         check(eng.L.etp_pano_fwd(eng.handle, ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), ptr(view_lens), B, V, ptr(out),
@@ -186,12 +187,12 @@ class _PanoFn(torch.autograd.Function):
     def backward(ctx, dout, _dmask):
         eng, (B, V) = ctx.eng, ctx.dims
         rgb, dep, loc, nav_types = ctx.saved_tensors
-        dout = dout.to(eng.tdtype).contiguous()
-        d_rgb = torch.empty(B, V, eng.cconf.img_feat, dtype=eng.tdtype, device=eng.device) if ctx.need_rgb_grad else None
+        dout = dout.float().contiguous()
+        d_rgb = torch.empty(B, V, eng.cconf.img_feat, dtype=torch.float32, device=eng.device) if ctx.need_rgb_grad else None
         ws = eng.ws(("pano", B, V), eng.L.etp_pano_ws_bytes(eng.handle, B, V))
         check(eng.L.etp_pano_bwd(eng.handle, ptr(dout), ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), B, V, ptr(d_rgb),
                                  ptr(ctx.stash), ptr(ws), eng.stream()), "etp_pano_bwd")
-        return None, None, (d_rgb.float() if d_rgb is not None else None), None, None, None, None
+        return None, None, d_rgb, None, None, None, None
 
 
 class _NavFn(torch.autograd.Function):
@@ -199,27 +200,27 @@ class _NavFn(torch.autograd.Function):
     def forward(ctx, anchor, eng: Engine, txt_embeds, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
         B, L, H = txt_embeds.shape
         G = step_ids.shape[1]
-        out = torch.empty(B, G, H, dtype=eng.tdtype, device=eng.device)
+        out = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         logits = torch.empty(B, G, dtype=torch.float32, device=eng.device)
         stash = eng.buf(eng.L.etp_nav_stash_bytes(eng.handle, B, L, G))
         check(eng.L.etp_nav_fwd(eng.handle, ptr(txt_embeds), ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts),
                                 ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(out), ptr(logits), ptr(stash),
                                 eng.stream()), "etp_nav_fwd")
         ctx.eng, ctx.stash, ctx.dims = eng, stash, (B, L, G)
-        ctx.save_for_backward(txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists, out)
+        ctx.save_for_backward(txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists)
         return out, logits
 
     @staticmethod
     def backward(ctx, d_out, d_logits):
         eng, (B, L, G) = ctx.eng, ctx.dims
-        txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists, out = ctx.saved_tensors
+        txt_embeds, txt_masks, step_ids, pos_fts, gmasks, visited, dists = ctx.saved_tensors
         H = eng.cconf.hidden
-        d_out = d_out.to(eng.tdtype).contiguous() if d_out is not None else None
+        d_out = d_out.float().contiguous() if d_out is not None else None
         d_logits = d_logits.float().contiguous() if d_logits is not None else None
-        d_txt = torch.empty(B, L, H, dtype=eng.tdtype, device=eng.device)
-        d_img = torch.empty(B, G, H, dtype=eng.tdtype, device=eng.device)
+        d_txt = torch.empty(B, L, H, dtype=torch.float32, device=eng.device)
+        d_img = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         ws = eng.ws(("nav", B, L, G), eng.L.etp_nav_ws_bytes(eng.handle, B, L, G))
-        check(eng.L.etp_nav_bwd(eng.handle, ptr(d_out), ptr(d_logits), ptr(out), ptr(txt_embeds), ptr(txt_masks),
+        check(eng.L.etp_nav_bwd(eng.handle, ptr(d_out), ptr(d_logits), ptr(txt_embeds), ptr(txt_masks),
                                 ptr(step_ids), ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_txt),
                                 ptr(d_img), ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd")
         return None, None, d_txt, None, None, d_img, None, None, None, None
@@ -366,7 +367,7 @@ class GlocalTextPathNavCMT(nn.Module):
                            gmap_masks, gmap_visited_masks, gmap_pair_dists):
         """vilmodel_cmt.py:721-750 (gmap_vpids is ignored, as in the reference)."""
         eng = self._prep()
-        t = eng.tdtype
+        t = torch.float32
         dists = gmap_pair_dists.float().contiguous() if gmap_pair_dists is not None else None
         embeds, logits = _NavFn.apply(self._anchor, eng, txt_embeds.to(t).contiguous(),
                                       txt_masks.to(torch.bool).contiguous(), gmap_step_ids.long().contiguous(),

@@ -74,7 +74,7 @@ class PlannerStep:
         (pf, xf, wf), (pb, xb, wb) = build_node_csr(batch["view_lens"].cpu(), V, G)
         self.csr_f = tuple(x.to(dev) for x in (pf, xf, wf))
         self.csr_b = tuple(x.to(dev) for x in (pb, xb, wb))
-        e = lambda *s, dt=t: torch.empty(*s, dtype=dt, device=dev)
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)   # API tensors are fp32 in both modes
         self.txt = e(B, Lt, H); self.pano = e(B, V, H); self.pmask = e(B, V, dt=torch.bool)
         self.gimg = e(B, G, H); self.gemb = e(B, G, H); self.logits = e(B, G, dt=torch.float32)
         self.dlogits = e(B, G, dt=torch.float32); self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -112,7 +112,7 @@ class PlannerStep:
         s2 = self.s2 if self.s2 is not None else s
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
-        dt = eng.cconf.dtype
+        dt = _lib.ETP_F32          # node assembly works on the fp32 API tensors
         check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
         if backward:
@@ -131,7 +131,7 @@ class PlannerStep:
                            1.0 / B, -100, s), "sap_ce")
         if not backward:
             return
-        check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.gemb), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
+        check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
         pb, xb, wb = self.csr_b

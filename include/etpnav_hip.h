@@ -108,29 +108,39 @@ typedef struct etp_attn_bwd_desc {
 } etp_attn_bwd_desc;
 int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t stream);
 
+/* Residual-stream convention: tensors that flow from one LayerNorm / residual add to the next are ALWAYS fp32 (as under
+ * the reference's autocast, where LayerNorm and residual adds stay fp32); `*_lp` arguments are optional copies in the GEMM
+ * operand dtype `dtype` for the next MFMA product (pass NULL in fp32 mode). */
+
+/* LayerNorm on the fp32 stream: y (fp32, may be NULL) and/or y_lp (operand dtype, may be NULL). */
+int etp_ln_stream_fwd(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* y_lp, float* stats, int M,
+                      int H, float eps, etp_stream_t stream);
+int etp_ln_stream_bwd(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
+                      float* dx, void* dx_lp, float* dgamma, float* dbeta, int M, int H, etp_stream_t stream);
+
 /* BertEmbeddings.forward vilmodel_cmt.py:62-77 (eval): y = LN(word[id] + pos[l] + type[0]). */
 int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
-                       const float* gamma, const float* beta, void* y, float* stats, int B, int L, int H, float eps,
+                       const float* gamma, const float* beta, float* y, void* y_lp, float* stats, int B, int L, int H, float eps,
                        etp_stream_t stream);
-int etp_text_embed_bwd(int dtype, const void* dy, const int64_t* ids, const float* word, const float* pos,
+int etp_text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos,
                        const float* type0, const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0,
                        float* dgamma, float* dbeta, int B, int L, int H, etp_stream_t stream);
 
 /* Panorama view-embedding fuse, forward_panorama vilmodel_cmt.py:695-711:
- *   y = LN(LN_i(a) + LN_d(d) + LN_l(loc.Wl^T+bl) + nav_emb[nav] + type_emb[1]); a,d = MFMA projections of rgb/depth.
+ *   y = LN(LN_i(a) + LN_d(d) + LN_l(loc.Wl^T+bl) + nav_emb[nav] + type_emb[1]); a,d (dtype T) = MFMA projections of rgb/depth.
  * params / grads: 12 fp32 pointers in the order g_img,b_img,g_dep,b_dep,w_loc,bias_loc,g_loc,b_loc,nav_emb,type1,g_out,b_out.
- * stats: [M,8]. */
+ * stats: [M,8]; y / dy fp32; da, dd in dtype T. */
 int etp_pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav,
-                       const float* const* params, void* y, float* stats, int M, int H, etp_stream_t stream);
-int etp_pano_embed_bwd(int dtype, const void* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
+                       const float* const* params, float* y, float* stats, int M, int H, etp_stream_t stream);
+int etp_pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                        const float* stats, const float* const* params, float* const* grads, void* da, void* dd, int M, int H,
                        etp_stream_t stream);
 
-/* forward_navigation vilmodel_cmt.py:728-730: x = img + step_emb[step] + LN(pos.Wp^T+bp). */
-int etp_gmap_embed_fwd(int dtype, const void* img, const int64_t* step_ids, const float* pos, const float* step_emb,
-                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, void* x, float* stats,
-                       int M, int H, int pos_dim, etp_stream_t stream);
-int etp_gmap_embed_bwd(int dtype, const void* dx, const int64_t* step_ids, const float* pos, const float* w_pos,
+/* forward_navigation vilmodel_cmt.py:728-730: x = img + step_emb[step] + LN(pos.Wp^T+bp)  (img, x, dx fp32). */
+int etp_gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const float* pos, const float* step_emb,
+                       const float* w_pos, const float* b_pos, const float* gamma, const float* beta, float* x, void* x_lp,
+                       float* stats, int M, int H, int pos_dim, etp_stream_t stream);
+int etp_gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const float* pos, const float* w_pos,
                        const float* b_pos, const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos,
                        float* d_b_pos, float* dgamma, float* dbeta, int M, int H, int pos_dim, etp_stream_t stream);
 
@@ -195,32 +205,35 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
 /* bf16 mode: refresh the bf16 shadow of the GEMM weights from the fp32 masters (autocast's per-step weight cast). */
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
 
+/* Activations that cross these entry points (txt_embeds, pano_embeds, gmap_img_fts, gmap_embeds and their gradients) are
+ * fp32 in BOTH modes, as they are under the reference's autocast (outputs of fp32 LayerNorms); `dtype` only selects the
+ * GEMM / attention operand precision inside. */
 int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L);
 int64_t etp_txt_ws_bytes(const etp_planner* p, int B, int L);
-int etp_txt_fwd(etp_planner* p, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L, void* txt_embeds /*T [B,L,H]*/,
+int etp_txt_fwd(etp_planner* p, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L, float* txt_embeds /*[B,L,H]*/,
                 void* stash, etp_stream_t stream);
-int etp_txt_bwd(etp_planner* p, const void* d_txt_embeds, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L,
+int etp_txt_bwd(etp_planner* p, const float* d_txt_embeds, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L,
                 void* stash, void* ws, etp_stream_t stream);
 
 int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V);
 int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V);
 int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float* loc, const int64_t* nav_types,
-                 const int64_t* view_lens, int B, int V, void* pano_embeds /*T [B,V,H]*/, uint8_t* pano_masks /*[B,V]*/,
+                 const int64_t* view_lens, int B, int V, float* pano_embeds /*[B,V,H]*/, uint8_t* pano_masks /*[B,V]*/,
                  void* stash, etp_stream_t stream);
-int etp_pano_bwd(etp_planner* p, const void* d_pano_embeds, const float* rgb, const float* dep, const float* loc,
-                 const int64_t* nav_types, int B, int V, void* d_rgb /*T [B,V,img_feat] or NULL*/, void* stash, void* ws,
+int etp_pano_bwd(etp_planner* p, const float* d_pano_embeds, const float* rgb, const float* dep, const float* loc,
+                 const int64_t* nav_types, int B, int V, float* d_rgb /*[B,V,img_feat] or NULL*/, void* stash, void* ws,
                  etp_stream_t stream);
 
 int64_t etp_nav_stash_bytes(const etp_planner* p, int B, int L, int G);
 int64_t etp_nav_ws_bytes(const etp_planner* p, int B, int L, int G);
-int etp_nav_fwd(etp_planner* p, const void* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
-                const void* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
+int etp_nav_fwd(etp_planner* p, const float* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                const float* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
                 const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G,
-                void* gmap_embeds /*T [B,G,H]*/, float* global_logits /*[B,G]*/, void* stash, etp_stream_t stream);
-int etp_nav_bwd(etp_planner* p, const void* d_gmap_embeds /*T or NULL*/, const float* d_logits /*or NULL*/,
-                const void* gmap_embeds /*forward output*/, const void* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
+                float* gmap_embeds /*[B,G,H]*/, float* global_logits /*[B,G]*/, void* stash, etp_stream_t stream);
+int etp_nav_bwd(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const float* d_logits /*or NULL*/,
+                const float* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
                 const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G,
-                void* d_txt_embeds /*T [B,L,H], overwritten*/, void* d_gmap_img_fts /*T [B,G,H], overwritten*/, void* stash,
+                float* d_txt_embeds /*[B,L,H], overwritten*/, float* d_gmap_img_fts /*[B,G,H], overwritten*/, void* stash,
                 void* ws, etp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ def compare_outputs(z, outs, atol, rtol=0.0):
     return worst
 
 
-def compare_grads(z, grads, atol, rel=None, rel_sample=None):
+def compare_grads(z, grads, atol, rel=None, rel_sample=None, abs_rel=0.0):
     """grads: name -> tensor.  Checks the 48 strided samples (abs) and the
     fingerprints (relative to the tensor's abs-max) of every parameter."""
     worst = 0.0
@@ -53,8 +53,8 @@ def compare_grads(z, grads, atol, rel=None, rel_sample=None):
         idx = torch.from_numpy(sample_idx(g.numel()))
         err = float((g[idx] - smp).abs().max())
         worst = max(worst, err)
-        assert err <= atol, f"grad {name}: sample err {err:.3e} > {atol}"
         scale = max(fp[1], 1e-12)
+        assert err <= atol + abs_rel * scale, f"grad {name}: sample err {err:.3e} > {atol} + {abs_rel}*{scale:.3e}"
         if rel_sample is not None:   # per-tensor relative bound on the samples
             assert err <= rel_sample * scale + 2e-6, f"grad {name}: sample err {err:.3e} vs abs-max {scale:.3e}"
         if rel is not None:

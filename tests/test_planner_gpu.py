@@ -5,8 +5,9 @@ for outputs AND every parameter gradient.
 
 Tolerances: fp32 parity mode must meet BASELINE.json's "within 1e-3 fp32" — we hold it to 2e-4 abs on
 outputs/gradients (observed ~1e-5) plus a 2e-3 per-tensor relative bound on gradient samples.
-bf16 performance mode is compared with the bound the reference itself shows between its bf16-autocast and
-fp32 runs (8e-3 logits, 2.3e-2 embeds, 5.7e-2 grads): 5e-2 logits/embeds, 8e-2 grads.
+bf16 performance mode (bf16 GEMM/attention operands, fp32 residual stream — autocast's policy) is compared with the
+bound the reference itself shows between its bf16-autocast and fp32 runs (8e-3 logits, 2.3e-2 embeds,
+5.7e-2 abs / ~7 % of abs-max on gradients): 5e-2 logits/embeds, 8e-2 + 10 % of the tensor's abs-max on gradients.
 """
 import pytest
 import torch
@@ -88,7 +89,7 @@ def test_bf16_step_close_to_reference_golden(name):
     step = PlannerStep(model, batch)
     step.run_eager()
     compare_outputs(z, step_outputs(step), atol=5e-2)
-    compare_grads(z, grads_of(model), atol=8e-2)
+    compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
 
 
 def test_fp32_step_vs_oracle_fresh_inputs_and_graph_replay():
