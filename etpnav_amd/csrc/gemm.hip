@@ -709,11 +709,14 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
   bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
   bool dma = dma_ok(BK, g.K, g.ksplit);
-  int stages = 2;
+  int stages = big ? 2 : 3;   // whole-step A/B on MI355X: 3-deep ring on 64x64 tiles 5.76 -> 5.37 ms/step
   const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r"
   if (force && force[0]) {
-    big = force[0] == '1';
+    if (force[0] == '1' || force[0] == '6') big = force[0] == '1';
+    stages = big ? 2 : 3;
+    if (strstr(force, "s2")) stages = 2;
     if (strstr(force, "s3")) stages = 3;
+    if (strstr(force, "s4")) stages = 4;
   }
   if (!dma) {
     if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
@@ -723,6 +726,7 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
     if (stages == 3) return launch_one<T, TC, TA, TB, 128, 128, 3>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 128, 128, 2>(g, nbatch, st);
   }
+  if (stages == 4) return launch_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
   if (stages == 3) return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
   return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);
 }

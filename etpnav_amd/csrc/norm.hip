@@ -7,6 +7,8 @@
 //
 // Both are HBM-bound row kernels: one 64-lane wavefront owns one row, statistics are reduced with
 // wave shuffles in fp32, I/O is 8/16-byte vectors per lane (coalesced 512 B / 1 KiB per wave instruction).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "kernels.h"
@@ -277,7 +279,9 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
              void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (dx || dxt), "bad arguments");
-  const int grid = (int)std::min<long>((M + 7) / 8, 128);
+  const char* eg = getenv("ETP_LNBWD_GRID");
+  const int cap = eg ? atoi(eg) : 128;
+  const int grid = (int)std::min<long>((M + 3) / 4, cap);
   if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, M) }
   else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, M) }
   ETP_CHECK_LAUNCH("ln_bwd_s");

@@ -15,6 +15,14 @@ def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
         A = torch.randn(M, K, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, N, device=dev, dtype=t)
         d.trans_a, d.trans_b, d.c_dtype = 0, 0, dtype; d.lda, d.ldb, d.ldc = K, K, N; d.M, d.N, d.K = M, N, K
         bias = torch.randn(N, device=dev); d.bias = bias.data_ptr()
+    elif kind == "fwd_s":  # fp32 stream out + fp32 residual
+        A = torch.randn(M, K, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, N, device=dev)
+        d.trans_a, d.trans_b, d.c_dtype = 0, 0, _lib.ETP_F32; d.lda, d.ldb, d.ldc = K, K, N; d.M, d.N, d.K = M, N, K
+        bias = torch.randn(N, device=dev); d.bias = bias.data_ptr(); R = torch.randn(M, N, device=dev); d.R = R.data_ptr(); d.ldr = N
+    elif kind == "dgrad_s":
+        A = torch.randn(M, N, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, K, device=dev)
+        d.trans_a, d.trans_b, d.c_dtype = 0, 1, _lib.ETP_F32; d.lda, d.ldb, d.ldc = N, K, K; d.M, d.N, d.K = M, K, N
+        R = torch.randn(M, K, device=dev); d.R = R.data_ptr(); d.ldr = K
     elif kind == "dgrad":  # dX[M,K] = dY[M,N] W[N,K]
         A = torch.randn(M, N, device=dev).to(t); B = torch.randn(N, K, device=dev).to(t); C = torch.empty(M, K, device=dev, dtype=t)
         d.trans_a, d.trans_b, d.c_dtype = 0, 1, dtype; d.lda, d.ldb, d.ldc = N, K, K; d.M, d.N, d.K = M, K, N
@@ -36,7 +44,8 @@ def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
     fl = 2.0 * M * N * K
     return us, fl / us / 1e6
 
-shapes = [("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
+shapes = [("fwd_s", 2560, 768, 768), ("fwd_s", 2560, 768, 3072), ("dgrad_s", 2560, 2304, 768), ("dgrad_s", 2560, 3072, 768),
+          ("dgrad_s", 512, 3072, 768), ("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
           ("fwd", 1152, 2304, 768), ("fwd", 512, 768, 768), ("fwd", 512, 3072, 768),
           ("dgrad", 2560, 2304, 768), ("dgrad", 2560, 768, 768), ("dgrad", 2560, 3072, 768), ("dgrad", 2560, 768, 3072),
           ("dgrad", 512, 768, 768),
