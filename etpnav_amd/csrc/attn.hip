@@ -157,6 +157,7 @@ struct AttnKArgs {
   void* P; int ldS;
   void* ctx; long ldc;
   int nh, Lq, Lk;
+  int nq;                        // forward: workgroups per (batch, head) along the query axis
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
   float alpha;
   // backward
@@ -188,14 +189,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
   float* ct = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-  const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
+  // one workgroup per (batch, head, block of BQ queries): long query axes are split over workgroups (K/V re-read from L2)
+  const int bh = blockIdx.x / a.nq, q0 = (blockIdx.x % a.nq) * BQ;
+  const int b = bh / a.nh, h = bh % a.nh;
+  const int Lq = min(BQ, a.Lq - q0);                     // valid query rows of this workgroup
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + ((long)b * a.Lq + q0) * a.ldq + h * 64;
   const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
   const T* Vg = reinterpret_cast<const T*>(a.V) + (long)b * a.Lk * a.ldv + h * 64;
-  T* Pg = reinterpret_cast<T*>(a.P) + (long)blockIdx.x * a.Lq * a.ldS;
-  T* Cg = reinterpret_cast<T*>(a.ctx) + (long)b * a.Lq * a.ldc + h * 64;
+  T* Pg = reinterpret_cast<T*>(a.P) + ((long)bh * a.Lq + q0) * a.ldS;
+  T* Cg = reinterpret_cast<T*>(a.ctx) + ((long)b * a.Lq + q0) * a.ldc + h * 64;
 
-  nat_load<T, BQ, 64>(qt, Qg, a.ldq, a.Lq, 64, tid);
+  nat_load<T, BQ, 64>(qt, Qg, a.ldq, Lq, 64, tid);
   nat_load<T, BKV, 64>(kt, Kg, a.ldk, a.Lk, 64, tid);
   nat_load<T, BKV, 64>(vt, Vg, a.ldv, a.Lk, 64, tid);
   // additive key mask / validity of this lane's NT columns (one per 16-column tile), loaded once
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
-      const float* d = (a.dist && row < a.Lq) ? a.dist + ((long)b * a.Lq + row) * a.Lk : nullptr;
+      const float* d = (a.dist && row < Lq) ? a.dist + ((long)b * a.Lq + q0 + row) * a.Lk : nullptr;
       float mx = -INFINITY;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
-      const float inv = (row < a.Lq) ? 1.0f / (rsum[row] + rsum[BQ + row]) : 0.f;   // unused query rows -> P = 0
+      const float inv = (row < Lq) ? 1.0f / (rsum[row] + rsum[BQ + row]) : 0.f;   // unused query rows -> P = 0
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int col = wc * (BKV / 2) + n * 16 + i;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
     using N = Nat<T, BKV>;
     for (int q = tid; q < BQ * N::CPR; q += 256) {
       const int r = q / N::CPR, c = (q % N::CPR) * N::EPC;
-      if (r < a.Lq && c < a.ldS)
+      if (r < Lq && c < a.ldS)
         *reinterpret_cast<uint4*>(Pg + (long)r * a.ldS + c) = *reinterpret_cast<const uint4*>(pt + r * PP + (q % N::CPR) * 16);
     }
   }
@@ -280,16 +284,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
   __syncthreads();   // P tile dead -> fp32 output staging
   acc_to_lds(oc, ct, 68, wr * (BQ / 2), wc * 32, 1.0f, lane);
   __syncthreads();
-  store_rows64<T, BQ>(ct, Cg, a.ldc, a.Lq, tid);
+  store_rows64<T, BQ>(ct, Cg, a.ldc, Lq, tid);
 }
 
+// Backward LDS plan (bf16 128x128: 77 KB -> two workgroups per CU): three slots that are reused as operands die:
+//   S1: dO (dP, dV)  -> Q (dK)      S2: V (dP) -> K (dQ)      S3: P (softmax bwd, dV) -> dS (dK, dQ)
 template <typename T, int BQ, int BKV> struct AttnBwdLds {
   static constexpr int PQ = Nat<T, 64>::PITCH, PP = Nat<T, BKV>::PITCH;
-  static constexpr int Q_OFF = 0, DO_OFF = BQ * PQ, K_OFF = 2 * BQ * PQ, V_OFF = K_OFF + BKV * PQ;
-  static constexpr int P_OFF = V_OFF + BKV * PQ, DS_OFF = P_OFF + BQ * PP, RD_OFF = DS_OFF + BQ * PP;
-  static constexpr int TOTAL = RD_OFF + 2 * BQ * 4 + 64;
+  static constexpr int S1_OFF = 0, S2_OFF = BQ * PQ, S3_OFF = S2_OFF + BKV * PQ, RD_OFF = S3_OFF + BQ * PP;
   static constexpr int STAGE_ROWS = BQ > BKV ? BQ : BKV;
-  static_assert(STAGE_ROWS * 68 * 4 <= P_OFF, "output staging must fit in the q/dO/k/v region");
+  static constexpr int TILES = RD_OFF, STAGE = STAGE_ROWS * 68 * 4;
+  static constexpr int RD = TILES > STAGE ? TILES : STAGE;                 // row-dot exchange sits behind tiles AND staging
+  static constexpr int TOTAL = RD + 2 * BQ * 4 + 64;
 };
 
 template <typename T, int BQ, int BKV>
@@ -298,11 +304,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
   constexpr int PQ = L::PQ, PP = L::PP;
   constexpr int MTq = BQ / 32, MTk = BKV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *qt = smem + L::Q_OFF, *dot = smem + L::DO_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *pt = smem + L::P_OFF,
-       *dst = smem + L::DS_OFF;
-  float* rowdot = reinterpret_cast<float*>(smem + L::RD_OFF);   // [2][BQ]
+  char *s1 = smem + L::S1_OFF, *s2 = smem + L::S2_OFF, *s3 = smem + L::S3_OFF;
+  float* rowdot = reinterpret_cast<float*>(smem + L::RD);      // [2][BQ]
   float* red = rowdot + 2 * BQ;                                  // [16] block reduction of the sprel gradients
-  float* ct = reinterpret_cast<float*>(smem);                    // output staging (aliases q/dO/k/v once they are dead)
+  float* ct = reinterpret_cast<float*>(smem);                    // output staging (aliases the tiles once they are dead)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
@@ -312,19 +317,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
   const T* Pg = reinterpret_cast<const T*>(a.P) + (long)blockIdx.x * a.Lq * a.ldS;
   const T* Dg = reinterpret_cast<const T*>(a.dctx) + (long)b * a.Lq * a.ldd + h * 64;
 
-  nat_load<T, BQ, 64>(qt, Qg, a.ldq, a.Lq, 64, tid);
-  nat_load<T, BQ, 64>(dot, Dg, a.ldd, a.Lq, 64, tid);
-  nat_load<T, BKV, 64>(kt, Kg, a.ldk, a.Lk, 64, tid);
-  nat_load<T, BKV, 64>(vt, Vg, a.ldv, a.Lk, 64, tid);
-  nat_load<T, BQ, BKV>(pt, Pg, a.ldS, a.Lq, a.ldS, tid);
+  nat_load<T, BQ, 64>(s1, Dg, a.ldd, a.Lq, 64, tid);         // dO
+  nat_load<T, BKV, 64>(s2, Vg, a.ldv, a.Lk, 64, tid);        // V
+  nat_load<T, BQ, BKV>(s3, Pg, a.ldS, a.Lq, a.ldS, tid);     // P
   __syncthreads();
 
   // dP = dO V^T, then dS = P * (dP - rowsum(dP*P)) without leaving the registers
   f32x4_t dp[MTq][MTk];
   acc_zero(dp);
-  tile_mma<T, MTq, MTk, 2, false, false, PQ, PQ>(dp, dot, wr * (BQ / 2), vt, wc * (BKV / 2), lane);
+  tile_mma<T, MTq, MTk, 2, false, false, PQ, PQ>(dp, s1, wr * (BQ / 2), s2, wc * (BKV / 2), lane);
   float pv[MTq][MTk][4];
-  float part[MTq][4];
 #pragma unroll
   for (int m = 0; m < MTq; ++m)
 #pragma unroll
@@ -334,16 +336,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
 #pragma unroll
       for (int n = 0; n < MTk; ++n) {
         const int col = wc * (BKV / 2) + n * 16 + i;
-        const float p = Elem<T>::ld(reinterpret_cast<const T*>(pt + row * PP) + col);
+        const float p = Elem<T>::ld(reinterpret_cast<const T*>(s3 + row * PP) + col);
         pv[m][n][r] = p;
         s += p * dp[m][n][r];
       }
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-      part[m][r] = s;
       if (i == 0) rowdot[wc * BQ + row] = s;
     }
-  __syncthreads();
+  // dV = P^T dO while P and dO are still resident
+  f32x4_t dv[MTk][2];
+  acc_zero(dv);
+  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dv, s3, wr * (BKV / 2), s1, wc * 32, lane);
+  __syncthreads();   // row dots published; every wave is done with dO, V and P
+  nat_load<T, BQ, 64>(s1, Qg, a.ldq, a.Lq, 64, tid);         // Q over dO
+  nat_load<T, BKV, 64>(s2, Kg, a.ldk, a.Lk, 64, tid);        // K over V
   float aw = 0.f, ab = 0.f;
 #pragma unroll
   for (int m = 0; m < MTq; ++m)
@@ -356,19 +363,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
       for (int n = 0; n < MTk; ++n) {
         const int col = wc * (BKV / 2) + n * 16 + i;
         const float ds = pv[m][n][r] * (dp[m][n][r] - dsum);
-        Elem<T>::st(reinterpret_cast<T*>(dst + row * PP) + col, ds);
+        Elem<T>::st(reinterpret_cast<T*>(s3 + row * PP) + col, ds);   // dS over P
         if (d && col < a.Lk) { aw += ds * d[col]; ab += ds; }
       }
     }
-  (void)part;
   __syncthreads();
 
-  // dV = P^T dO, dK = alpha dS^T Q (rows = keys), dQ = alpha dS K (rows = queries)
-  f32x4_t dv[MTk][2], dk[MTk][2], dq[MTq][2];
-  acc_zero(dv); acc_zero(dk); acc_zero(dq);
-  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dv, pt, wr * (BKV / 2), dot, wc * 32, lane);
-  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dk, dst, wr * (BKV / 2), qt, wc * 32, lane);
-  tile_mma<T, MTq, 2, BKV / 32, false, true, PP, PQ>(dq, dst, wr * (BQ / 2), kt, wc * 32, lane);
+  // dK = alpha dS^T Q (rows = keys), dQ = alpha dS K (rows = queries)
+  f32x4_t dk[MTk][2], dq[MTq][2];
+  acc_zero(dk); acc_zero(dq);
+  tile_mma<T, MTk, 2, BQ / 32, true, true, PP, PQ>(dk, s3, wr * (BKV / 2), s1, wc * 32, lane);
+  tile_mma<T, MTq, 2, BKV / 32, false, true, PP, PQ>(dq, s3, wr * (BQ / 2), s2, wc * 32, lane);
   __syncthreads();   // every operand tile is dead: reuse the front of LDS as the fp32 staging tile
 
   T* dQg = reinterpret_cast<T*>(a.dQ) + (long)b * a.Lq * a.lddq + h * 64;
@@ -449,11 +454,10 @@ static AttnKArgs make_args(int nh, const AttnBuf& a, float alpha) {
 int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
   AttnKArgs k = make_args(nh, a, alpha);
   k.P = P; k.ctx = ctx; k.ldc = ldc;
-  const int blocks = a.B * nh;
-  const bool bq = a.Lq > 64, bk = a.Lk > 64;
+  k.nq = (a.Lq + 63) / 64;                        // 64 queries per workgroup
+  const int blocks = a.B * nh * k.nq;
+  const bool bk = a.Lk > 64;
   if (dt == ETP_BF16) {
-    if (bq && bk) return launch_fwd<bf16_t, 128, 128>(k, blocks, st);
-    if (bq) return launch_fwd<bf16_t, 128, 64>(k, blocks, st);
     if (bk) return launch_fwd<bf16_t, 64, 128>(k, blocks, st);
     return launch_fwd<bf16_t, 64, 64>(k, blocks, st);
   }
