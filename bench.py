@@ -103,6 +103,10 @@ def main():
                          "slower on MI355X: the step is not launch-bound (DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
+    ap.add_argument("--same-device", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,10 +115,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://")
+        dist.init_process_group(args.dist_backend, init_method="env://")
 
     from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
     from etpnav_amd.step import PlannerStep
@@ -132,7 +138,7 @@ def main():
     step = PlannerStep(model, batch, overlap="s2" if use_graph else True)
     reducer = None
     if world > 1:
-        ranges, sparse = dp.planner_buckets(model)
+        ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=3)
         reducer = dp.GradReducer(model.flat_grads, ranges,
                                  comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
                                  sparse_rows=sparse)
@@ -150,9 +156,14 @@ def main():
         reducer.reduce_bucket(0)                                 # non-text matrices: overlaps the text backward
         if use_graph:
             step.replay(part=1)
+            nxt = 1
         else:
-            step.enqueue_txt_bwd(model._engine.stream())
-        for i in range(1, len(reducer.ranges)):
+            # text backward in layer groups (last layers first); each group's gradients are reduced while the next runs
+            for k, (lo, hi) in enumerate(txt_groups):
+                step.enqueue_txt_bwd(model._engine.stream(), lo, hi)
+                reducer.reduce_bucket(1 + k)
+            nxt = 1 + len(txt_groups)
+        for i in range(nxt, len(reducer.ranges)):
             reducer.reduce_bucket(i)
         reducer.reduce_sparse_rows(step.inp["txt_ids"])
         reducer.finish()

@@ -581,26 +581,37 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
   return ETP_OK;
 }
 
-int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
-                etp_stream_t stream) {
+// Backward of text layers [layer_lo, layer_hi) (processed from layer_hi-1 down).  The running gradient lives at the front of
+// `ws`, so consecutive calls with the same ws continue where the previous one stopped; a caller can therefore interleave
+// gradient all-reduces of the finished layers with the rest of the backward (data-parallel overlap).
+int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash,
+                      void* ws, int layer_lo, int layer_hi, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P && p->G && dout && ids && mask && stash && ws && B > 0 && L > 0, "bad arguments");
+  ETP_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= p->cfg.n_l, "bad layer range");
   Ctx c = make_ctx(p, stream);
   Bump b(stash);
   TxtStash t = plan_txt(p, b, B, L);
   Bump wb(ws);
   const int H = c.H, M = B * L;
   float* g = (float*)wb.take((size_t)M * H * 4);
-  ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
+  if (layer_hi == p->cfg.n_l) ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
   for (int l = p->cfg.n_l - 1; l >= 0; --l) {
     const Act x = l == 0 ? t.x0 : t.ffn[l - 1].y;
-    BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf));
+    BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);   // same carving in every call
     BwdWs wa = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
+    if (l >= layer_hi || l < layer_lo) continue;
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf));
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa));
   }
-  ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
-                         p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st));
+  if (layer_lo == 0)
+    ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
+                           p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st));
   return join_wgrads(c);
+}
+int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
+                etp_stream_t stream) {
+  ETP_REQUIRE(p, "null planner");
+  return etp_txt_bwd_range(p, dout, ids, mask, B, L, stash, ws, 0, p->cfg.n_l, stream);
 }
 
 // ======================================================================================

@@ -84,10 +84,46 @@ class GradReducer:
         for h, buf, view in self._pending:
             if h is not None:
                 h.wait()
-            if buf is not None:
-                view.copy_(buf)
-            view.mul_(1.0 / self.world)
+            if buf is None:
+                view.mul_(1.0 / self.world)
+            elif view.is_cuda:
+                # one pass: bf16 sum -> fp32 mean (hand-written cast kernel through the C ABI)
+                from . import _lib
+                _lib.check(_lib.lib().etp_cast_bf16_to_f32(buf.data_ptr(), view.data_ptr(), view.numel(), 1.0 / self.world,
+                                                           torch.cuda.current_stream().cuda_stream), "cast_bf16_to_f32")
+            else:
+                torch.mul(buf, 1.0 / self.world, out=view)
         self._pending.clear()
+
+
+def planner_buckets_layered(model, text_groups: int = 3):
+    """Finer buckets for overlap with the text-encoder backward: bucket 0 = non-text matrices (ready after the navigation
+    and panorama backward), then one bucket per group of text layers in backward order (last layers first), then vectors
+    and small tables.  Returns (ranges, sparse_word_table, [(layer_lo, layer_hi) per text bucket])."""
+    eng = model._engine
+    tab = {n: (off, shape) for n, shape, off in eng.table}
+    n_l = int(eng.cconf.n_l)
+    starts = [tab[f"lang_encoder.layer.{l}.attention.self.query.weight"][0] for l in range(n_l)]
+    first_non_text = min(off for n, (off, _) in tab.items() if off < eng.n_matrix and not n.startswith("lang_encoder."))
+    assert starts == sorted(starts) and (not starts or starts[0] == 0) and all(s < first_non_text for s in starts)
+    starts.append(first_non_text)
+    word_off, word_shape = tab["embeddings.word_embeddings.weight"]
+    word_end = word_off + ((word_shape[0] * word_shape[1] + 63) // 64) * 64
+    ranges, groups = [], []
+    if first_non_text < eng.n_matrix:
+        ranges.append((first_non_text, eng.n_matrix))
+    text_groups = max(1, min(text_groups, n_l)) if n_l else 0
+    hi = n_l
+    for gidx in range(text_groups):
+        lo = (n_l * (text_groups - 1 - gidx)) // text_groups
+        ranges.append((starts[lo], starts[hi]))
+        groups.append((lo, hi))
+        hi = lo
+    if word_off > eng.n_matrix:
+        ranges.append((eng.n_matrix, word_off))
+    if word_end < eng.total:
+        ranges.append((word_end, eng.total))
+    return ranges, (word_off, word_shape[0], word_shape[1]), groups
 
 
 def planner_buckets(model, split_text: bool = True):

@@ -145,10 +145,15 @@ class PlannerStep:
         else:
             self._pano_pending = True
 
-    def enqueue_txt_bwd(self, s: int):
+    def enqueue_txt_bwd(self, s: int, layer_lo: int = 0, layer_hi: Optional[int] = None):
+        """Text-encoder backward (optionally only layers [layer_lo, layer_hi), descending calls share the running gradient)."""
         L, eng, i = self.L, self.eng, self.inp
-        check(L.etp_txt_bwd(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
-                            ptr(self.st_txt), ptr(self.ws_txt), s), "txt_bwd")
+        if layer_hi is None:
+            layer_hi = eng.cconf.n_l
+        check(L.etp_txt_bwd_range(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
+                                  ptr(self.st_txt), ptr(self.ws_txt), layer_lo, layer_hi, s), "txt_bwd")
+        if layer_lo > 0:
+            return
         if self._pano_pending:
             check(L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
             self._pano_pending = False

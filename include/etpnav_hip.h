@@ -215,6 +215,12 @@ int etp_txt_fwd(etp_planner* p, const int64_t* txt_ids, const uint8_t* txt_masks
 int etp_txt_bwd(etp_planner* p, const float* d_txt_embeds, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L,
                 void* stash, void* ws, etp_stream_t stream);
 
+/* Same, restricted to text layers [layer_lo, layer_hi) (call with descending ranges and the same ws: the running gradient is
+ * kept in ws).  The first call (layer_hi = n_l) reads d_txt_embeds, the last (layer_lo = 0) also runs the embedding backward.
+ * Lets a data-parallel caller all-reduce the gradients of finished layers while earlier layers are still in backward. */
+int etp_txt_bwd_range(etp_planner* p, const float* d_txt_embeds, const int64_t* txt_ids, const uint8_t* txt_masks, int B, int L,
+                      void* stash, void* ws, int layer_lo, int layer_hi, etp_stream_t stream);
+
 int64_t etp_pano_stash_bytes(const etp_planner* p, int B, int V);
 int64_t etp_pano_ws_bytes(const etp_planner* p, int B, int V);
 int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float* loc, const int64_t* nav_types,

@@ -81,3 +81,26 @@ def test_planner_bucket_ranges_cover_the_arena_once():
         off = (p.data_ptr() - m.flat_params.data_ptr()) // 4
         if name.startswith("lang_encoder.") or name.startswith("embeddings."):
             assert not (s0 <= off < e0), name
+
+
+def test_layered_buckets_cover_the_arena_once_and_follow_backward_order():
+    from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
+    m = GlocalTextPathNavCMT(default_config(vocab_size=1024), dtype=torch.float32, device="cpu")
+    ranges, (woff, wrows, wlen), groups = dp.planner_buckets_layered(m, text_groups=3)
+    assert groups == [(6, 9), (3, 6), (0, 3)]
+    cover = torch.zeros(m.flat_grads.numel(), dtype=torch.int32)
+    for s, e in ranges:
+        cover[s:e] += 1
+    cover[woff:woff + wrows * wlen] += 1
+    base = m.flat_params.data_ptr()
+    for name, p in m.named_parameters():
+        off = (p.data_ptr() - base) // 4
+        assert bool((cover[off:off + p.numel()] == 1).all()), name
+    # text bucket k holds exactly the matrices of its layer group
+    for k, (lo, hi) in enumerate(groups):
+        s, e = ranges[1 + k]
+        for name, p in m.named_parameters():
+            if name.startswith("lang_encoder.layer.") and p.dim() == 2:
+                layer = int(name.split(".")[2])
+                off = (p.data_ptr() - base) // 4
+                assert (s <= off < e) == (lo <= layer < hi), name

@@ -123,3 +123,20 @@ def test_fp32_step_vs_oracle_fresh_inputs_and_graph_replay():
     # atomically-accumulated sums may differ in the last bits between runs
     assert (model.flat_grads - eager_grad).abs().max().item() < 1e-4
     step.close()
+
+
+def test_text_backward_in_layer_ranges_equals_single_call():
+    """etp_txt_bwd_range over [6,9),[3,6),[0,3) (the data-parallel overlap schedule of bench.py) == one etp_txt_bwd."""
+    cfg = po.PlannerConfig.r2r(vocab_size=4096)
+    P = po.init_params(cfg, seed=2)
+    batch = po.make_batch(cfg, B=3, L=24, V=14, G=8, seed=5, ragged=True)
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch)
+    step.run_eager(); torch.cuda.synchronize()
+    ref = model.flat_grads.clone()
+    s = model._engine.stream()
+    step.enqueue_main(s, True, join_pano=True)
+    for lo, hi in ((6, 9), (3, 6), (0, 3)):
+        step.enqueue_txt_bwd(s, lo, hi)
+    torch.cuda.synchronize()
+    assert (model.flat_grads - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())

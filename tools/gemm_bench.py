@@ -44,26 +44,28 @@ def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
     fl = 2.0 * M * N * K
     return us, fl / us / 1e6
 
-shapes = [("fwd_s", 2560, 768, 768), ("fwd_s", 2560, 768, 3072), ("dgrad_s", 2560, 2304, 768), ("dgrad_s", 2560, 3072, 768),
-          ("dgrad_s", 512, 3072, 768), ("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
-          ("fwd", 1152, 2304, 768), ("fwd", 512, 768, 768), ("fwd", 512, 3072, 768),
-          ("dgrad", 2560, 2304, 768), ("dgrad", 2560, 768, 768), ("dgrad", 2560, 3072, 768), ("dgrad", 2560, 768, 3072),
-          ("dgrad", 512, 768, 768),
-          ("wgrad", 2560, 2304, 768), ("wgrad", 2560, 768, 768), ("wgrad", 2560, 3072, 768), ("wgrad", 2560, 768, 3072),
-          ("wgrad", 512, 768, 768), ("wgrad", 512, 3072, 768)]
-tiles = sys.argv[1:] or ["auto", "128", "64"]
-print(f"{'kind':6} {'M':>5} {'N':>5} {'K':>5} " + " ".join(f"{t+':us':>10} {'TF':>7}" for t in tiles))
-for kind, M, N, K in shapes:
-    row = f"{kind:6} {M:5d} {N:5d} {K:5d} "
-    for tl in tiles:
-        os.environ["ETP_GEMM_TILE"] = "" if tl == "auto" else tl
-        if kind == "wgrad":
-            best = None
-            for ks in (1, 2, 4, 8):
-                us, tf = run(kind, M, N, K, ksplit=ks)
-                if best is None or us < best[0]: best = (us, tf, ks)
-            row += f"{best[0]:10.1f} {best[1]:7.1f}(ks{best[2]})"
-        else:
-            us, tf = run(kind, M, N, K)
-            row += f"{us:10.1f} {tf:7.1f} "
-    print(row, flush=True)
+if __name__ == "__main__":
+    shapes = [("fwd_s", 2560, 768, 768), ("fwd_s", 2560, 768, 3072), ("dgrad_s", 2560, 2304, 768), ("dgrad_s", 2560, 3072, 768),
+              ("dgrad_s", 512, 3072, 768), ("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
+              ("fwd", 1152, 2304, 768), ("fwd", 512, 768, 768), ("fwd", 512, 3072, 768),
+              ("dgrad", 2560, 2304, 768), ("dgrad", 2560, 768, 768), ("dgrad", 2560, 3072, 768), ("dgrad", 2560, 768, 3072),
+              ("dgrad", 512, 768, 768),
+              ("wgrad", 2560, 2304, 768), ("wgrad", 2560, 768, 768), ("wgrad", 2560, 3072, 768), ("wgrad", 2560, 768, 3072),
+              ("wgrad", 512, 768, 768), ("wgrad", 512, 3072, 768)]
+    tiles = sys.argv[1:] or ["auto", "128", "64"]
+    print(f"{'kind':6} {'M':>5} {'N':>5} {'K':>5} " + " ".join(f"{t+':us':>10} {'TF':>7}" for t in tiles))
+    for kind, M, N, K in shapes:
+        row = f"{kind:6} {M:5d} {N:5d} {K:5d} "
+        for tl in tiles:
+            os.environ["ETP_GEMM_TILE"] = "" if tl == "auto" else tl
+            if kind == "wgrad":
+                best = None
+                for ks in (1, 2, 4, 8):
+                    us, tf = run(kind, M, N, K, ksplit=ks)
+                    if best is None or us < best[0]: best = (us, tf, ks)
+                row += f"{best[0]:10.1f} {best[1]:7.1f}(ks{best[2]})"
+            else:
+                us, tf = run(kind, M, N, K)
+                row += f"{us:10.1f} {tf:7.1f} "
+        print(row, flush=True)
+
