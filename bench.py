@@ -102,6 +102,9 @@ def main():
                     help="replay a captured hipGraph (one side stream) instead of eager three-stream issue; measured "
                          "slower on MI355X: the step is not launch-bound (DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="train (default): dropout active at every site, as under the reference's policy.train() "
+                         "(ss_trainer_ETP.py:483); eval: dropout off (the parity-fixture configuration)")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
@@ -135,7 +138,8 @@ def main():
     batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
                        seed=1234 + rank)                          # each rank owns its episodes
     use_graph = args.graph
-    step = PlannerStep(model, batch, overlap="s2" if use_graph else True)
+    step = PlannerStep(model, batch, overlap="s2" if use_graph else True,
+                       dropout="config" if args.mode == "train" else None, drop_seed=rank)
     reducer = None
     if world > 1:
         ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=3)
@@ -230,7 +234,10 @@ def main():
                                    f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
                        "global_batch": w["B"] * world, "parallelism": f"dp{world}",
-                       "graph": use_graph, "grad_comm_dtype": args.comm_dtype if world > 1 else None},
+                       "graph": use_graph, "mode": args.mode,
+                       "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
+                                    "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
+                       "grad_comm_dtype": args.comm_dtype if world > 1 else None},
             "loss": round(loss, 5),
             "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
             "model_flops_per_step": fl,

@@ -81,7 +81,8 @@ class ProfEntry(ctypes.Structure):
 
 
 # ---- header parsing --------------------------------------------------------------------------
-_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+            "float": ctypes.c_float,
             "etp_stream_t": ctypes.c_void_p}
 
 

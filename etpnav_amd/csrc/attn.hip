@@ -158,6 +158,7 @@ struct AttnKArgs {
   void* ctx; long ldc;
   int nh, Lq, Lk;
   int nq;                        // forward: workgroups per (batch, head) along the query axis
+  Drop drop;                     // dropout on the probabilities; element index = ((b*heads+h)*Lq + q)*Lk + k
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
   float alpha;
   // backward
@@ -278,6 +279,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnKArgs a) {
         *reinterpret_cast<uint4*>(Pg + (long)r * a.ldS + c) = *reinterpret_cast<const uint4*>(pt + r * PP + (q % N::CPR) * 16);
     }
   }
+  if (a.drop.p > 0.f) {   // attention dropout (vilmodel_cmt.py:127): P.V uses the dropped probabilities, backward keeps P
+    __syncthreads();      // the undropped tile has been copied out
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+        const float inv = (row < Lq) ? 1.0f / (rsum[row] + rsum[BQ + row]) : 0.f;
+        const uint32_t rbase = ((uint32_t)bh * a.Lq + q0 + row) * (uint32_t)a.Lk;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = wc * (BKV / 2) + n * 16 + i;
+          Elem<T>::st(reinterpret_cast<T*>(pt + row * PP) + col,
+                      sc[m][n][r] * inv * drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep));
+        }
+      }
+    __syncthreads();
+  }
   f32x4_t oc[MT][2];
   acc_zero(oc);
   tile_mma<T, MT, 2, BKV / 32, false, true, PP, PQ>(oc, pt, wr * (BQ / 2), vt, wc * 32, lane);
@@ -327,23 +346,43 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
   acc_zero(dp);
   tile_mma<T, MTq, MTk, 2, false, false, PQ, PQ>(dp, s1, wr * (BQ / 2), s2, wc * (BKV / 2), lane);
   float pv[MTq][MTk][4];
+  const bool dropping = a.drop.p > 0.f;
 #pragma unroll
   for (int m = 0; m < MTq; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+      const uint32_t rbase = ((uint32_t)blockIdx.x * a.Lq + row) * (uint32_t)a.Lk;
       float s = 0.f;
 #pragma unroll
       for (int n = 0; n < MTk; ++n) {
         const int col = wc * (BKV / 2) + n * 16 + i;
         const float p = Elem<T>::ld(reinterpret_cast<const T*>(s3 + row * PP) + col);
         pv[m][n][r] = p;
+        if (dropping) dp[m][n][r] *= drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep);   // d P = d P_drop * mask/(1-p)
         s += p * dp[m][n][r];
       }
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
       if (i == 0) rowdot[wc * BQ + row] = s;
     }
+  if (dropping) {   // dV needs the DROPPED probabilities: rewrite this lane's elements of the tile (all pv are in registers)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MTq; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * (BQ / 2) + m * 16 + g * 4 + r;
+        const uint32_t rbase = ((uint32_t)blockIdx.x * a.Lq + row) * (uint32_t)a.Lk;
+#pragma unroll
+        for (int n = 0; n < MTk; ++n) {
+          const int col = wc * (BKV / 2) + n * 16 + i;
+          Elem<T>::st(reinterpret_cast<T*>(s3 + row * PP) + col,
+                      pv[m][n][r] * drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep));
+        }
+      }
+    __syncthreads();
+  }
   // dV = P^T dO while P and dO are still resident
   f32x4_t dv[MTk][2];
   acc_zero(dv);
@@ -451,8 +490,9 @@ static AttnKArgs make_args(int nh, const AttnBuf& a, float alpha) {
   return k;
 }
 
-int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
+int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   AttnKArgs k = make_args(nh, a, alpha);
+  k.drop = drop;
   k.P = P; k.ctx = ctx; k.ldc = ldc;
   k.nq = (a.Lq + 63) / 64;                        // 64 queries per workgroup
   const int blocks = a.B * nh * k.nq;
@@ -465,8 +505,9 @@ int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ld
 }
 
 int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK,
-                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st) {
+                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop) {
   AttnKArgs k = make_args(nh, a, alpha);
+  k.drop = drop;
   k.P = const_cast<void*>(P); k.dctx = dctx; k.ldd = ldd;
   k.dQ = dQ; k.dK = dK; k.dV = dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv; k.d_sp_w = d_sp_w; k.d_sp_b = d_sp_b;
   const int blocks = a.B * nh;

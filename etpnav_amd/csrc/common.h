@@ -69,6 +69,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// ---- counter-based dropout: mask bit = hash(seed, element index); forward and backward recompute the same mask, none is
+// stored.  `seed` already mixes the per-step seed with the dropout site id (drop_site_seed on the host).
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x += seed * 0x27D4EB2Fu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return x;
+}
+// multiplier of element idx under dropout probability p: 0 (dropped) or 1/(1-p)
+__host__ __device__ __forceinline__ float drop_mult(uint32_t seed, uint32_t idx, float p, float inv_keep) {
+  return ((drop_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+struct Drop {                          // dropout of one site; p == 0 -> identity
+  float p, inv_keep; uint32_t seed;
+};
+inline Drop drop_none() { Drop d; d.p = 0.f; d.inv_keep = 1.f; d.seed = 0; return d; }
+inline Drop drop_site(float p, uint64_t step_seed, uint32_t site) {
+  Drop d;
+  d.p = p; d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+  d.seed = drop_hash((uint32_t)(step_seed ^ (step_seed >> 32)) * 0x9E3779B1u + 0x7F4A7C15u, site * 0x632BE5ABu + 17u);
+  return d;
+}
+
 // ---- host side ----
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
@@ -109,6 +132,8 @@ struct GemmArgs {
   int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
   int vec_epilogue;                   // set by launch_gemm: 16-byte epilogue accesses are legal
   float* a_colsum;                    // TN (wgrad) only: a_colsum[m] += sum_k A[m,k]  (bias gradient), LDS-DMA kernel only
+  Drop drop;                          // dropout on the epilogue value (after activation / its backward, before the residual);
+                                      // element index = row * N + col
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
 bool gemm_uses_dma(int dtype, int K, int ksplit);   // true when launch_gemm will take the LDS-DMA kernel for this reduction

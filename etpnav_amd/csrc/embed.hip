@@ -122,6 +122,16 @@ template <int NCH> __device__ __forceinline__ void block_flush(float* scratch, c
     atomicAdd(dst + (long)col * stride + off, scratch[col] + scratch[H + col] + scratch[2 * H + col] + scratch[3 * H + col]);
   __syncthreads();
 }
+// x[col] *= mask(row*H + col) / (1-p)
+template <int NCH> __device__ __forceinline__ void row_dropout(Row<NCH>& x, const Drop& d, int row, int lane) {
+  if (d.p > 0.f) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        x.v[c][e] *= drop_mult(d.seed, (uint32_t)row * (NCH * 256) + c * 256 + lane * 4 + e, d.p, d.inv_keep);
+  }
+}
 template <int NCH> __device__ __forceinline__ void global_acc(float* dst, const Row<NCH>& a, int lane) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
                                                              const float* __restrict__ pos, const float* __restrict__ type0,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ y, T* __restrict__ yt, float* __restrict__ stats,
-                                                             int M, int L, float eps) {
+                                                             int M, int L, float eps, Drop drop) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
     float mean, rstd;
     row_normalize<NCH>(x, eps, mean, rstd);
     row_affine<NCH>(t, x, gamma, beta, lane);
+    row_dropout<NCH>(t, drop, row, lane);             // BertEmbeddings.dropout vilmodel_cmt.py:76
     row_store<NCH>(t, y + (long)row * H, lane);
     if (yt != nullptr) row_store<NCH>(t, yt + (long)row * H, lane);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
@@ -165,7 +176,8 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
                                                              const float* __restrict__ type0, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, float* __restrict__ dword,
                                                              float* __restrict__ dpos, float* __restrict__ dtype0,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int L) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int L,
+                                                             Drop drop) {
   constexpr int H = NCH * 256;
   __shared__ float scratch[4 * H];
   Row<NCH> a_g, a_b, a_t;   // dgamma, dbeta, dtype0
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 4; ++e) x.v[c][e] = (x.v[c][e] - mean) * rstd;
     row_load<NCH>(d, dy + (long)row * H, lane);
+    row_dropout<NCH>(d, drop, row, lane);
     acc_mul<NCH>(a_g, d, x);
     acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
@@ -221,7 +234,7 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict__ a, const T* __restrict__ d,
                                                              const float* __restrict__ loc, const int64_t* __restrict__ nav,
                                                              PanoEmbedParams p, float* __restrict__ y, float* __restrict__ stats,
-                                                             int M) {
+                                                             int M, Drop drop) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict
     row_add<NCH>(e, t);
     row_normalize<NCH>(e, 1e-12f, mean, rstd);
     row_affine<NCH>(t, e, p.g_out, p.b_out, lane);
+    row_dropout<NCH>(t, drop, row, lane);             // img_embeddings.dropout vilmodel_cmt.py:711
     row_store<NCH>(t, y + (long)row * H, lane);
     if (lane == 0) { st[6] = mean; st[7] = rstd; }
   }
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __rest
                                                              const T* __restrict__ d, const float* __restrict__ loc,
                                                              const int64_t* __restrict__ nav, const float* __restrict__ stats,
                                                              PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
-                                                             T* __restrict__ dd, int M) {
+                                                             T* __restrict__ dd, int M, Drop drop) {
   constexpr int H = NCH * 256;
   // register accumulators: g/b x {img,dep,loc,out} + nav_emb[0..1] + type1 + bias_loc + w_loc[.,0..3] = 16 rows
   extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __rest
       for (int k = 0; k < 4; ++k) e.v[c][k] = (e.v[c][k] - st[6]) * st[7];
     // outer LN backward
     row_load<NCH>(de, dy + (long)row * H, lane);
+    row_dropout<NCH>(de, drop, row, lane);
     acc_mul<NCH>(A_go, de, e);
     acc_scaled<NCH>(A_bo, de, 1.0f);
     row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);   // de = grad wrt the branch sum
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(256) void sap_tail_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, const float* __restrict__ w2,
                                                            const float* __restrict__ b2, const uint8_t* __restrict__ visited,
                                                            const uint8_t* __restrict__ valid, float* __restrict__ logits,
-                                                           float* __restrict__ stats, int M) {
+                                                           float* __restrict__ stats, int M, Drop drop) {
   constexpr int H = NCH * 256;
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
@@ -460,6 +475,7 @@ __global__ __launch_bounds__(256) void sap_tail_fwd_kernel(const T* __restrict__
     float mean, rstd;
     row_normalize<NCH>(x, 1e-12f, mean, rstd);
     row_affine<NCH>(n, x, gamma, beta, lane);
+    row_dropout<NCH>(n, drop, row, lane);             // NextActionPrediction Dropout vilmodel_cmt.py:657
     row_load<NCH>(w, w2, lane);
     const float v = row_dot<NCH>(n, w) + b2[0];
     if (lane == 0) {
@@ -478,7 +494,7 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
                                                            const uint8_t* __restrict__ visited, const uint8_t* __restrict__ valid,
                                                            T* __restrict__ dz, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, float* __restrict__ dw2,
-                                                           float* __restrict__ db2, int M) {
+                                                           float* __restrict__ db2, int M, Drop drop) {
   constexpr int H = NCH * 256;
   __shared__ float scratch[4 * H];
   __shared__ float sb2[4];
@@ -497,13 +513,15 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) x.v[c][e] = (rr.v[c][e] - mean) * rstd;
     row_affine<NCH>(n, x, gamma, beta, lane);
-    acc_scaled<NCH>(a_w, n, dl);                     // dw2 += dl * n
+    row_dropout<NCH>(n, drop, row, lane);
+    acc_scaled<NCH>(a_w, n, dl);                     // dw2 += dl * dropout(n)
     a_b2 += dl;                                      // db2 (same value on every lane)
     row_load<NCH>(d, w2, lane);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) d.v[c][e] *= dl;
+    row_dropout<NCH>(d, drop, row, lane);            // d n = dl * w2 * mask/(1-p)
     acc_mul<NCH>(a_g, d, x);
     acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
@@ -625,6 +643,21 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     }
   }
 }
+// dst(T) = dropout(src): ETP.forward drop_env on the RGB view features (Policy_ViewSelection_ETP.py:102,345) fused with the
+// fp32 -> operand-dtype conversion
+template <typename T>
+__global__ __launch_bounds__(256) void cast_drop_kernel(const float* __restrict__ src, T* __restrict__ dst, long n, Drop drop) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i + 4 <= n; i += stride) {
+    float v[4];
+    load4(src + i, v);
+    if (drop.p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= drop_mult(drop.seed, (uint32_t)(i + e), drop.p, drop.inv_keep);
+    }
+    store4(dst + i, v);
+  }
+}
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n,
                                                             float scale) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -650,44 +683,44 @@ static inline int row_grid(int M, int cap) { return (int)std::min<long>(((long)M
 // Activations that cross kernels of the "residual stream" are fp32 (y / dy below); `yt` / `xt` are optional copies in
 // the GEMM operand dtype `dtype` (NULL in fp32 mode, where the fp32 tensor itself is the operand).
 int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st) {
+                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st, Drop drop) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   const int M = B * L, grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (bf16_t*)yt, stats, M, L, eps)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (float*)yt, stats, M, L, eps)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (bf16_t*)yt, stats, M, L, eps, drop)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (float*)yt, stats, M, L, eps, drop)); }
   ETP_CHECK_LAUNCH("text_embed_fwd");
   return ETP_OK;
 }
 
 int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
                    const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
-                   int B, int L, int H, hipStream_t st) {
+                   int B, int L, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   (void)dtype;
   const int M = B * L, grid = row_grid(M, 128);
-  ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L));
+  ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
   ETP_CHECK_LAUNCH("text_embed_bwd");
   return ETP_OK;
 }
 
 int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
-                   float* y, float* stats, int M, int H, hipStream_t st) {
+                   float* y, float* stats, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, y, stats, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, y, stats, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, y, stats, M, drop)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, y, stats, M, drop)); }
   ETP_CHECK_LAUNCH("pano_embed_fwd");
   return ETP_OK;
 }
 
 int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
-                   hipStream_t st) {
+                   hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M, drop)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M, drop)); }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }
@@ -716,22 +749,22 @@ int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const fl
 }
 
 int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
-                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st) {
+                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
   ETP_CHECK_LAUNCH("sap_tail_fwd");
   return ETP_OK;
 }
 
 int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
                  const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
-                 float* dw2, float* db2, int M, int H, hipStream_t st) {
+                 float* dw2, float* db2, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 64);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
+  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
   ETP_CHECK_LAUNCH("sap_tail_bwd");
   return ETP_OK;
 }
@@ -769,6 +802,15 @@ int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
   const int grid = (int)std::min<long>((n / 8 + 255) / 256 + 1, 4096);
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
   ETP_CHECK_LAUNCH("cast_f32_bf16");
+  return ETP_OK;
+}
+int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  ETP_REQUIRE(n % 4 == 0, "cast_drop: element count must be a multiple of 4");
+  const int grid = (int)std::min<long>((n / 4 + 255) / 256, 4096);
+  if (dtype == ETP_BF16) hipLaunchKernelGGL((cast_drop_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n, drop);
+  else hipLaunchKernelGGL((cast_drop_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, drop);
+  ETP_CHECK_LAUNCH("cast_drop");
   return ETP_OK;
 }
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st) {

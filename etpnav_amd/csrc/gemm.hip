@@ -307,6 +307,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
           for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
         }
       }
+      if (g.drop.p > 0.f) {
+        const uint32_t e0 = (uint32_t)row * (uint32_t)g.N + (uint32_t)col;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_mult(g.drop.seed, e0 + e, g.drop.p, g.drop.inv_keep);
+      }
       if (has_r) {
         float rf[8];
         unpack8<TC>(rr[jj], rf);
@@ -350,6 +355,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
     } else if (g.act == ETP_ACT_RELU_BWD) {
       v = (Elem<T>::ld(Z + (long)row * g.ldz + col) > 0.f) ? v : 0.f;
     }
+    if (g.drop.p > 0.f) v *= drop_mult(g.drop.seed, (uint32_t)row * (uint32_t)g.N + (uint32_t)col, g.drop.p, g.drop.inv_keep);
     if (g.R != nullptr) v += Elem<TC>::ld(reinterpret_cast<const TC*>(g.R) + (long)row * g.ldr + col);
     TC* dst = C + (long)row * g.ldc + col;
     if constexpr (sizeof(TC) == 4) {
@@ -749,6 +755,7 @@ int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, in
               "batch strides must keep 16-byte alignment");
   ETP_REQUIRE(g0.out_mode != 2 || c_dtype == ETP_F32, "atomic accumulation needs an fp32 C");
   ETP_REQUIRE(g0.ksplit == 1 || g0.out_mode == 2, "split-K needs atomic accumulation");
+  ETP_REQUIRE(g0.drop.p == 0.f || (g0.ksplit == 1 && nbatch == 1), "epilogue dropout needs an unsplit, unbatched product");
   ETP_REQUIRE(g0.a_colsum == nullptr || (ta && tb && gemm_uses_dma(dtype, g0.K, g0.ksplit)),
               "a_colsum needs the TN LDS-DMA kernel (check gemm_uses_dma first)");
   GemmArgs g = g_in;

@@ -18,22 +18,23 @@ int ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const f
 int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,
              float eps, hipStream_t st);
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
-             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st);
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop = drop_none());
 int softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
                 int nh, int Lq, int Lk, int ldS, int mask_mode, hipStream_t st);
 int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int nh, int Lq,
                 int Lk, int ldS, hipStream_t st);
 
 int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st);
+                   const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st,
+                   Drop drop = drop_none());
 int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* word, const float* pos, const float* type0,
                    const float* gamma, const float* stats, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
-                   int B, int L, int H, hipStream_t st);
+                   int B, int L, int H, hipStream_t st, Drop drop = drop_none());
 int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, const int64_t* nav, const PanoEmbedParams& p,
-                   float* y, float* stats, int M, int H, hipStream_t st);
+                   float* y, float* stats, int M, int H, hipStream_t st, Drop drop = drop_none());
 int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
-                   hipStream_t st);
+                   hipStream_t st, Drop drop = drop_none());
 int gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const float* pos, const float* step_emb,
                    const float* w_pos, const float* b_pos, const float* gamma, const float* beta, float* x, void* xt, float* stats,
                    int M, int H, int PK, hipStream_t st);
@@ -41,16 +42,18 @@ int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const fl
                    const float* gamma, const float* stats, float* d_step_emb, float* d_w_pos, float* d_b_pos, float* dgamma,
                    float* dbeta, int M, int H, int PK, hipStream_t st);
 int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta, const float* w2, const float* b2,
-                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st);
+                 const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st,
+                 Drop drop = drop_none());
 int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* gamma, const float* beta, const float* w2,
                  const float* stats, const uint8_t* visited, const uint8_t* valid, void* dz, float* dgamma, float* dbeta,
-                 float* dw2, float* db2, int M, int H, hipStream_t st);
+                 float* dw2, float* db2, int M, int H, hipStream_t st, Drop drop = drop_none());
 int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale, long ignore_index,
            hipStream_t st);
 int gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
                int accumulate, hipStream_t st);
 int colsum(int dtype, const void* dy, long ld, float* db, int M, int N, hipStream_t st);
 int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);
+int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStream_t st);   // dst(T) = dropout(src)
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st);
 int scale_f32(float* p, long n, float scale, hipStream_t st);
 
@@ -62,11 +65,14 @@ struct AttnBuf {
 };
 // fused single-kernel variants (attn.hip) for Lq, Lk <= 128
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);
-int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st);
+int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
 int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK,
-                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st);
-int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st);
+                   long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop);
+// drop = dropout on the attention probabilities (vilmodel_cmt.py:127,346; MHA dropout); only the fused kernels implement it
+int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st,
+                  Drop drop = drop_none());
 int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
-                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st);
+                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st,
+                  Drop drop = drop_none());
 
 }  // namespace etp

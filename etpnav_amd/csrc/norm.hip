@@ -193,7 +193,7 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ add, float* __restrict__ dx, T* __restrict__ dxt,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M, Drop drop) {
   constexpr int H = NCH * 256;
   __shared__ float red[4][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -239,7 +239,13 @@ __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) o[e] += av[e];
       }
       if (dx != nullptr) store4(dx + (long)row * H + col, o);
-      if (dxt != nullptr) store4(dxt + (long)row * H + col, o);
+      if (dxt != nullptr) {
+        if (drop.p > 0.f) {   // the operand copy is the gradient of a dropped dense output: d(dense) = dx * mask / (1-p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= drop_mult(drop.seed, (uint32_t)row * H + col + e, drop.p, drop.inv_keep);
+        }
+        store4(dxt + (long)row * H + col, o);
+      }
     }
   }
   if (dgamma == nullptr) return;
@@ -277,13 +283,14 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
   return ETP_OK;
 }
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
-             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st) {
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (dx || dxt), "bad arguments");
+  ETP_REQUIRE(drop.p == 0.f || (dxt != nullptr && dxt != (void*)dx), "dropout needs a separate operand copy");
   const char* eg = getenv("ETP_LNBWD_GRID");
   const int cap = eg ? atoi(eg) : 128;
   const int grid = (int)std::min<long>((M + 3) / 4, cap);
-  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, M) }
-  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, M) }
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, M, drop) }
+  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, M, drop) }
   ETP_CHECK_LAUNCH("ln_bwd_s");
   return ETP_OK;
 }

@@ -45,6 +45,9 @@ struct etp_planner {
   int sap0_w, sap0_b, sap2_g, sap2_b, sap4_w, sap4_b;
   // bound arenas
   float* P = nullptr; void* S = nullptr; float* G = nullptr;
+  // training-mode dropout (0 = eval): hidden / attention-probability / RGB-feature ("drop_env") rates and the step seed
+  float p_hidden = 0.f, p_attn = 0.f, p_env = 0.f, p_head = 0.f;
+  uint64_t drop_seed = 0;
   // optional second stream: weight-gradient GEMMs (leaves of the backward graph) run beside the dgrad chain
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> events;
@@ -228,6 +231,16 @@ struct Ctx {
   int H, I, nh;
   hipStream_t sw;                                      // stream of the weight-gradient launches (== st when no aux stream)
 };
+// dropout sites: (entry point, layer, slot) -> independent mask streams
+enum { SITE_EMBED = 0, SITE_ATT_P = 1, SITE_ATT_O = 2, SITE_FFN_O = 3, SITE_FFN_I = 4, SITE_X_P = 5, SITE_X_O = 6, SITE_HEAD = 7,
+       SITE_ENV = 8 };
+enum { MODE_TXT = 1, MODE_PANO = 2, MODE_NAV = 3 };
+static inline Drop site(const Ctx& c, float p, int mode, int layer, int slot) {
+  return p > 0.f ? drop_site(p, c.pl->drop_seed, (uint32_t)(mode << 16 | layer << 4 | slot)) : drop_none();
+}
+static inline Drop hid(const Ctx& c, int mode, int layer, int slot) { return site(c, c.pl->p_hidden, mode, layer, slot); }
+static inline Drop att(const Ctx& c, int mode, int layer, int slot) { return site(c, c.pl->p_attn, mode, layer, slot); }
+
 static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
   Ctx c;
   c.pl = pl; c.st = reinterpret_cast<hipStream_t>(s); c.dt = pl->cfg.dtype; c.es = dtype_size(c.dt);
@@ -255,8 +268,9 @@ static GemmArgs base_args() {
 
 // Y[M,N] = act(X[M,K] . W[N,K]^T + b) (+R)
 static int linear_fwd(const Ctx& c, const void* X, long ldx, int wi, int bi, void* Y, long ldy, int M, int N, int K, int act,
-                      void* Z, const void* R, long ldr) {
+                      void* Z, const void* R, long ldr, Drop drop = drop_none()) {
   GemmArgs g = base_args();
+  g.drop = drop;
   g.A = X; g.lda = ldx; g.B = c.pl->pw(wi); g.ldb = K; g.C = Y; g.ldc = ldy;
   g.M = M; g.N = N; g.K = K;
   g.bias = bi >= 0 ? c.pl->pf(bi) : nullptr;
@@ -265,8 +279,9 @@ static int linear_fwd(const Ctx& c, const void* X, long ldx, int wi, int bi, voi
 }
 // dX[M,K] = act_bwd(dY[M,N] . W[N,K]) (+R)      (B operand = W stored [N (reduction)][K])
 static int linear_dgrad(const Ctx& c, const void* dY, long ldy, int wi, void* dX, long ldx, int M, int N, int K, int act,
-                        void* Z, long ldz, const void* R, long ldr, int out_mode = 0) {
+                        void* Z, long ldz, const void* R, long ldr, int out_mode = 0, Drop drop = drop_none()) {
   GemmArgs g = base_args();
+  g.drop = drop;
   g.A = dY; g.lda = ldy; g.B = c.pl->pw(wi); g.ldb = K; g.C = dX; g.ldc = ldx;
   g.M = M; g.N = K; g.K = N;
   g.act = act; g.Z = Z; g.ldz = ldz; g.R = R; g.ldr = ldr; g.out_mode = out_mode;
@@ -274,8 +289,10 @@ static int linear_dgrad(const Ctx& c, const void* dY, long ldy, int wi, void* dX
 }
 // stream-output variants: C (and the residual R) are fp32 whatever the operand dtype -- the residual stream never
 // drops to bf16 (mirrors autocast: half-precision GEMMs, fp32 residual adds and LayerNorms)
-static int linear_fwd_s(const Ctx& c, const void* X, long ldx, int wi, int bi, float* Y, int M, int N, int K, const float* R) {
+static int linear_fwd_s(const Ctx& c, const void* X, long ldx, int wi, int bi, float* Y, int M, int N, int K, const float* R,
+                        Drop drop = drop_none()) {
   GemmArgs g = base_args();
+  g.drop = drop;
   g.A = X; g.lda = ldx; g.B = c.pl->pw(wi); g.ldb = K; g.C = Y; g.ldc = N;
   g.M = M; g.N = N; g.K = K;
   g.bias = bi >= 0 ? c.pl->pf(bi) : nullptr;
@@ -283,8 +300,9 @@ static int linear_fwd_s(const Ctx& c, const void* X, long ldx, int wi, int bi, f
   return launch_gemm(c.dt, ETP_F32, 0, 0, g, 1, c.st);
 }
 static int linear_dgrad_s(const Ctx& c, const void* dY, long ldy, int wi, float* dX, int M, int N, int K, const float* R,
-                          int out_mode = 0) {
+                          int out_mode = 0, Drop drop = drop_none()) {
   GemmArgs g = base_args();
+  g.drop = drop;
   g.A = dY; g.lda = ldy; g.B = c.pl->pw(wi); g.ldb = K; g.C = dX; g.ldc = K;
   g.M = M; g.N = K; g.K = N;
   g.R = R; g.ldr = K; g.out_mode = out_mode;
@@ -316,9 +334,10 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
 static inline const void* offs(const void* p, long elems, size_t es) { return reinterpret_cast<const char*>(p) + elems * es; }
 static inline void* offs(void* p, long elems, size_t es) { return reinterpret_cast<char*>(p) + elems * es; }
 
-int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st) {
+int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   const int dh = 64;
-  if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st);
+  if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st, drop);
+  ETP_REQUIRE(drop.p == 0.f, "attention dropout is implemented in the fused kernels only (Lq, Lk <= 128; fp32: <= 64)");
   GemmArgs g = base_args();
   // S = alpha * Q K^T
   g.A = a.Q; g.lda = a.ldq; g.sAo = (long)a.Lq * a.ldq; g.sAi = dh;
@@ -337,13 +356,15 @@ int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc
 }
 
 int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
-                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st) {
+                  void* dK, long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st,
+                  Drop drop) {
   const int dh = 64;
   {
     const int epc = dt == ETP_BF16 ? 8 : 4;
     if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
-      return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st);
+      return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
   }
+  ETP_REQUIRE(drop.p == 0.f, "attention dropout is implemented in the fused kernels only (Lq, Lk <= 128; fp32: <= 64)");
   const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;
   // dP = dctx V^T
   GemmArgs g = base_args();
@@ -386,6 +407,17 @@ static Act take_act(Bump& b, int dt, long n) {
   return a;
 }
 static inline void* lp(const Act& a, int dt) { return dt == ETP_BF16 ? a.t : nullptr; }   // second kernel output (or none)
+// backward scratch: the operand copy is ALWAYS a separate buffer (under dropout it differs from the fp32 gradient)
+static Act take_act2(Bump& b, int dt, long n) {
+  Act a;
+  a.f = (float*)b.take((size_t)n * 4);
+  a.t = b.take((size_t)n * dtype_size(dt));
+  return a;
+}
+// pointer the producing kernel writes the operand copy to (NULL: fp32 mode without dropout -> the fp32 tensor is the operand)
+static inline void* lp2(const Ctx& c, const Act& a, const Drop& d) { return (c.dt == ETP_BF16 || d.p > 0.f) ? a.t : nullptr; }
+// pointer the consuming GEMMs read
+static inline const void* op2(const Ctx& c, const Act& a, const Drop& d) { return (c.dt == ETP_BF16 || d.p > 0.f) ? a.t : (void*)a.f; }
 
 // ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
 struct SelfAttStash { void *qkv, *P, *ctx; float* s; float* st; Act y; };
@@ -420,7 +452,7 @@ struct BwdWs { Act t1; void *t2, *dI, *dqkv, *dP; };
 static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
   const size_t es = dtype_size(dt);
   BwdWs w;
-  w.t1 = take_act(b, dt, M * H);
+  w.t1 = take_act2(b, dt, M * H);
   w.t2 = b.take(M * H * es);
   w.dI = b.take(M * I * es);
   w.dqkv = b.take(M * 3 * H * es);
@@ -428,48 +460,53 @@ static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, i
   return w;
 }
 
-// y = LN(dense(attn(x)) + x)
+// y = LN(dropout(dense(attn(x))) + x)
 static int self_att_fwd(const Ctx& c, const AttnP& p, const Act& x, SelfAttStash& s, int Bn, int L, const uint8_t* keymask,
-                        const float* dist, const float* sp_w, const float* sp_b, float eps) {
+                        const float* dist, const float* sp_w, const float* sp_b, float eps, int mode, int layer) {
   const int H = c.H, M = Bn * L;
   ETP_TRY(linear_fwd(c, x.t, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
-  ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st));
-  ETP_TRY(linear_fwd_s(c, s.ctx, H, p.o_w, p.o_b, s.s, M, H, H, x.f));
+  ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st, att(c, mode, layer, SITE_ATT_P)));
+  ETP_TRY(linear_fwd_s(c, s.ctx, H, p.o_w, p.o_b, s.s, M, H, H, x.f, hid(c, mode, layer, SITE_ATT_O)));
   return ln_fwd_s(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y.f, lp(s.y, c.dt), s.st, M, H, eps, c.st);
 }
 // g (fp32): in = dL/dy, out = dL/dx (same buffer)
 static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAttStash& s, int Bn, int L,
                         const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, float* d_sp_w,
-                        float* d_sp_b, float* g, const BwdWs& w) {
+                        float* d_sp_b, float* g, const BwdWs& w, int mode, int layer) {
   const int H = c.H, M = Bn * L;
   etp_planner* pl = c.pl;
-  ETP_TRY(ln_bwd_s(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp(w.t1, c.dt), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
-                   c.st));                                                                                    // t1 = ds
-  ETP_TRY(linear_wgrad(c, w.t1.t, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
-  ETP_TRY(linear_dgrad(c, w.t1.t, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));        // t2 = dctx
+  const Drop dh = hid(c, mode, layer, SITE_ATT_O);
+  ETP_TRY(ln_bwd_s(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
+                   c.st, dh));                                                          // t1.f = ds, operand copy = ds * mask
+  const void* ds = op2(c, w.t1, dh);
+  ETP_TRY(linear_wgrad(c, ds, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
+  ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t2 = dctx
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, w.t2, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
-                        offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st));
+                        offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
   return linear_dgrad_s(c, w.dqkv, 3 * H, p.qkv_w, g, M, 3 * H, H, w.t1.f);                                  // g = dx
 }
 
-static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M, float eps) {
+static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M, float eps, int mode, int layer) {
   const int H = c.H, I = c.I;
   ETP_TRY(linear_fwd(c, x.t, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU, f.z, nullptr, 0));
-  ETP_TRY(linear_fwd_s(c, f.h, I, p.o_w, p.o_b, f.s, M, H, I, x.f));
+  ETP_TRY(linear_fwd_s(c, f.h, I, p.o_w, p.o_b, f.s, M, H, I, x.f, hid(c, mode, layer, SITE_FFN_O)));
   return ln_fwd_s(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y.f, lp(f.y, c.dt), f.st, M, H, eps, c.st);
 }
-static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f, int M, float* g, const BwdWs& w) {
+static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f, int M, float* g, const BwdWs& w, int mode,
+                   int layer) {
   const int H = c.H, I = c.I;
   etp_planner* pl = c.pl;
-  ETP_TRY(ln_bwd_s(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp(w.t1, c.dt), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
-                   c.st));                                                                                    // t1 = ds
-  ETP_TRY(linear_wgrad(c, w.t1.t, H, f.h, I, p.o_w, p.o_b, M, H, I));
-  ETP_TRY(linear_dgrad(c, w.t1.t, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));        // dI = dz
+  const Drop dh = hid(c, mode, layer, SITE_FFN_O);
+  ETP_TRY(ln_bwd_s(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
+                   c.st, dh));
+  const void* ds = op2(c, w.t1, dh);
+  ETP_TRY(linear_wgrad(c, ds, H, f.h, I, p.o_w, p.o_b, M, H, I));
+  ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));            // dI = dz
   ETP_TRY(linear_wgrad(c, w.dI, I, x.t, H, p.i_w, p.i_b, M, I, H));
   return linear_dgrad_s(c, w.dI, I, p.i_w, g, M, I, H, w.t1.f);                                               // g = dx
 }
@@ -539,6 +576,19 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux) {
   p->aux = reinterpret_cast<hipStream_t>(aux);
   return ETP_OK;
 }
+int etp_planner_set_dropout(etp_planner* p, float p_hidden, float p_attn, float p_head, float p_env, uint64_t seed) {
+  ETP_REQUIRE(p && p_hidden >= 0.f && p_hidden < 1.f && p_attn >= 0.f && p_attn < 1.f && p_env >= 0.f && p_env < 1.f &&
+                  p_head >= 0.f && p_head < 1.f,
+              "dropout rates must be in [0, 1)");
+  p->p_hidden = p_hidden; p->p_attn = p_attn; p->p_env = p_env; p->p_head = p_head; p->drop_seed = seed;
+  return ETP_OK;
+}
+int etp_dropout_multipliers(float p, uint64_t seed, int mode, int layer, int slot, int64_t n, float* out_host) {
+  ETP_REQUIRE(out_host && n >= 0 && p >= 0.f && p < 1.f && mode >= 0 && layer >= 0 && slot >= 0 && slot < 16, "bad arguments");
+  const Drop d = drop_site(p, seed, (uint32_t)(mode << 16 | layer << 4 | slot));
+  for (int64_t i = 0; i < n; ++i) out_host[i] = p > 0.f ? drop_mult(d.seed, (uint32_t)i, d.p, d.inv_keep) : 1.f;
+  return ETP_OK;
+}
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream) {
   ETP_REQUIRE(p && p->P, "planner not bound");
   if (p->cfg.dtype != ETP_BF16) return ETP_OK;
@@ -570,11 +620,11 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
   const int H = c.H, M = B * L;
   const float eps = p->cfg.ln_eps;
   ETP_TRY(text_embed_fwd(c.dt, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), p->pf(p->emb_b), t.x0.f,
-                         lp(t.x0, c.dt), t.st0, B, L, H, eps, c.st));
+                         lp(t.x0, c.dt), t.st0, B, L, H, eps, c.st, hid(c, MODE_TXT, 0, SITE_EMBED)));
   Act x = t.x0;
   for (int l = 0; l < p->cfg.n_l; ++l) {
-    ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps));
-    ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps));
+    ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps, MODE_TXT, l));
+    ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps, MODE_TXT, l));
     x = t.ffn[l].y;
   }
   ETP_CHECK_HIP(hipMemcpyAsync(out, x.f, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
@@ -600,12 +650,13 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);   // same carving in every call
     BwdWs wa = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
     if (l >= layer_hi || l < layer_lo) continue;
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf));
-    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa));
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l));
+    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
   }
   if (layer_lo == 0)
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
-                           p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st));
+                           p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st,
+                           hid(c, MODE_TXT, 0, SITE_EMBED)));
   return join_wgrads(c);
 }
 int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,
@@ -630,7 +681,7 @@ PanoStash plan_pano(const etp_planner* pl, Bump& b, int Bn, int V) {
   const long M = (long)Bn * V;
   const int H = c.hidden, I = c.inter, ldS = (int)round_up(V, 8);
   PanoStash s;
-  s.rgbT = c.dtype == ETP_BF16 ? b.take(M * c.img_feat * es) : nullptr;
+  s.rgbT = b.take(M * c.img_feat * es);      // operand copy of the RGB features (bf16 cast and/or drop_env mask)
   s.depT = (c.dtype == ETP_BF16 && c.use_depth) ? b.take(M * c.dep_feat * es) : nullptr;
   s.a = b.take(M * H * es);
   s.d = c.use_depth ? b.take(M * H * es) : nullptr;
@@ -687,9 +738,9 @@ struct PanoWs { Act g; float* t1f; Act t2; void *dI, *t1, *dqkv, *dP; };
 PanoWs plan_pano_ws(Bump& b, int dt, long M, int Bn, int nh, int V, int ldS, int H, int I) {
   const size_t es = dtype_size(dt);
   PanoWs w;
-  w.g = take_act(b, dt, M * H);          // dx of this layer (fp32 stream + operand copy: it feeds a weight gradient)
+  w.g = take_act2(b, dt, M * H);         // dx of this layer (fp32 stream + operand copy: it feeds a weight gradient)
   w.t1f = (float*)b.take(M * H * 4);
-  w.t2 = take_act(b, dt, M * H);
+  w.t2 = take_act2(b, dt, M * H);
   w.dI = b.take(M * I * es);
   w.t1 = b.take(M * H * es);
   w.dqkv = b.take(M * 3 * H * es);
@@ -724,16 +775,17 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
   hipLaunchKernelGGL(seq_mask_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, view_lens, s.mask, out_mask, B, V);
   ETP_CHECK_LAUNCH("seq_mask");
   const void* rgbT = rgb; const void* depT = dep;
-  if (c.dt == ETP_BF16) {
-    ETP_TRY(cast_f32_to_bf16(rgb, s.rgbT, (long)M * cf.img_feat, c.st));
+  const Drop denv = site(c, p->p_env, MODE_PANO, 0, SITE_ENV);     // Policy_ViewSelection_ETP.py:102,345 (drop_env on the RGB features)
+  if (c.dt == ETP_BF16 || denv.p > 0.f) {
+    ETP_TRY(cast_drop(c.dt, rgb, s.rgbT, (long)M * cf.img_feat, denv, c.st));
     rgbT = s.rgbT;
-    if (cf.use_depth) { ETP_TRY(cast_f32_to_bf16(dep, s.depT, (long)M * cf.dep_feat, c.st)); depT = s.depT; }
   }
+  if (c.dt == ETP_BF16 && cf.use_depth) { ETP_TRY(cast_f32_to_bf16(dep, s.depT, (long)M * cf.dep_feat, c.st)); depT = s.depT; }
   ETP_TRY(linear_fwd(c, rgbT, cf.img_feat, p->img_w, p->img_b, s.a, H, M, H, cf.img_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
   if (cf.use_depth)
     ETP_TRY(linear_fwd(c, depT, cf.dep_feat, p->dep_w, p->dep_b, s.d, H, M, H, cf.dep_feat, ETP_ACT_NONE, nullptr, nullptr, 0));
   float* x0 = cf.n_p == 0 ? out : s.x0;
-  ETP_TRY(pano_embed_fwd(c.dt, s.a, s.d, loc, nav, pano_params(p), x0, s.est, M, H, c.st));
+  ETP_TRY(pano_embed_fwd(c.dt, s.a, s.d, loc, nav, pano_params(p), x0, s.est, M, H, c.st, hid(c, MODE_PANO, 0, SITE_EMBED)));
   const float* x = x0;
   for (int l = 0; l < cf.n_p; ++l) {   // TransformerEncoderLayer.forward_pre common/transformer.py:170-182
     const PanoLayerP& q = p->pano[l];
@@ -743,12 +795,12 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
     ETP_TRY(linear_fwd(c, t.a, H, q.in_w, q.in_b, t.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
-    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st));
-    ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x));
+    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));   // MHA dropout = hidden rate
+    ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x, hid(c, MODE_PANO, l, SITE_ATT_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), c.dt == ETP_BF16 ? nullptr : (float*)t.f,
                      c.dt == ETP_BF16 ? t.f : nullptr, t.st2, M, H, 1e-5f, c.st));
-    ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU, t.z, nullptr, 0));
-    ETP_TRY(linear_fwd_s(c, t.h, I, q.l2_w, q.l2_b, t.x2, M, H, I, t.x1));
+    ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU, t.z, nullptr, 0, hid(c, MODE_PANO, l, SITE_FFN_I)));
+    ETP_TRY(linear_fwd_s(c, t.h, I, q.l2_w, q.l2_b, t.x2, M, H, I, t.x1, hid(c, MODE_PANO, l, SITE_FFN_O)));
     x = t.x2;
   }
   if (cf.n_p > 0) ETP_TRY(ln_fwd_s(c.dt, x, p->pf(p->pn_g), p->pf(p->pn_b), out, nullptr, s.stn, M, H, 1e-12f, c.st));
@@ -766,10 +818,12 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   Bump wb(ws);
   PanoWs w0 = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
   Act g = w0.g;
+  Drop gd = drop_none();
   if (cf.n_p > 0) {
     const float* xin = s.layers[cf.n_p - 1].x2;
-    ETP_TRY(ln_bwd_s(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g.f, lp(g, c.dt), p->gf(p->pn_g), p->gf(p->pn_b), M, H,
-                     c.st));
+    gd = hid(c, MODE_PANO, cf.n_p - 1, SITE_FFN_O);      // g's operand copy carries the mask of the layer that consumes it
+    ETP_TRY(ln_bwd_s(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g.f, lp2(c, g, gd), p->gf(p->pn_g), p->gf(p->pn_b), M, H,
+                     c.st, gd));
   } else {
     ETP_CHECK_HIP(hipMemcpyAsync(g.f, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
   }
@@ -779,33 +833,40 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     const float* x = l == 0 ? s.x0 : s.layers[l - 1].x2;
     PanoWs w = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
     // FFN: x2 = x1 + W2 gelu(W1 LN2(x1))
-    ETP_TRY(linear_wgrad(c, g.t, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
-    ETP_TRY(linear_dgrad(c, g.t, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0));
+    const void* gop = op2(c, g, gd);                                                                              // dx2 * mask(dropout2)
+    ETP_TRY(linear_wgrad(c, gop, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
+    ETP_TRY(linear_dgrad(c, gop, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0, 0,
+                         hid(c, MODE_PANO, l, SITE_FFN_I)));
     ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
     ETP_TRY(linear_dgrad_s(c, w.dI, I, q.l1_w, w.t1f, M, I, H, nullptr));                                         // t1f = df
-    ETP_TRY(ln_bwd_s(c.dt, w.t1f, t.x1, t.st2, p->pf(q.n2_g), g.f, w.t2.f, lp(w.t2, c.dt), p->gf(q.n2_g), p->gf(q.n2_b), M, H,
-                     c.st));                                                                                        // t2 = dx1
-    // attention: x1 = x + Wo attn(LN1(x))
-    ETP_TRY(linear_wgrad(c, w.t2.t, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
-    ETP_TRY(linear_dgrad(c, w.t2.t, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));         // t1 = dctx
+    const Drop d1 = hid(c, MODE_PANO, l, SITE_ATT_O);
+    ETP_TRY(ln_bwd_s(c.dt, w.t1f, t.x1, t.st2, p->pf(q.n2_g), g.f, w.t2.f, lp2(c, w.t2, d1), p->gf(q.n2_g), p->gf(q.n2_b), M, H,
+                     c.st, d1));                                                                                    // t2 = dx1
+    // attention: x1 = x + dropout1(Wo attn(LN1(x)))
+    const void* t2op = op2(c, w.t2, d1);
+    ETP_TRY(linear_wgrad(c, t2op, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
+    ETP_TRY(linear_dgrad(c, t2op, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
-                          offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st));
+                          offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
     ETP_TRY(linear_dgrad_s(c, w.dqkv, 3 * H, q.in_w, w.t1f, M, 3 * H, H, nullptr));                               // t1f = da
-    ETP_TRY(ln_bwd_s(c.dt, w.t1f, x, t.st1, p->pf(q.n1_g), w.t2.f, w.g.f, lp(w.g, c.dt), p->gf(q.n1_g), p->gf(q.n1_b), M, H,
-                     c.st));                                                                                        // dx
+    gd = l > 0 ? hid(c, MODE_PANO, l - 1, SITE_FFN_O) : drop_none();
+    ETP_TRY(ln_bwd_s(c.dt, w.t1f, x, t.st1, p->pf(q.n1_g), w.t2.f, w.g.f, l > 0 ? lp2(c, w.g, gd) : nullptr, p->gf(q.n1_g),
+                     p->gf(q.n1_b), M, H, c.st, gd));                                                               // dx
     g = w.g;
   }
   // embedding fuse backward -> da (t1), dd (dI reused as [M,H])
   PanoWs w = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
-  ETP_TRY(pano_embed_bwd(c.dt, g.f, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, w.dI, M, H, c.st));
-  const void* rgbT = c.dt == ETP_BF16 ? s.rgbT : (const void*)rgb;
+  ETP_TRY(pano_embed_bwd(c.dt, g.f, s.a, s.d, loc, nav, s.est, pano_params(p), pano_grads(p), w.t1, w.dI, M, H, c.st,
+                         hid(c, MODE_PANO, 0, SITE_EMBED)));
+  const Drop denv = site(c, p->p_env, MODE_PANO, 0, SITE_ENV);
+  const void* rgbT = (c.dt == ETP_BF16 || denv.p > 0.f) ? s.rgbT : (const void*)rgb;
   const void* depT = c.dt == ETP_BF16 ? s.depT : (const void*)dep;
   ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
   if (cf.use_depth) ETP_TRY(linear_wgrad(c, w.dI, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
-  if (d_rgb) ETP_TRY(linear_dgrad_s(c, w.t1, H, p->img_w, d_rgb, M, H, cf.img_feat, nullptr));
+  if (d_rgb) ETP_TRY(linear_dgrad_s(c, w.t1, H, p->img_w, d_rgb, M, H, cf.img_feat, nullptr, 0, denv));
   return join_wgrads(c);
 }
 
@@ -913,20 +974,20 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
-    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st));
-    ETP_TRY(linear_fwd_s(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, Mg, H, H, x.f));
+    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st, att(c, MODE_NAV, l, SITE_X_P)));
+    ETP_TRY(linear_fwd_s(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, Mg, H, H, x.f, hid(c, MODE_NAV, l, SITE_X_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y.f, lp(t.cross.y, c.dt), t.cross.st, Mg, H, eps,
                      c.st));
     // graph self attention with the pairwise-distance bias (:391-393)
-    ETP_TRY(self_att_fwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, eps));
-    ETP_TRY(ffn_fwd(c, q.ffn, t.self.y, t.ffn, Mg, eps));
+    ETP_TRY(self_att_fwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, eps, MODE_NAV, l));
+    ETP_TRY(ffn_fwd(c, q.ffn, t.self.y, t.ffn, Mg, eps, MODE_NAV, l));
     x = t.ffn.y;
   }
   ETP_CHECK_HIP(hipMemcpyAsync(out_embeds, x.f, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   // SAP head: Linear -> ReLU (GEMM epilogue) -> LN -> Linear(H->1) -> masks
   ETP_TRY(linear_fwd(c, x.t, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
   return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
-                      out_logits, s.str, Mg, H, c.st);
+                      out_logits, s.str, Mg, H, c.st, site(c, p->p_head, MODE_NAV, 0, SITE_HEAD));
 }
 
 int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, const float* txt, const uint8_t* txt_mask,
@@ -951,7 +1012,8 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
   float* g = n.g;
   if (d_logits) {
     ETP_TRY(sap_tail_bwd(c.dt, d_logits, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), s.str, visited, gmask,
-                         n.head.t2, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st));
+                         n.head.t2, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st,
+                         site(c, p->p_head, MODE_NAV, 0, SITE_HEAD)));
     ETP_TRY(linear_wgrad(c, n.head.t2, H, xlast.t, H, p->sap0_w, p->sap0_b, Mg, H, H));
     ETP_TRY(linear_dgrad_s(c, n.head.t2, H, p->sap0_w, g, Mg, H, H, d_embeds));
   } else {
@@ -964,18 +1026,20 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
     const Act x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
     const NavCrossWs& xc = n.cross[l];
     const BwdWs& w = xc.w;
-    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, n.ffn[l]));
+    ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, n.ffn[l], MODE_NAV, l));
     ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, g,
-                         n.self[l]));
+                         n.self[l], MODE_NAV, l));
     // cross attention backward
-    ETP_TRY(ln_bwd_s(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1.f, lp(w.t1, c.dt), p->gf(q.xln_g),
-                     p->gf(q.xln_b), Mg, H, c.st));
-    ETP_TRY(linear_wgrad(c, w.t1.t, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, w.t1.t, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+    const Drop dx = hid(c, MODE_NAV, l, SITE_X_O);
+    ETP_TRY(ln_bwd_s(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1.f, lp2(c, w.t1, dx), p->gf(q.xln_g),
+                     p->gf(q.xln_b), Mg, H, c.st, dx));
+    const void* dso = op2(c, w.t1, dx);
+    ETP_TRY(linear_wgrad(c, dso, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
+    ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, xc.dkv, 2L * H, offs(xc.dkv, H, c.es), 2L * H,
-                          0.125f, nullptr, nullptr, c.st));
+                          0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, g, Mg, H, H, w.t1.f));
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));

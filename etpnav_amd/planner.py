@@ -131,6 +131,13 @@ class Engine:
             check(self.L.etp_planner_refresh_weights(self.handle, self.stream()), "refresh_weights")
             self._shadow_version = self.params._version
 
+    def set_dropout(self, drop):
+        """drop = None (eval) or (p_hidden, p_attn, p_head, p_env, seed); read by the next enqueued entry points."""
+        if drop is None:
+            drop = (0.0, 0.0, 0.0, 0.0, 0)
+        ph, pa, pd, pe, seed = drop
+        check(self.L.etp_planner_set_dropout(self.handle, ph, pa, pd, pe, seed), "set_dropout")
+
     def buf(self, nbytes: int) -> torch.Tensor:
         return torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
 
@@ -145,11 +152,13 @@ class Engine:
 # ---- autograd bridges ------------------------------------------------------------------------
 class _TxtFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, eng: Engine, txt_ids, txt_masks):
+    def forward(ctx, anchor, eng: Engine, drop, txt_ids, txt_masks):
         B, L = txt_ids.shape
         H = eng.cconf.hidden
         out = torch.empty(B, L, H, dtype=torch.float32, device=eng.device)
         stash = eng.buf(eng.L.etp_txt_stash_bytes(eng.handle, B, L))
+        eng.set_dropout(drop)
+        ctx.drop = drop
         check(eng.L.etp_txt_fwd(eng.handle, ptr(txt_ids), ptr(txt_masks), B, L, ptr(out), ptr(stash), eng.stream()),
               "etp_txt_fwd")
         ctx.eng, ctx.stash, ctx.dims = eng, stash, (B, L)
@@ -162,16 +171,19 @@ class _TxtFn(torch.autograd.Function):
         txt_ids, txt_masks = ctx.saved_tensors
         dout = dout.float().contiguous()
         ws = eng.ws(("txt", B, L), eng.L.etp_txt_ws_bytes(eng.handle, B, L))
+        eng.set_dropout(ctx.drop)
         check(eng.L.etp_txt_bwd(eng.handle, ptr(dout), ptr(txt_ids), ptr(txt_masks), B, L, ptr(ctx.stash), ptr(ws),
                                 eng.stream()), "etp_txt_bwd")
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class _PanoFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, eng: Engine, rgb, dep, loc, nav_types, view_lens):
+    def forward(ctx, anchor, eng: Engine, drop, rgb, dep, loc, nav_types, view_lens):
         B, V, _ = rgb.shape
         H = eng.cconf.hidden
+        eng.set_dropout(drop)
+        ctx.drop = drop
         out = torch.empty(B, V, H, dtype=torch.float32, device=eng.device)
         masks = torch.empty(B, V, dtype=torch.bool, device=eng.device)
         stash = eng.buf(eng.L.etp_pano_stash_bytes(eng.handle, B, V))
@@ -190,15 +202,18 @@ class _PanoFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         d_rgb = torch.empty(B, V, eng.cconf.img_feat, dtype=torch.float32, device=eng.device) if ctx.need_rgb_grad else None
         ws = eng.ws(("pano", B, V), eng.L.etp_pano_ws_bytes(eng.handle, B, V))
+        eng.set_dropout(ctx.drop)
         check(eng.L.etp_pano_bwd(eng.handle, ptr(dout), ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), B, V, ptr(d_rgb),
                                  ptr(ctx.stash), ptr(ws), eng.stream()), "etp_pano_bwd")
-        return None, None, d_rgb, None, None, None, None
+        return None, None, None, d_rgb, None, None, None, None
 
 
 class _NavFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, eng: Engine, txt_embeds, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
+    def forward(ctx, anchor, eng: Engine, drop, txt_embeds, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
         B, L, H = txt_embeds.shape
+        eng.set_dropout(drop)
+        ctx.drop = drop
         G = step_ids.shape[1]
         out = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         logits = torch.empty(B, G, dtype=torch.float32, device=eng.device)
@@ -220,10 +235,11 @@ class _NavFn(torch.autograd.Function):
         d_txt = torch.empty(B, L, H, dtype=torch.float32, device=eng.device)
         d_img = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         ws = eng.ws(("nav", B, L, G), eng.L.etp_nav_ws_bytes(eng.handle, B, L, G))
+        eng.set_dropout(ctx.drop)
         check(eng.L.etp_nav_bwd(eng.handle, ptr(d_out), ptr(d_logits), ptr(txt_embeds), ptr(txt_masks),
                                 ptr(step_ids), ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_txt),
                                 ptr(d_img), ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd")
-        return None, None, d_txt, None, None, d_img, None, None, None, None
+        return None, None, None, d_txt, None, None, d_img, None, None, None, None
 
 
 class GlocalTextPathNavCMT(nn.Module):
@@ -248,6 +264,29 @@ class GlocalTextPathNavCMT(nn.Module):
                 if k.startswith("img_embeddings."):
                     v.requires_grad = False
         self._anchor = torch.zeros(1, device=self._engine.device, requires_grad=True)
+        # training-mode dropout (nn.Module.training, as the reference's nn.Dropout layers): rates from the config,
+        # masks from a counter-based generator keyed by (seed, call counter, site, element)
+        self.drop_env_prob = 0.0          # >0 fuses the policy's drop_env (Policy_ViewSelection_ETP.py:102,345) into forward_panorama
+        self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFF
+        self._drop_calls = 0
+
+    def seed_dropout(self, seed: int):
+        """Restart the dropout mask stream (deterministic training runs, tests)."""
+        self._drop_seed = int(seed) & 0xFFFFFFFF
+        self._drop_calls = 0
+
+    def _dropout(self):
+        if not self.training:
+            return None
+        c = self.config
+        ph = float(_cfg_get(c, "hidden_dropout_prob", 0.1))
+        pa = float(_cfg_get(c, "attention_probs_dropout_prob", 0.1))
+        pd = float(_cfg_get(c, "pred_head_dropout_prob", 0.1))
+        pe = float(self.drop_env_prob)
+        if ph == 0.0 and pa == 0.0 and pd == 0.0 and pe == 0.0:
+            return None
+        self._drop_calls += 1
+        return (ph, pa, pd, pe, (self._drop_seed << 32) | (self._drop_calls & 0xFFFFFFFF))
 
     # ---- parameter tree over the flat arena ---------------------------------------------------
     def _build_tree(self):
@@ -351,7 +390,7 @@ class GlocalTextPathNavCMT(nn.Module):
     def forward_txt(self, txt_ids, txt_masks):
         """vilmodel_cmt.py:684-688.  txt_ids [B,L] int64, txt_masks [B,L] bool -> [B,L,H]."""
         eng = self._prep()
-        out = _TxtFn.apply(self._anchor, eng, txt_ids.contiguous(), txt_masks.to(torch.bool).contiguous())
+        out = _TxtFn.apply(self._anchor, eng, self._dropout(), txt_ids.contiguous(), txt_masks.to(torch.bool).contiguous())
         if _cfg_get(self.config, "fix_lang_embedding", False):
             out = out.detach()   # LanguageEncoder.forward :431-432
         return out
@@ -360,7 +399,7 @@ class GlocalTextPathNavCMT(nn.Module):
         """vilmodel_cmt.py:690-719 -> (pano_embeds [B,V,H], pano_masks [B,V] bool)."""
         eng = self._prep()
         dep = dep_fts.float().contiguous() if dep_fts is not None else None
-        return _PanoFn.apply(self._anchor, eng, rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
+        return _PanoFn.apply(self._anchor, eng, self._dropout(), rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
                              nav_types.long().contiguous(), view_lens.long().contiguous())
 
     def forward_navigation(self, txt_embeds, txt_masks, gmap_vpids, gmap_step_ids, gmap_img_fts, gmap_pos_fts,
@@ -369,7 +408,7 @@ class GlocalTextPathNavCMT(nn.Module):
         eng = self._prep()
         t = torch.float32
         dists = gmap_pair_dists.float().contiguous() if gmap_pair_dists is not None else None
-        embeds, logits = _NavFn.apply(self._anchor, eng, txt_embeds.to(t).contiguous(),
+        embeds, logits = _NavFn.apply(self._anchor, eng, self._dropout(), txt_embeds.to(t).contiguous(),
                                       txt_masks.to(torch.bool).contiguous(), gmap_step_ids.long().contiguous(),
                                       gmap_img_fts.to(t).contiguous(), gmap_pos_fts.float().contiguous(),
                                       gmap_masks.to(torch.bool).contiguous(),

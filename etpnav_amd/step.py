@@ -50,8 +50,18 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
 
 
 class PlannerStep:
-    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True):
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True,
+                 dropout=None, drop_seed: int = 0):
+        """dropout: None (eval-mode step), "config" (the model config's rates, the reference's policy.train()), or a
+        tuple (p_hidden, p_attn, p_head, p_env)."""
         self.model = model
+        if dropout == "config":
+            c = model.config
+            dropout = (float(getattr(c, "hidden_dropout_prob", 0.1)), float(getattr(c, "attention_probs_dropout_prob", 0.1)),
+                       float(getattr(c, "pred_head_dropout_prob", 0.1)), float(model.drop_env_prob))
+        self.dropout = dropout
+        self.drop_seed = int(drop_seed) & 0xFFFFFFFF
+        self.step_no = 0
         eng = self.eng = model._engine
         eng.require_gpu()
         dev = eng.device
@@ -113,6 +123,8 @@ class PlannerStep:
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
         dt = _lib.ETP_F32          # node assembly works on the fp32 API tensors
+        self.step_no += 1
+        eng.set_dropout(self._drop_state())
         check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
         if backward:
@@ -150,6 +162,7 @@ class PlannerStep:
         L, eng, i = self.L, self.eng, self.inp
         if layer_hi is None:
             layer_hi = eng.cconf.n_l
+        eng.set_dropout(self._drop_state())
         check(L.etp_txt_bwd_range(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
                                   ptr(self.st_txt), ptr(self.ws_txt), layer_lo, layer_hi, s), "txt_bwd")
         if layer_lo > 0:
@@ -158,8 +171,14 @@ class PlannerStep:
             check(L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
             self._pano_pending = False
 
+    def _drop_state(self):
+        if self.dropout is None:
+            return None
+        return tuple(self.dropout) + ((self.drop_seed << 32) | (self.step_no & 0xFFFFFFFF),)
+
     def run_eager(self, stream: Optional[int] = None, backward: bool = True):
-        """Enqueue one step on `stream` (default: torch's current stream)."""
+        """Enqueue one step on `stream` (default: torch's current stream).  With dropout on, every call draws fresh
+        masks (the step counter is part of the seed); a captured graph replays the masks it was captured with."""
         s = stream if stream is not None else self.eng.stream()
         self.enqueue_main(s, backward, join_pano=not backward)   # panorama backward overlaps the text backward
         if backward:

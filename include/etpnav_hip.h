@@ -202,6 +202,25 @@ int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads);
  * on `aux` after their dY producer and joined back before the call returns to `stream`, so they overlap the dgrad
  * chain (works eagerly and under hipGraph capture: the fork/join become graph edges).  NULL = single stream. */
 int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
+/* Training-mode dropout (all rates 0 = eval, the default).  Masks are a counter-based hash of (seed, site, element index):
+ * nothing is stored, the backward entry points recompute the masks, so a backward call must see the same rates and seed as
+ * its forward (the state is read at enqueue time; change it between calls freely).  Sites mirror the reference:
+ *   p_hidden  nn.Dropout(hidden_dropout_prob): BertEmbeddings vilmodel_cmt.py:76, BertSelfOutput :152, BertOutput :191,
+ *             BertXAttention output :363 (BertSelfOutput), panorama embedding :711, and the panorama
+ *             TransformerEncoderLayer's dropout/dropout1/dropout2 + its MultiheadAttention dropout (common/ops.py:15,
+ *             common/transformer.py:138-147,178-181);
+ *   p_attn    attention_probs_dropout_prob on softmax probabilities (:127 self, :346 cross);
+ *   p_head    ClsPrediction dropout (:657, pred_head_dropout_prob);
+ *   p_env     the policy's drop_env on the RGB features (Policy_ViewSelection_ETP.py:102,345) fused into the operand
+ *             cast of forward_panorama (0 = leave it to the caller, as the reference does).
+ * Needs the fused attention kernels (Lq, Lk <= 128; fp32 mode <= 64): the unfused fallback returns an error. */
+int etp_planner_set_dropout(etp_planner* p, float p_hidden, float p_attn, float p_head, float p_env, uint64_t seed);
+/* Host-side view of the mask generator (tests, debugging): out_host[i] = multiplier (0 or 1/(1-p)) of element i (row-major
+ * index into the site's tensor) at site (mode 1=txt 2=panorama 3=navigation, layer, slot) for step seed `seed`.  Slots:
+ * 0 embedding output, 1 self-attention probabilities, 2 attention-output dense, 3 FFN-output dense, 4 FFN inner
+ * (panorama layers), 5 cross-attention probabilities, 6 cross-attention-output dense, 7 SAP head, 8 drop_env.
+ * Needs no GPU. */
+int etp_dropout_multipliers(float p, uint64_t seed, int mode, int layer, int slot, int64_t n, float* out_host);
 /* bf16 mode: refresh the bf16 shadow of the GEMM weights from the fp32 masters (autocast's per-step weight cast). */
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
 

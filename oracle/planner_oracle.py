@@ -197,6 +197,66 @@ def init_params(cfg: PlannerConfig, seed: int = 0, dtype=torch.float32,
 
 
 # --------------------------------------------------------------------------
+# training-mode dropout with reproducible masks.  The reference draws its masks from torch's RNG (nn.Dropout), which no
+# other implementation can reproduce bit-for-bit; what parity CAN pin is where dropout sits and how it scales.  The oracle
+# therefore applies dropout at exactly the reference's sites (cited at each call below) with masks from the documented
+# counter-based generator of include/etpnav_hip.h (etp_planner_set_dropout): keep element i of a site iff
+# (mix(seed_site, i) >> 8) / 2^24 >= p, scaled by 1/(1-p) -- the same convention as nn.Dropout (Bernoulli(1-p) / (1-p)).
+# --------------------------------------------------------------------------
+import numpy as _np
+
+MODE_TXT, MODE_PANO, MODE_NAV = 1, 2, 3
+SITE_EMBED, SITE_ATT_P, SITE_ATT_O, SITE_FFN_O, SITE_FFN_I, SITE_X_P, SITE_X_O, SITE_HEAD, SITE_ENV = range(9)
+
+
+def _mix(seed, idx):
+    """uint32 avalanche of (seed, idx); numpy uint32 arithmetic wraps like the device code."""
+    with _np.errstate(over="ignore"):
+        seed = _np.uint32(seed)
+        x = idx.astype(_np.uint32) * _np.uint32(0x9E3779B1) + seed
+        x ^= x >> _np.uint32(16); x *= _np.uint32(0x85EBCA6B); x ^= x >> _np.uint32(13); x *= _np.uint32(0xC2B2AE35)
+        x ^= x >> _np.uint32(16)
+        x += seed * _np.uint32(0x27D4EB2F); x ^= x >> _np.uint32(15); x *= _np.uint32(0x2C1B3C6D); x ^= x >> _np.uint32(12)
+    return x
+
+
+class DropSpec:
+    """Rates + step seed of one planner call (mirrors etp_planner_set_dropout)."""
+
+    def __init__(self, p_hidden=0.1, p_attn=0.1, p_head=0.1, p_env=0.0, seed=0):
+        self.p_hidden, self.p_attn, self.p_head, self.p_env, self.seed = p_hidden, p_attn, p_head, p_env, int(seed)
+
+    def site_seed(self, mode, layer, slot):
+        site = (mode << 16) | (layer << 4) | slot
+        s = self.seed & 0xFFFFFFFFFFFFFFFF
+        lo = (s ^ (s >> 32)) & 0xFFFFFFFF
+        with _np.errstate(over="ignore"):
+            a = _np.uint32(lo) * _np.uint32(0x9E3779B1) + _np.uint32(0x7F4A7C15)
+            b = _np.array([site], dtype=_np.uint32) * _np.uint32(0x632BE5AB) + _np.uint32(17)
+        return int(_mix(a, b)[0])
+
+    def mult(self, p, mode, layer, slot, shape, dtype=torch.float32):
+        """Multiplier tensor (0 or 1/(1-p)) for a site whose tensor is `shape`, indexed row-major."""
+        if p <= 0.0:
+            return None
+        n = 1
+        for d in shape:
+            n *= int(d)
+        h = _mix(self.site_seed(mode, layer, slot), _np.arange(n, dtype=_np.uint32))
+        u = (h >> _np.uint32(8)).astype(_np.float32) * _np.float32(1.0 / 16777216.0)
+        inv = _np.float32(1.0) / (_np.float32(1.0) - _np.float32(p))
+        m = _np.where(u >= _np.float32(p), inv, _np.float32(0.0)).astype(_np.float32)
+        return torch.from_numpy(m).view(*shape).to(dtype)
+
+
+def _drop(x: Tensor, drop, p_name: str, mode: int, layer: int, slot: int) -> Tensor:
+    if drop is None:
+        return x
+    m = drop.mult(getattr(drop, p_name), mode, layer, slot, x.shape, x.dtype)
+    return x if m is None else x * m
+
+
+# --------------------------------------------------------------------------
 # building blocks (SURVEY.md Appendix A)
 # --------------------------------------------------------------------------
 def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
@@ -239,43 +299,50 @@ def _merge_heads(x: Tensor) -> Tensor:
     return x.permute(0, 2, 1, 3).reshape(n, t, nh * d)
 
 
-def bert_attention_core(q: Tensor, k: Tensor, v: Tensor, add_mask: Tensor, nh: int) -> Tensor:
-    """vilmodel_cmt.py:112-137 / :330-351: softmax(QK^T/sqrt(d) + mask) V."""
+def bert_attention_core(q: Tensor, k: Tensor, v: Tensor, add_mask: Tensor, nh: int, drop=None, site=None) -> Tensor:
+    """vilmodel_cmt.py:112-137 / :330-351: softmax(QK^T/sqrt(d) + mask) V; training: dropout on the
+    probabilities (:127 / :346)."""
     qh, kh, vh = _split_heads(q, nh), _split_heads(k, nh), _split_heads(v, nh)
     scores = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
     scores = scores + add_mask
     probs = torch.softmax(scores, dim=-1)
+    if drop is not None:
+        probs = _drop(probs.contiguous(), drop, "p_attn", *site)
     return _merge_heads(probs @ vh)
 
 
-def bert_self_attention_block(P, p: str, x: Tensor, add_mask: Tensor, cfg: PlannerConfig) -> Tensor:
+def bert_self_attention_block(P, p: str, x: Tensor, add_mask: Tensor, cfg: PlannerConfig, drop=None, mode=0,
+                              layer=0) -> Tensor:
     """BertAttention (vilmodel_cmt.py:156-166) = BertSelfAttention :103-141 +
     BertSelfOutput :150-154 (post-LN)."""
     q = linear(x, P[f"{p}.self.query.weight"], P[f"{p}.self.query.bias"])
     k = linear(x, P[f"{p}.self.key.weight"], P[f"{p}.self.key.bias"])
     v = linear(x, P[f"{p}.self.value.weight"], P[f"{p}.self.value.bias"])
-    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads)
+    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads, drop, (mode, layer, SITE_ATT_P))
     o = linear(ctx, P[f"{p}.output.dense.weight"], P[f"{p}.output.dense.bias"])
+    o = _drop(o, drop, "p_hidden", mode, layer, SITE_ATT_O)                      # BertSelfOutput :152
     return layer_norm(o + x, P[f"{p}.output.LayerNorm.weight"], P[f"{p}.output.LayerNorm.bias"],
                       cfg.layer_norm_eps)
 
 
-def bert_ffn_block(P, pi: str, po: str, x: Tensor, cfg: PlannerConfig) -> Tensor:
+def bert_ffn_block(P, pi: str, po: str, x: Tensor, cfg: PlannerConfig, drop=None, mode=0, layer=0) -> Tensor:
     """BertIntermediate :177-180 + BertOutput :189-193."""
     h = gelu_erf(linear(x, P[f"{pi}.dense.weight"], P[f"{pi}.dense.bias"]))
     o = linear(h, P[f"{po}.dense.weight"], P[f"{po}.dense.bias"])
+    o = _drop(o, drop, "p_hidden", mode, layer, SITE_FFN_O)                      # BertOutput :191
     return layer_norm(o + x, P[f"{po}.LayerNorm.weight"], P[f"{po}.LayerNorm.bias"],
                       cfg.layer_norm_eps)
 
 
 def cross_attention_block(P, p: str, x: Tensor, ctx_in: Tensor, add_mask: Tensor,
-                          cfg: PlannerConfig) -> Tensor:
+                          cfg: PlannerConfig, drop=None, mode=0, layer=0) -> Tensor:
     """BertXAttention :360-363 = BertOutAttention :325-352 + BertSelfOutput."""
     q = linear(x, P[f"{p}.att.query.weight"], P[f"{p}.att.query.bias"])
     k = linear(ctx_in, P[f"{p}.att.key.weight"], P[f"{p}.att.key.bias"])
     v = linear(ctx_in, P[f"{p}.att.value.weight"], P[f"{p}.att.value.bias"])
-    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads)
+    ctx = bert_attention_core(q, k, v, add_mask, cfg.num_attention_heads, drop, (mode, layer, SITE_X_P))
     o = linear(ctx, P[f"{p}.output.dense.weight"], P[f"{p}.output.dense.bias"])
+    o = _drop(o, drop, "p_hidden", mode, layer, SITE_X_O)                        # BertSelfOutput :152 via BertXAttention :363
     return layer_norm(o + x, P[f"{p}.output.LayerNorm.weight"], P[f"{p}.output.LayerNorm.bias"],
                       cfg.layer_norm_eps)
 
@@ -283,9 +350,9 @@ def cross_attention_block(P, p: str, x: Tensor, ctx_in: Tensor, add_mask: Tensor
 # --------------------------------------------------------------------------
 # the three planner entry points
 # --------------------------------------------------------------------------
-def forward_txt(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor) -> Tensor:
+def forward_txt(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor, drop=None) -> Tensor:
     """GlocalTextPathNavCMT.forward_txt vilmodel_cmt.py:684-688 =
-    BertEmbeddings :62-77 (eval: dropout off) + LanguageEncoder :426-433."""
+    BertEmbeddings :62-77 + LanguageEncoder :426-433.  drop=None is eval mode."""
     dt = P["embeddings.LayerNorm.weight"].dtype
     L = txt_ids.shape[1]
     e = (P["embeddings.word_embeddings.weight"][txt_ids]
@@ -293,15 +360,16 @@ def forward_txt(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor) -> Te
          + P["embeddings.token_type_embeddings.weight"][0][None, None])
     x = layer_norm(e, P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"],
                    cfg.layer_norm_eps)
+    x = _drop(x, drop, "p_hidden", MODE_TXT, 0, SITE_EMBED)                      # :76
     m = extend_neg_masks(txt_masks, dt)
     for l in range(cfg.num_l_layers):
         p = f"lang_encoder.layer.{l}"
-        x = bert_self_attention_block(P, f"{p}.attention", x, m, cfg)
-        x = bert_ffn_block(P, f"{p}.intermediate", f"{p}.output", x, cfg)
+        x = bert_self_attention_block(P, f"{p}.attention", x, m, cfg, drop, MODE_TXT, l)
+        x = bert_ffn_block(P, f"{p}.intermediate", f"{p}.output", x, cfg, drop, MODE_TXT, l)
     return x
 
 
-def pano_encoder_layer(P, p: str, x: Tensor, key_valid: Tensor, cfg: PlannerConfig) -> Tensor:
+def pano_encoder_layer(P, p: str, x: Tensor, key_valid: Tensor, cfg: PlannerConfig, drop=None, layer=0) -> Tensor:
     """TransformerEncoderLayer.forward_pre common/transformer.py:170-182 with
     nn.MultiheadAttention math spelt out: packed in_proj [3H,H], q scaled by
     1/sqrt(d), padded keys -> -inf.  norm1/norm2 use eps=1e-5 (:144-145).
@@ -314,17 +382,26 @@ def pano_encoder_layer(P, p: str, x: Tensor, key_valid: Tensor, cfg: PlannerConf
     qh, kh, vh = _split_heads(q, nh), _split_heads(k, nh), _split_heads(v, nh)
     scores = (qh / math.sqrt(H // nh)) @ kh.transpose(-1, -2)
     scores = scores.masked_fill(~key_valid[:, None, None, :], float("-inf"))
-    ctx = _merge_heads(torch.softmax(scores, -1) @ vh)
-    x = x + linear(ctx, P[f"{p}.self_attn.out_proj.weight"], P[f"{p}.self_attn.out_proj.bias"])
+    probs = torch.softmax(scores, -1)
+    # training: every dropout of this layer uses hidden_dropout_prob (common/ops.py:15): the MultiheadAttention's
+    # probability dropout (transformer.py:138), dropout1 (:178), the FFN-inner dropout (:180) and dropout2 (:181)
+    probs = _drop(probs.contiguous(), drop, "p_hidden", MODE_PANO, layer, SITE_ATT_P)
+    ctx = _merge_heads(probs @ vh)
+    x = x + _drop(linear(ctx, P[f"{p}.self_attn.out_proj.weight"], P[f"{p}.self_attn.out_proj.bias"]), drop, "p_hidden",
+                  MODE_PANO, layer, SITE_ATT_O)
     f = layer_norm(x, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"], 1e-5)
     h = gelu_erf(linear(f, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"]))
-    return x + linear(h, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"])
+    h = _drop(h, drop, "p_hidden", MODE_PANO, layer, SITE_FFN_I)
+    return x + _drop(linear(h, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"]), drop, "p_hidden", MODE_PANO, layer,
+                     SITE_FFN_O)
 
 
 def forward_panorama(P, cfg: PlannerConfig, rgb_fts: Tensor, dep_fts: Tensor, loc_fts: Tensor,
-                     nav_types: Tensor, view_lens: Tensor):
-    """GlocalTextPathNavCMT.forward_panorama vilmodel_cmt.py:690-719."""
+                     nav_types: Tensor, view_lens: Tensor, drop=None):
+    """GlocalTextPathNavCMT.forward_panorama vilmodel_cmt.py:690-719.  drop.p_env > 0 additionally applies the
+    policy's drop_env to the RGB features first (Policy_ViewSelection_ETP.py:102,345)."""
     e = "img_embeddings"
+    rgb_fts = _drop(rgb_fts, drop, "p_env", MODE_PANO, 0, SITE_ENV)
     x = layer_norm(linear(rgb_fts, P[f"{e}.img_linear.weight"], P[f"{e}.img_linear.bias"]),
                    P[f"{e}.img_layer_norm.weight"], P[f"{e}.img_layer_norm.bias"], 1e-12)
     if cfg.use_depth_embedding:
@@ -336,9 +413,10 @@ def forward_panorama(P, cfg: PlannerConfig, rgb_fts: Tensor, dep_fts: Tensor, lo
          + P[f"{e}.nav_type_embedding.weight"][nav_types]
          + P["embeddings.token_type_embeddings.weight"][1][None, None])
     x = layer_norm(x, P[f"{e}.layer_norm.weight"], P[f"{e}.layer_norm.bias"], 1e-12)
+    x = _drop(x, drop, "p_hidden", MODE_PANO, 0, SITE_EMBED)                     # :711
     masks = gen_seq_masks(view_lens, rgb_fts.shape[1])
     for l in range(cfg.num_pano_layers):
-        x = pano_encoder_layer(P, f"{e}.pano_encoder.layers.{l}", x, masks, cfg)
+        x = pano_encoder_layer(P, f"{e}.pano_encoder.layers.{l}", x, masks, cfg, drop, l)
     if cfg.num_pano_layers > 0:
         x = layer_norm(x, P[f"{e}.pano_encoder.norm.weight"], P[f"{e}.pano_encoder.norm.bias"], 1e-12)
     return x, masks
@@ -346,7 +424,7 @@ def forward_panorama(P, cfg: PlannerConfig, rgb_fts: Tensor, dep_fts: Tensor, lo
 
 def forward_navigation(P, cfg: PlannerConfig, txt_embeds: Tensor, txt_masks: Tensor,
                        gmap_step_ids: Tensor, gmap_img_fts: Tensor, gmap_pos_fts: Tensor,
-                       gmap_masks: Tensor, gmap_visited_masks: Tensor, gmap_pair_dists: Tensor):
+                       gmap_masks: Tensor, gmap_visited_masks: Tensor, gmap_pair_dists: Tensor, drop=None):
     """GlocalTextPathNavCMT.forward_navigation vilmodel_cmt.py:721-750
     (gmap_vpids is ignored by the reference and omitted here)."""
     g = "global_encoder"
@@ -367,11 +445,12 @@ def forward_navigation(P, cfg: PlannerConfig, txt_embeds: Tensor, txt_masks: Ten
         self_m = img_m
     for l in range(cfg.num_x_layers):
         p = f"{g}.encoder.x_layers.{l}"
-        x = cross_attention_block(P, f"{p}.visual_attention", x, txt_embeds, txt_m, cfg)
-        x = bert_self_attention_block(P, f"{p}.visn_self_att", x, self_m, cfg)
-        x = bert_ffn_block(P, f"{p}.visn_inter", f"{p}.visn_output", x, cfg)
+        x = cross_attention_block(P, f"{p}.visual_attention", x, txt_embeds, txt_m, cfg, drop, MODE_NAV, l)
+        x = bert_self_attention_block(P, f"{p}.visn_self_att", x, self_m, cfg, drop, MODE_NAV, l)
+        x = bert_ffn_block(P, f"{p}.visn_inter", f"{p}.visn_output", x, cfg, drop, MODE_NAV, l)
     h = torch.relu(linear(x, P["global_sap_head.net.0.weight"], P["global_sap_head.net.0.bias"]))
     h = layer_norm(h, P["global_sap_head.net.2.weight"], P["global_sap_head.net.2.bias"], 1e-12)
+    h = _drop(h, drop, "p_head", MODE_NAV, 0, SITE_HEAD)                         # ClsPrediction :657
     logits = linear(h, P["global_sap_head.net.4.weight"], P["global_sap_head.net.4.bias"]).squeeze(-1)
     logits = logits.masked_fill(gmap_visited_masks, float("-inf"))            # :743
     logits = logits.masked_fill(~gmap_masks, float("-inf"))                   # :744
@@ -404,17 +483,17 @@ def assemble_gmap_img_fts(pano_embeds: Tensor, pano_masks: Tensor, view_lens: Te
     return torch.cat([torch.zeros(B, 1, H, dtype=pano_embeds.dtype), avg[:, None], views], 1)
 
 
-def planner_step(P, cfg: PlannerConfig, batch: Dict[str, Tensor], n_ghost: int = 4):
+def planner_step(P, cfg: PlannerConfig, batch: Dict[str, Tensor], n_ghost: int = 4, drop=None):
     """forward_txt -> forward_panorama -> node assembly -> forward_navigation ->
     CE(sum)/B, mirroring one rollout step of ss_trainer_ETP.py:801-892,:1055."""
-    txt = forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"])
+    txt = forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"], drop)
     pano, pmask = forward_panorama(P, cfg, batch["rgb_fts"], batch["dep_fts"], batch["loc_fts"],
-                                   batch["nav_types"], batch["view_lens"])
+                                   batch["nav_types"], batch["view_lens"], drop)
     G = batch["gmap_step_ids"].shape[1]
     gimg = assemble_gmap_img_fts(pano, pmask, batch["view_lens"], G)
     outs = forward_navigation(P, cfg, txt, batch["txt_masks"], batch["gmap_step_ids"], gimg,
                               batch["gmap_pos_fts"], batch["gmap_masks"],
-                              batch["gmap_visited_masks"], batch["gmap_pair_dists"])
+                              batch["gmap_visited_masks"], batch["gmap_pair_dists"], drop)
     B = batch["txt_ids"].shape[0]
     loss = cross_entropy_sum(outs["global_logits"], batch["labels"]) / B
     return {"txt_embeds": txt, "pano_embeds": pano, "pano_masks": pmask, "gmap_img_fts": gimg,
@@ -464,12 +543,12 @@ def make_batch(cfg: PlannerConfig, B: int, L: int, V: int, G: int, seed: int = 1
             "gmap_pair_dists": d.to(dtype), "labels": labels}
 
 
-def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4):
+def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4, drop=None):
     """Run planner_step with autograd; returns (outputs, {name: grad})."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     b = dict(batch)
     b["rgb_fts"] = batch["rgb_fts"].detach().clone().requires_grad_(True)
-    outs = planner_step(Pg, cfg, b, n_ghost)
+    outs = planner_step(Pg, cfg, b, n_ghost, drop)
     outs["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     grads["__input__.rgb_fts"] = b["rgb_fts"].grad

@@ -106,3 +106,41 @@ def test_policy_api_and_checkpoint_remap_cpu(tmp_path):
     assert m.tolist() == [[True, False, False], [True, True, True]]
     assert extend_neg_masks(m).shape == (2, 1, 1, 3) and float(extend_neg_masks(m)[0, 0, 0, 1]) == -10000.0
     assert pad_tensors_wgrad([torch.ones(2, 4), torch.ones(3, 4)]).shape == (2, 3, 4)
+
+
+def test_dropout_mask_generator_is_pinned_and_calibrated():
+    """The oracle's numpy restatement of the counter-based mask generator equals the library's host-side view of it
+    bit for bit (so GPU train-mode parity tests apply identical masks), the keep rate is 1-p, the scale is 1/(1-p),
+    sites and seeds give independent streams, and bad rates are refused."""
+    import ctypes
+    import numpy as np
+    L = _lib.lib()
+    n = 200000
+    seen = []
+    for (p, seed, mode, layer, slot) in [(0.1, 12345, 1, 3, 2), (0.4, (7 << 32) | 9, 2, 0, 8), (0.1, 0, 3, 1, 5),
+                                         (0.1, 12346, 1, 3, 2), (0.1, 12345, 1, 4, 2)]:
+        out = np.empty(n, np.float32)
+        assert L.etp_dropout_multipliers(p, seed, mode, layer, slot, n, out.ctypes.data) == 0
+        ref = po.DropSpec(seed=seed).mult(p, mode, layer, slot, (n,)).numpy()
+        assert np.array_equal(out, ref)
+        kept = out != 0
+        assert abs(kept.mean() - (1 - p)) < 4e-3
+        assert np.allclose(out[kept], np.float32(1) / (np.float32(1) - np.float32(p)))
+        seen.append(kept)
+    for i in range(len(seen)):
+        for j in range(i + 1, len(seen)):
+            if i == 1 or j == 1:
+                continue        # different p
+            agree = (seen[i] == seen[j]).mean()
+            assert abs(agree - 0.82) < 0.01, (i, j, agree)      # independent Bernoulli(0.9): 0.81 + 0.01
+    assert L.etp_dropout_multipliers(1.0, 0, 1, 0, 0, 1, np.empty(1, np.float32).ctypes.data) != 0
+    m = GlocalTextPathNavCMT(po.PlannerConfig.r2r(vocab_size=512).to_dict(), dtype=torch.float32, device="cpu")
+    assert L.etp_planner_set_dropout(m._engine.handle, 0.1, 0.1, 0.1, 0.4, 99) == 0
+    assert L.etp_planner_set_dropout(m._engine.handle, -0.1, 0.1, 0.1, 0.4, 99) != 0
+    assert L.etp_planner_set_dropout(m._engine.handle, 0.1, 1.0, 0.1, 0.4, 99) != 0
+    # nn.Module semantics: train() draws a fresh stream per call, eval() turns dropout off
+    m.train(); m.seed_dropout(3)
+    a, b = m._dropout(), m._dropout()
+    assert a[:4] == (0.1, 0.1, 0.1, 0.0) and a[4] == (3 << 32) | 1 and b[4] == (3 << 32) | 2
+    m.eval()
+    assert m._dropout() is None

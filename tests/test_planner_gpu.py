@@ -25,8 +25,8 @@ CASES = ["c1_single_episode", "ragged_small", "c2_shape_b2", "c5_g64_b2", "c4_rx
 
 def build_model(cfg, P, dtype):
     m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=dtype, device="cuda")
-    missing = m.load_state_dict({k: v for k, v in P.items()}, strict=True)
-    return m
+    m.load_state_dict({k: v for k, v in P.items()}, strict=True)
+    return m.eval()      # parity fixtures are eval-mode (the reference's dropout RNG cannot be reproduced); see the train-mode tests
 
 
 def grads_of(model):
@@ -140,3 +140,121 @@ def test_text_backward_in_layer_ranges_equals_single_call():
         step.enqueue_txt_bwd(s, lo, hi)
     torch.cuda.synchronize()
     assert (model.flat_grads - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+# ---- training mode: dropout at the reference's sites, masks from the documented counter-based generator ---------------
+RATES = (0.1, 0.1, 0.1, 0.4)     # hidden, attention-probs, SAP head (vlnbert_init.py:58), drop_env (Policy_ViewSelection_ETP.py:102)
+
+
+def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3):
+    for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
+        assert (got[k].float().cpu() - outs[k]).abs().max().item() < atol, k
+    fin = torch.isfinite(outs["global_logits"])
+    assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
+    assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < atol
+    assert abs(got["loss"].item() - outs["loss"].item()) < atol
+    for k, g in grads.items():
+        if k.startswith("__input__"):
+            continue
+        err = (mine[k] - g).abs().max().item()
+        assert err < atol + rel * g.abs().max().item(), f"{k}: {err}"
+
+
+def test_fp32_train_mode_step_matches_oracle_with_same_masks():
+    """policy.train() (ss_trainer_ETP.py:483): every dropout of the path active.  The oracle applies the same masks at
+    the reference's dropout sites, so outputs and all gradients must agree to fp32 accuracy; two steps draw different
+    masks; rates 0 reproduce eval."""
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=4)
+    batch = po.make_batch(cfg, B=3, L=21, V=12, G=9, seed=17, ragged=True)
+    model = build_model(cfg, P, torch.float32)
+    step = PlannerStep(model, batch, dropout=RATES, drop_seed=77)
+    for k in (1, 2):
+        step.run_eager()
+        got = step_outputs(step)
+        drop = po.DropSpec(*RATES, seed=(77 << 32) | k)
+        outs, grads = po.step_with_grads(P, cfg, batch, drop=drop)
+        _assert_step_matches(outs, grads, got, grads_of(model))
+        if k == 1:
+            first = got["loss"].item()
+    assert abs(first - got["loss"].item()) > 1e-4          # fresh masks every step
+    eval_outs, _ = po.step_with_grads(P, cfg, batch)
+    assert abs(eval_outs["loss"].item() - got["loss"].item()) > 1e-4
+    step.close()
+    step = PlannerStep(model, batch, dropout=(0.0, 0.0, 0.0, 0.0))
+    step.run_eager()
+    assert abs(step_outputs(step)["loss"].item() - eval_outs["loss"].item()) < 2e-4
+    step.close()
+
+
+def test_fp32_train_mode_module_api_matches_oracle():
+    """model.train() through the drop-in API + torch autograd: each entry-point call draws its own mask stream
+    (seed = (seed_dropout << 32) | call counter) and its backward recomputes the same masks."""
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=5)
+    batch = po.make_batch(cfg, B=2, L=17, V=10, G=7, seed=23, ragged=True)
+    model = build_model(cfg, P, torch.float32).train()
+    model.seed_dropout(1234)
+    b = {k: v.cuda() for k, v in batch.items()}
+    rgb = b["rgb_fts"].clone().requires_grad_(True)
+    model.zero_grad()
+    txt = model.forward_txt(b["txt_ids"], b["txt_masks"])
+    pano, pmask = model.forward_panorama(rgb, b["dep_fts"], b["loc_fts"], b["nav_types"], b["view_lens"])
+    G = b["gmap_step_ids"].shape[1]
+    m = pmask.to(pano.dtype)
+    avg = (pano * m[..., None]).sum(1) / m.sum(1, keepdim=True)
+    idx = torch.arange(G - 2, device="cuda")[None, :] % b["view_lens"][:, None]
+    views = torch.gather(pano, 1, idx[..., None].expand(-1, -1, pano.shape[-1]))
+    gimg = torch.cat([torch.zeros_like(avg[:, None]), avg[:, None], views], 1)
+    outs = model.forward_navigation(txt, b["txt_masks"], None, b["gmap_step_ids"], gimg, b["gmap_pos_fts"], b["gmap_masks"],
+                                    b["gmap_visited_masks"], b["gmap_pair_dists"])
+    loss = F.cross_entropy(outs["global_logits"], b["labels"], reduction="sum", ignore_index=-100) / b["txt_ids"].shape[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle: the three calls used call counters 1, 2, 3
+    r = (0.1, 0.1, 0.1, 0.0)          # default_config rates: hidden, attention_probs, pred_head; drop_env stays with the caller
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    ob = dict(batch)
+    ob["rgb_fts"] = batch["rgb_fts"].clone().requires_grad_(True)
+    o_txt = po.forward_txt(Pg, cfg, ob["txt_ids"], ob["txt_masks"], po.DropSpec(*r, seed=(1234 << 32) | 1))
+    o_pano, o_mask = po.forward_panorama(Pg, cfg, ob["rgb_fts"], ob["dep_fts"], ob["loc_fts"], ob["nav_types"], ob["view_lens"],
+                                         po.DropSpec(*r, seed=(1234 << 32) | 2))
+    o_gimg = po.assemble_gmap_img_fts(o_pano, o_mask, ob["view_lens"], G)
+    o = po.forward_navigation(Pg, cfg, o_txt, ob["txt_masks"], ob["gmap_step_ids"], o_gimg, ob["gmap_pos_fts"], ob["gmap_masks"],
+                              ob["gmap_visited_masks"], ob["gmap_pair_dists"], po.DropSpec(*r, seed=(1234 << 32) | 3))
+    o_loss = po.cross_entropy_sum(o["global_logits"], ob["labels"]) / ob["txt_ids"].shape[0]
+    o_loss.backward()
+    ref_outs = {"txt_embeds": o_txt.detach(), "pano_embeds": o_pano.detach(), "gmap_embeds": o["gmap_embeds"].detach(),
+                "global_logits": o["global_logits"].detach(), "loss": o_loss.detach()}
+    ref_grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    _assert_step_matches(ref_outs, ref_grads, {"txt_embeds": txt.detach(), "pano_embeds": pano.detach(),
+                                               "gmap_embeds": outs["gmap_embeds"].detach(),
+                                               "global_logits": outs["global_logits"].detach(), "loss": loss.detach()},
+                         grads_of(model))
+    assert (rgb.grad.cpu() - ob["rgb_fts"].grad).abs().max().item() < 2e-4
+    # eval() switches every site off again
+    model.eval()
+    e_txt = model.forward_txt(b["txt_ids"], b["txt_masks"])
+    assert (e_txt.detach().cpu() - po.forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"])).abs().max().item() < 2e-4
+
+
+def test_bf16_train_mode_step_close_to_oracle_with_same_masks():
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=6)
+    batch = po.make_batch(cfg, B=4, L=40, V=20, G=12, seed=31, ragged=True)
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch, dropout=RATES, drop_seed=5)
+    step.run_eager()
+    got = step_outputs(step)
+    outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*RATES, seed=(5 << 32) | 1))
+    _assert_step_matches(outs, grads, got, grads_of(model), atol=8e-2, rel=0.1)
+    # ranged text backward (DP overlap schedule) recomputes the same masks
+    ref = model.flat_grads.clone()
+    s = model._engine.stream()
+    step.step_no -= 1                      # same masks as the step above
+    step.enqueue_main(s, True, join_pano=True)
+    for lo, hi in ((6, 9), (3, 6), (0, 3)):
+        step.enqueue_txt_bwd(s, lo, hi)
+    torch.cuda.synchronize()
+    assert (model.flat_grads - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-4
+    step.close()
