@@ -49,10 +49,10 @@ template <typename T, int ROWS, int COLS>
 __device__ __forceinline__ void nat_load(char* lds, const T* __restrict__ g, long ld, int rows_valid, int cols_valid, int tid) {
   using N = Nat<T, COLS>;
   constexpr int TOTAL = ROWS * N::CPR;
-  static_assert(TOTAL % 256 == 0, "tile chunk count must be a multiple of the block size");
 #pragma unroll
-  for (int j = 0; j < TOTAL / 256; ++j) {
+  for (int j = 0; j < (TOTAL + 255) / 256; ++j) {
     const int q = tid + j * 256;
+    if (TOTAL % 256 != 0 && q >= TOTAL) break;          // only the last pass of a 96-wide tile is partial
     const int r = q / N::CPR, c = (q % N::CPR) * N::EPC;
     const bool ok = r < rows_valid && c < cols_valid;
     const int rc = min(r, rows_valid - 1), cc = min(c, cols_valid - N::EPC);
@@ -496,9 +496,9 @@ int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ld
   k.P = P; k.ctx = ctx; k.ldc = ldc;
   k.nq = (a.Lq + 63) / 64;                        // 64 queries per workgroup
   const int blocks = a.B * nh * k.nq;
-  const bool bk = a.Lk > 64;
-  if (dt == ETP_BF16) {
-    if (bk) return launch_fwd<bf16_t, 64, 128>(k, blocks, st);
+  if (dt == ETP_BF16) {     // key tile = 64 / 96 / 128 columns: the 80-token instruction takes the 96 one, not a 128 pad
+    if (a.Lk > 96) return launch_fwd<bf16_t, 64, 128>(k, blocks, st);
+    if (a.Lk > 64) return launch_fwd<bf16_t, 64, 96>(k, blocks, st);
     return launch_fwd<bf16_t, 64, 64>(k, blocks, st);
   }
   return launch_fwd<float, 64, 64>(k, blocks, st);
@@ -513,6 +513,8 @@ int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* 
   const int blocks = a.B * nh;
   const bool bq = a.Lq > 64, bk = a.Lk > 64;
   if (dt == ETP_BF16) {
+    if (bq && bk && a.Lq <= 96 && a.Lk <= 96) return launch_bwd<bf16_t, 96, 96>(k, blocks, st);
+    if (!bq && bk && a.Lk <= 96) return launch_bwd<bf16_t, 64, 96>(k, blocks, st);
     if (bq && bk) return launch_bwd<bf16_t, 128, 128>(k, blocks, st);
     if (bq) return launch_bwd<bf16_t, 128, 64>(k, blocks, st);
     if (bk) return launch_bwd<bf16_t, 64, 128>(k, blocks, st);

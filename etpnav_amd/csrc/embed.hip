@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __rest
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
   constexpr int H = NCH * 256;
   extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
-  Row<NCH> a_g, a_b, a_bp, a_w[PK];                                  // dgamma, dbeta, d_b_pos, d_w_pos[.,j]
-  row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_bp);
+  Row<NCH> a_g, a_b, a_bp, a_w[PK], a_s0;                            // dgamma, dbeta, d_b_pos, d_w_pos[.,j], d_step_emb[0]
+  row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_bp); row_zero<NCH>(a_s0);
 #pragma unroll
   for (int j = 0; j < PK; ++j) row_zero<NCH>(a_w[j]);
   const int lane = threadIdx.x & 63;
@@ -441,7 +441,11 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 4; ++e) t.v[c][e] = (t.v[c][e] - mean) * rstd;
     row_load<NCH>(d, dx + (long)row * H, lane);
-    global_acc<NCH>(d_step_emb + step_ids[row] * H, d, lane);
+    // step id 0 marks the [stop] token and every unvisited (ghost) node (ss_trainer_ETP.py:364-366,393): most rows hit
+    // table row 0, and per-row atomics on one row serialise in L2 -- those rows go through the block accumulator instead
+    const int64_t sid = step_ids[row];
+    if (sid == 0) acc_scaled<NCH>(a_s0, d, 1.0f);
+    else global_acc<NCH>(d_step_emb + sid * H, d, lane);
     acc_mul<NCH>(a_g, d, t);
     acc_scaled<NCH>(a_b, d, 1.0f);
     row_ln_bwd<NCH>(d, t, gamma, rstd, lane);
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __rest
   block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
   block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
   block_flush<NCH>(scratch, a_bp, d_b_pos, 1, 0);
+  block_flush<NCH>(scratch, a_s0, d_step_emb, 1, 0);
 #pragma unroll
   for (int j = 0; j < PK; ++j) block_flush<NCH>(scratch, a_w[j], d_w_pos, PK, j);
 }

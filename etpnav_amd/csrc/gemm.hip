@@ -716,13 +716,16 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
   bool dma = dma_ok(BK, g.K, g.ksplit);
   int stages = big ? 2 : 3;   // whole-step A/B on MI355X: 3-deep ring on 64x64 tiles 5.76 -> 5.37 ms/step
-  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r"
+  bool wide = false;          // 128x64 tiles
+  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r", "w", "64s6"
   if (force && force[0]) {
     if (force[0] == '1' || force[0] == '6') big = force[0] == '1';
+    if (force[0] == 'w') { wide = true; big = false; }
     stages = big ? 2 : 3;
     if (strstr(force, "s2")) stages = 2;
     if (strstr(force, "s3")) stages = 3;
     if (strstr(force, "s4")) stages = 4;
+    if (strstr(force, "s6")) stages = 6;
   }
   if (!dma) {
     if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
@@ -732,6 +735,12 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
     if (stages == 3) return launch_one<T, TC, TA, TB, 128, 128, 3>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 128, 128, 2>(g, nbatch, st);
   }
+  if (wide) {
+    if (stages == 2) return launch_one<T, TC, TA, TB, 128, 64, 2>(g, nbatch, st);
+    if (stages == 4) return launch_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
+    return launch_one<T, TC, TA, TB, 128, 64, 3>(g, nbatch, st);
+  }
+  if (stages == 6) return launch_one<T, TC, TA, TB, 64, 64, 6>(g, nbatch, st);
   if (stages == 4) return launch_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
   if (stages == 3) return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
   return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);

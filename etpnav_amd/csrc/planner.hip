@@ -594,6 +594,17 @@ int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream) {
   if (p->cfg.dtype != ETP_BF16) return ETP_OK;
   return cast_f32_to_bf16(p->P, p->S, p->n_matrix, (hipStream_t)stream);
 }
+int etp_planner_refresh_part(etp_planner* p, int part, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && part >= 0 && part <= 2, "planner not bound / part must be 0 (text), 1 (panorama) or 2 (navigation)");
+  if (p->cfg.dtype != ETP_BF16) return ETP_OK;
+  // matrix region order (build_layout): text layers | view projections + panorama layers | x-layers + SAP head
+  const long txt_end = p->off(p->img_w);
+  const long pano_end = p->cfg.n_x > 0 ? p->off(p->xl[0].self.qkv_w) : p->off(p->sap0_w);
+  const long lo = part == 0 ? 0 : part == 1 ? txt_end : pano_end;
+  const long hi = part == 0 ? txt_end : part == 1 ? pano_end : p->n_matrix;
+  if (hi <= lo) return ETP_OK;
+  return cast_f32_to_bf16(p->P + lo, reinterpret_cast<uint16_t*>(p->S) + lo, hi - lo, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------
 int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L) {
@@ -966,12 +977,28 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
   const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
   Act x = s.x0;
+  // The text K/V projections of ALL x-layers depend only on the text (M = B*L rows, the largest GEMMs of this entry
+  // point), not on the node chain: with a side stream they are issued up front and each layer waits for its own.
+  const bool kv_side = c.sw != c.st;
+  std::vector<hipEvent_t> kv_ready(cf.n_x);
+  if (kv_side) {
+    ETP_TRY(stream_after(p, c.st, c.sw));
+    Ctx cs = c;
+    cs.st = c.sw;
+    for (int l = 0; l < cf.n_x; ++l) {
+      ETP_TRY(linear_fwd(cs, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, s.layers[l].cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE,
+                         nullptr, nullptr, 0));
+      kv_ready[l] = p->next_event();
+      ETP_CHECK_HIP(hipEventRecord(kv_ready[l], c.sw));
+    }
+  }
   for (int l = 0; l < cf.n_x; ++l) {   // GraphLXRTXLayer.forward vilmodel_cmt.py:383-398
     const XLayerP& q = p->xl[l];
     XStash& t = s.layers[l];
     // cross attention nodes -> text (BertXAttention :360-363)
     ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
-    ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    if (kv_side) ETP_CHECK_HIP(hipStreamWaitEvent(c.st, kv_ready[l], 0));
+    else ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
               nullptr, nullptr};
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st, att(c, MODE_NAV, l, SITE_X_P)));
@@ -1043,7 +1070,12 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, g, Mg, H, H, w.t1.f));
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
-    ETP_TRY(linear_dgrad_s(c, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
+    // d_txt accumulates over the layers and is consumed only by the caller: like the weight gradients it is a leaf of
+    // this entry point, so it follows the K/V weight gradient on the side stream (in order there: the read-modify-write
+    // accumulation over layers stays serial) and is joined by join_wgrads below
+    Ctx cs = c;
+    cs.st = c.sw;
+    ETP_TRY(linear_dgrad_s(cs, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
   }
   ETP_TRY(gmap_embed_bwd(c.dt, g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,

@@ -125,11 +125,16 @@ class PlannerStep:
         dt = _lib.ETP_F32          # node assembly works on the fp32 API tensors
         self.step_no += 1
         eng.set_dropout(self._drop_state())
-        check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
+        # weight-shadow refresh and gradient zeroing ride on the stream that first needs them: the text cast on the main
+        # stream, the panorama/navigation casts and the (bandwidth-bound) gradient memset on the panorama stream, whose
+        # join below precedes forward_navigation and every backward kernel
+        check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
-        if backward:
-            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s), "memset grads")
         check(L.etp_stream_after(s, s2), "fork")
+        check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
+        check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
+        if backward:
+            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), B, V,
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")

@@ -223,6 +223,10 @@ int etp_planner_set_dropout(etp_planner* p, float p_hidden, float p_attn, float 
 int etp_dropout_multipliers(float p, uint64_t seed, int mode, int layer, int slot, int64_t n, float* out_host);
 /* bf16 mode: refresh the bf16 shadow of the GEMM weights from the fp32 masters (autocast's per-step weight cast). */
 int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
+/* The same refresh for one consumer only, so a multi-stream step can put each cast on the stream that first needs it:
+ * part 0 = text encoder (forward_txt), 1 = view projections + panorama encoder (forward_panorama), 2 = x-layers + SAP
+ * head (forward_navigation).  The three parts tile the matrix region exactly. */
+int etp_planner_refresh_part(etp_planner* p, int part, etp_stream_t stream);
 
 /* Activations that cross these entry points (txt_embeds, pano_embeds, gmap_img_fts, gmap_embeds and their gradients) are
  * fp32 in BOTH modes, as they are under the reference's autocast (outputs of fp32 LayerNorms); `dtype` only selects the

@@ -202,7 +202,7 @@ def test_softmax(dtype, mask_mode):
 
 
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
-@pytest.mark.parametrize("Lq,Lk", [(80, 80), (9, 20), (36, 36), (16, 512)])
+@pytest.mark.parametrize("Lq,Lk", [(80, 80), (9, 20), (36, 36), (16, 512), (16, 80), (100, 120), (70, 40), (96, 72)])
 def test_attention_fwd_bwd(dtype, Lq, Lk):
     """softmax(QK^T/8 + mask + sprel)V and its backward against torch autograd (head dim 64)."""
     torch.manual_seed(4)

@@ -36,6 +36,11 @@ def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(3): check(L.etp_gemm(ctypes.byref(d), s))
     torch.cuda.synchronize()
+    if os.environ.get("GEMM_CHECK") and kind in ("fwd", "dgrad"):
+        ref = (A.float() @ (B.float().t() if kind == "fwd" else B.float()))
+        if kind == "fwd": ref = ref + bias
+        err = (C.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert err < 2e-2, (kind, M, N, K, os.environ.get("ETP_GEMM_TILE"), err)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): check(L.etp_gemm(ctypes.byref(d), s))

@@ -1,0 +1,99 @@
+"""Timeline analysis of a `rocprofv3 --kernel-trace` CSV of bench.py: where does a planner step's wall time go?
+
+  python tools/timeline.py gpurun_out/prof/r01_kernel_trace.csv [--steps 20]
+
+Steps are delimited by the first kernel of each step (the bf16 weight-shadow refresh, `cast_f32_to_bf16` with the largest
+grid).  For the last `--steps` steps it prints: wall time per step, the union of kernel-busy time (any stream), idle
+gaps, per-stream busy time, and per kernel family the summed duration, the "exclusive" duration (time during which it
+was the only kernel running) and the launch count.  Exclusive time of small-grid kernels is what the three-stream
+schedule failed to overlap: the list to attack first.
+"""
+import argparse
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void\s+", "", n)
+    m = re.match(r"([\w:]+)<(.*)>\(", n)
+    if m:
+        args = m.group(2)
+        args = re.sub(r"__hip_bfloat16|hip_bfloat16", "bf16", args)
+        args = re.sub(r"\s+", "", args)
+        return f"{m.group(1).split('::')[-1]}<{args[:48]}>"
+    return n.split("(")[0][-60:]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--top", type=int, default=28)
+    a = ap.parse_args()
+    rows = []
+    with open(a.csv, newline="") as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", "0"),
+                         int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]),
+                         int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])))
+    rows.sort()
+    # step starts: the weight-shadow refresh cast (largest cast grid)
+    casts = [r for r in rows if "cast_f32_bf16_kernel" in r[2]]
+    if not casts:
+        sys.exit("no cast kernels found: cannot delimit steps")
+    big = max(r[4] for r in casts)
+    starts = [r[0] for r in casts if r[4] == big]
+    if len(starts) < a.steps + 1:
+        a.steps = len(starts) - 1
+    t0, t1 = starts[-a.steps - 1], starts[-1]
+    win = [r for r in rows if t0 <= r[0] < t1]
+    wall = (t1 - t0) / a.steps
+    # union busy + exclusive time via sweep
+    ev = []
+    for i, r in enumerate(win):
+        ev.append((r[0], 1, i))
+        ev.append((min(r[1], t1), -1, i))
+    ev.sort()
+    active = set()
+    busy = 0
+    excl = defaultdict(int)
+    conc_hist = defaultdict(int)
+    last = t0
+    for t, d, i in ev:
+        if t > last:
+            n = len(active)
+            conc_hist[min(n, 4)] += t - last
+            if n >= 1:
+                busy += t - last
+            if n == 1:
+                excl[short(win[next(iter(active))][2])] += t - last
+            last = t
+        if d == 1:
+            active.add(i)
+        else:
+            active.discard(i)
+    tot = defaultdict(int)
+    cnt = defaultdict(int)
+    wgs = defaultdict(int)
+    per_stream = defaultdict(int)
+    for r in win:
+        k = short(r[2])
+        tot[k] += r[1] - r[0]
+        cnt[k] += 1
+        wgs[k] += r[4] // max(r[5], 1)
+        per_stream[r[3]] += r[1] - r[0]
+    us = lambda x: x / a.steps / 1e3
+    print(f"steps analysed: {a.steps}   wall/step {wall / 1e3:.1f} us   kernels/step {len(win) / a.steps:.0f}")
+    print(f"busy (>=1 kernel) {us(busy):.1f} us/step   idle {wall / 1e3 - us(busy):.1f} us/step")
+    print("concurrency histogram (us/step): " + "  ".join(f"{k if k < 4 else '4+'}:{us(v):.0f}" for k, v in sorted(conc_hist.items())))
+    print("per-stream kernel time (us/step): " + "  ".join(f"s{k}:{us(v):.0f}" for k, v in sorted(per_stream.items())))
+    print(f"{'kernel':72s} {'sum us':>8s} {'excl us':>8s} {'n':>5s} {'avg us':>7s} {'avg WGs':>8s}")
+    for k in sorted(tot, key=lambda k: -tot[k])[:a.top]:
+        print(f"{k[:72]:72s} {us(tot[k]):8.1f} {us(excl[k]):8.1f} {cnt[k] / a.steps:5.0f} {tot[k] / cnt[k] / 1e3:7.1f} {wgs[k] / cnt[k]:8.0f}")
+
+
+if __name__ == "__main__":
+    main()
