@@ -75,6 +75,12 @@ class ParamInfo(ctypes.Structure):
                 ("offset", ctypes.c_int64)]
 
 
+class AdamwCfg(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("weight_decay", ctypes.c_float), ("step", ctypes.c_int32), ("hf_style", ctypes.c_int32),
+                ("correct_bias", ctypes.c_int32), ("grad_scale", ctypes.c_float), ("max_norm", ctypes.c_float)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 96), ("launches", ctypes.c_int64), ("ms", ctypes.c_double),
                 ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]

@@ -154,6 +154,16 @@ int etp_sap_ce(const float* logits, const int64_t* labels, float* loss, float* d
   ETP_REQUIRE(logits && labels && loss, "null pointer");
   return sap_ce(logits, labels, loss, dlogits, B, G, scale, (long)ignore_index, (hipStream_t)s);
 }
+int etp_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow, int64_t n_shadow,
+                   const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
+                   int zero_grads, etp_stream_t s) {
+  ETP_REQUIRE(cfg, "null config");
+  return adamw_step(params, grads, exp_avg, exp_avg_sq, shadow, (long)n_shadow, decay_mask, (long)n, *cfg, sumsq, skip,
+                    zero_grads, (hipStream_t)s);
+}
+int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t s) {
+  return grad_sqnorm(grads, (long)n, sumsq, nonfinite, (hipStream_t)s);
+}
 int etp_gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
                    int accumulate, etp_stream_t s) {
   ETP_REQUIRE(src && ptr && idx && w && out, "null pointer");

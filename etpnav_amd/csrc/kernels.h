@@ -57,6 +57,11 @@ int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStre
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st);
 int scale_f32(float* p, long n, float scale, hipStream_t st);
 
+// optim.hip: fused AdamW (+ bf16 shadow refresh + gradient zeroing) and the gradient norm / non-finite scan
+int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,
+               const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st);
+int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st);
+
 // attention = batched MFMA GEMMs + masked softmax (planner.hip); head dim 64, heads interleaved in the row
 struct AttnBuf {
   const void* Q; long ldq; const void* K; long ldk; const void* V; long ldv;

@@ -131,6 +131,10 @@ class Engine:
             check(self.L.etp_planner_refresh_weights(self.handle, self.stream()), "refresh_weights")
             self._shadow_version = self.params._version
 
+    def mark_shadow_current(self):
+        """Called by FusedAdamW: its kernel wrote the bf16 shadow together with the fp32 masters."""
+        self._shadow_version = self.params._version
+
     def set_dropout(self, drop):
         """drop = None (eval) or (p_hidden, p_attn, p_head, p_env, seed); read by the next enqueued entry points."""
         if drop is None:

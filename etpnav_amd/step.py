@@ -51,10 +51,12 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
 
 class PlannerStep:
     def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True,
-                 dropout=None, drop_seed: int = 0):
+                 dropout=None, drop_seed: int = 0, refresh_weights: bool = True, zero_grads: bool = True):
         """dropout: None (eval-mode step), "config" (the model config's rates, the reference's policy.train()), or a
-        tuple (p_hidden, p_attn, p_head, p_env)."""
+        tuple (p_hidden, p_attn, p_head, p_env).  refresh_weights / zero_grads = False when etpnav_amd.optim.FusedAdamW
+        closes the step: its kernel already wrote the bf16 weight shadow and zeroed the gradient arena."""
         self.model = model
+        self.refresh_weights, self.zero_grads = refresh_weights, zero_grads
         if dropout == "config":
             c = model.config
             dropout = (float(getattr(c, "hidden_dropout_prob", 0.1)), float(getattr(c, "attention_probs_dropout_prob", 0.1)),
@@ -128,12 +130,14 @@ class PlannerStep:
         # weight-shadow refresh and gradient zeroing ride on the stream that first needs them: the text cast on the main
         # stream, the panorama/navigation casts and the (bandwidth-bound) gradient memset on the panorama stream, whose
         # join below precedes forward_navigation and every backward kernel
-        check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
+        if self.refresh_weights:
+            check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
         check(L.etp_stream_after(s, s2), "fork")
-        check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
-        check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
-        if backward:
+        if self.refresh_weights:
+            check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
+            check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
+        if backward and self.zero_grads:
             check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), B, V,

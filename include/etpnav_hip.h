@@ -168,6 +168,33 @@ int etp_cast_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, et
 int etp_scale_f32(float* p, int64_t n, float scale, etp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Fused AdamW over flat fp32 arenas.  Replaces, in ONE HBM pass per step: torch.optim.AdamW
+ * (ss_trainer_ETP.py:213,505) or the pre-training AdamW (pretrain_src/pretrain_src/optim/adamw.py:53-112),
+ * GradScaler.unscale_ + its non-finite check (ss_trainer_ETP.py:463,504-506), clip_grad_norm_, the autocast weight
+ * casts of the next forward (etp_planner_refresh_weights) and optimizer.zero_grad().
+ *   hf_style 0: torch.optim.AdamW      p *= 1 - lr*wd;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ *   hf_style 1: optim/adamw.py         p -= lr*sqrt(bc2)/bc1 * m / (sqrt(v) + eps);  p -= lr*wd*p
+ *   bc1 = 1-beta1^step, bc2 = 1-beta2^step (both 1 when correct_bias == 0); step counts from 1.
+ *   g = grad * grad_scale * clip, clip = min(1, max_norm / (sqrt(*sumsq)*|grad_scale| + 1e-6)) when max_norm > 0.
+ * decay_mask (nullable = decay everywhere): one byte per 64 consecutive elements, non-zero = apply weight_decay
+ * (planner parameters start on 64-element boundaries, so any per-parameter grouping such as optim/misc.py:12-22 fits).
+ * shadow (nullable): bf16 copy written for elements [0, n_shadow).  skip (nullable, device int32): non-zero -> leave
+ * p/m/v/shadow untouched (GradScaler's skipped step); gradients are still zeroed when zero_grads != 0.
+ * sumsq / skip are produced by etp_grad_sqnorm (both ACCUMULATE: zero them first).  n % 4 == 0, 16-byte aligned. */
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;
+  int32_t hf_style;
+  int32_t correct_bias;
+  float grad_scale;
+  float max_norm;
+} etp_adamw_cfg;
+int etp_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow, int64_t n_shadow,
+                   const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
+                   int zero_grads, etp_stream_t stream);
+int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Planner engine: whole forward/backward of the three planner entry points over one flat parameter arena.
  * Replaces GlocalTextPathNavCMT.forward_txt / forward_panorama / forward_navigation (vilmodel_cmt.py:684-750)
  * and their autograd backward.
