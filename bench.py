@@ -51,7 +51,7 @@ def flops_per_step(w, cfg):
     return 3.0 * (lang + pano + xl + head)
 
 
-def cpu_baseline(w, cfg_kwargs, budget_s=20.0):
+def cpu_baseline(w, cfg_kwargs, budget_s=20.0, train=True):
     """Time the CPU oracle (test infrastructure; the checker, not the product) on a BOUNDED sample of the same
     workload: full 36-view x 80-token x 16-node episodes, but only as many episodes per step as fit ~budget_s of CPU
     time (steps/s is then scaled by sample_batch / batch — per-episode work is independent)."""
@@ -64,11 +64,12 @@ def cpu_baseline(w, cfg_kwargs, budget_s=20.0):
     cores = max(1, min(avail, 32))                 # torch CPU matmuls stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     P = {k: v.requires_grad_(True) for k, v in po.init_params(ocfg, seed=0).items()}
+    drop = po.TorchDrop(0.1, 0.1, 0.1, 0.0) if train else None     # policy.train(): nn.Dropout at every reference site
 
     def one(b):                                    # fwd + bwd of the oracle, gradients into P[k].grad
         for v in P.values():
             v.grad = None
-        po.planner_step(P, ocfg, b)["loss"].backward()
+        po.planner_step(P, ocfg, b, drop=drop)["loss"].backward()
 
     probe_b = min(2, w["B"])
     pb = po.make_batch(ocfg, B=probe_b, L=w["L"], V=w["V"], G=w["G"], seed=1234)
@@ -88,7 +89,8 @@ def cpu_baseline(w, cfg_kwargs, budget_s=20.0):
     scale = sb / w["B"]
     return {"value": scale / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} timed fwd+bwd steps of {sb} of the {w['B']} episodes per step (same L/V/G), rate scaled by "
-                      f"{sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py), {cores} threads of {avail} available"}
+                      f"{sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py, {'train mode: dropout on' if train else 'eval mode'}), "
+                      f"{cores} threads of {avail} available"}
 
 
 def main():
@@ -102,6 +104,7 @@ def main():
                     help="replay a captured hipGraph (one side stream) instead of eager three-stream issue; measured "
                          "slower on MI355X: the step is not launch-bound (DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-AdamW leg")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train (default): dropout active at every site, as under the reference's policy.train() "
                          "(ss_trainer_ETP.py:483); eval: dropout off (the parity-fixture configuration)")
@@ -218,10 +221,43 @@ def main():
                         "frac": round(d["tflops"] / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                         "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches_per_step"],
                         "traffic": None,
+                        "alg_bytes_per_launch": round(d["alg_gbs"] * 1e9 * d["avg_us"] * 1e-6),
                         "note": "achieved = algorithmic 2MNK FLOPs of every launch of this kernel in a step / summed "
                                 "HIP-event durations (events on the launch stream, eager replays after the timed region)"}
+            # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
+            # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on the weight-shadow cast: tools/pmc_traffic.py)
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            if args.workload == "c2" and args.dtype == "bf16" and os.path.exists(pmc):
+                try:
+                    ent = json.load(open(pmc))["kernels"].get(d["kernel"])
+                    if ent and ent.get("hbm_bytes_per_launch"):
+                        roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
+                        roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                except (ValueError, KeyError):
+                    pass
 
     out = None
+    # ---- optimizer leg (reported separately): fused AdamW closing the step on device ----
+    optimizer = None
+    if rank == 0 and not args.no_optimizer:
+        from etpnav_amd.optim import FusedAdamW
+        opt = FusedAdamW(model, lr=1e-5)                          # ss_trainer_ETP.py:213 torch.optim.AdamW semantics
+        eng = model._engine
+        for _ in range(2):
+            opt.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nopt = 10
+        e0.record()
+        for _ in range(nopt):
+            opt.step()
+        e1.record(); torch.cuda.synchronize()
+        oms = e0.elapsed_time(e1) / nopt
+        obytes = eng.total * (16 + 12 + 4) + (eng.n_matrix * 2 if eng.shadow is not None else 0)
+        optimizer = {"kind": "FusedAdamW (etp_adamw_step: update + bf16 shadow + grad zeroing in one pass)",
+                     "ms_per_step": round(oms, 4), "params": eng.total, "alg_bytes": obytes,
+                     "roofline": {"bound": "hbm", "achieved": round(obytes / (oms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": round(obytes / (oms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                     "note": "not part of `value`; replaces torch AdamW + the next step's weight cast and gradient memset"}
     if rank == 0:
         fl = flops_per_step(w, cfg)
         out = {
@@ -242,10 +278,11 @@ def main():
             "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
             "model_flops_per_step": fl,
             "roofline": roofline,
+            "optimizer": optimizer,
             "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, dict(image_feat_size=w["image_feat_size"]))
+            out["cpu_baseline"] = cpu_baseline(w, dict(image_feat_size=w["image_feat_size"]), train=args.mode == "train")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

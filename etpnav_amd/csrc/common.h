@@ -132,6 +132,7 @@ struct GemmArgs {
   int out_mode;                       // 0 store, 1 C += v, 2 atomicAdd (fp32 C only)
   int vec_epilogue;                   // set by launch_gemm: 16-byte epilogue accesses are legal
   float* a_colsum;                    // TN (wgrad) only: a_colsum[m] += sum_k A[m,k]  (bias gradient), LDS-DMA kernel only
+  int xcd_map;                        // 1: XCD-aware workgroup->tile order (set by launch_gemm; env ETP_GEMM_XCD=0 disables)
   Drop drop;                          // dropout on the epilogue value (after activation / its backward, before the residual);
                                       // element index = row * N + col
 };

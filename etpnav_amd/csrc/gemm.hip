@@ -370,6 +370,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
   (void)R;
 }
 
+// XCD-aware workgroup -> tile map.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD
+// i % 8) and every XCD has a private 4 MiB L2: with the plain row-major map each XCD touches every row tile AND every
+// column tile, so both operands are fetched from the fabric once per XCD (PMC, round 1: 60 MB fetched per weight-gradient
+// launch for 16 MB of algorithmic operand bytes).  Remapped, the workgroups of one XCD own a CONTIGUOUS slab of the tile
+// grid, sliced along the longer tile axis: its L2 then holds 1/8 of the long operand plus the short one.
+// (bijective form of the remap: cdna_hip_programming.md, "XCD swizzle must be bijective")
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int xcd_map, int& tm, int& tn) {
+  int id = bid;
+  if (xcd_map) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  if (!xcd_map || tiles_m >= tiles_n) { tm = id / tiles_n; tn = id % tiles_n; }
+  else { tn = id / tiles_m; tm = id % tiles_m; }
+}
+
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   using GA = TileGeom<T, TA, BM>;
@@ -386,7 +402,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   // tile / batch / split-K coordinates.  blockIdx.x walks N fastest so that consecutive blocks share the
   // A row-panel; TODO(round 2): XCD-aware remap.
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
   const int zo = z / g.nb_inner, zi = z % g.nb_inner;
@@ -535,7 +552,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
   const int zo = z / g.nb_inner, zi = z % g.nb_inner;
@@ -768,6 +786,10 @@ int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, in
   ETP_REQUIRE(g0.a_colsum == nullptr || (ta && tb && gemm_uses_dma(dtype, g0.K, g0.ksplit)),
               "a_colsum needs the TN LDS-DMA kernel (check gemm_uses_dma first)");
   GemmArgs g = g_in;
+  {
+    static const int xcd_on = [] { const char* e = getenv("ETP_GEMM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    g.xcd_map = xcd_on;
+  }
   {  // the vectorised epilogue needs 8-column chunks to stay in-bounds and 16-byte aligned
     const size_t cs = dtype_size(c_dtype), ts = dtype_size(dtype);
     bool ok = (g.ldc % 8 == 0) && (g.ldc >= round_up(g.N, 8)) && ((uintptr_t)g.C % 16 == 0) && ((g.sCo * cs) % 16 == 0) &&

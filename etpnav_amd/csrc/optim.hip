@@ -22,6 +22,16 @@ struct AdamwK {
   float max_norm;             // > 0: clip to this global L2 norm using *sumsq (torch.nn.utils.clip_grad_norm_)
 };
 
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntload(const float* p) {
+  const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+  return make_float4(x[0], x[1], x[2], x[3]);
+}
+__device__ __forceinline__ void ntstore(float* p, float4 v) {
+  f4_t x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n_shadow,
                                                     const uint8_t* __restrict__ decay_mask, long n, AdamwK k,
@@ -36,11 +46,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const long e0 = i * 4;
-    float4 gv = *reinterpret_cast<const float4*>(g + e0);
+    // every array is streamed exactly once: non-temporal accesses keep 4.7 GB of optimizer traffic out of L2/MALL
+    float4 gv = ntload(g + e0);
     if (!skipped) {
-      float4 pv = *reinterpret_cast<const float4*>(p + e0);
-      float4 mv = *reinterpret_cast<const float4*>(m + e0);
-      float4 vv = *reinterpret_cast<const float4*>(v + e0);
+      float4 pv = ntload(p + e0);
+      float4 mv = ntload(m + e0);
+      float4 vv = ntload(v + e0);
       const float wd = (decay_mask == nullptr || decay_mask[e0 >> 6]) ? k.wd : 0.f;
       float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
       float mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -57,12 +68,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
           pp[e] = dec - (k.lr / k.bc1) * mm[e] / (sqrtf(vq[e]) / k.bc2_sqrt + k.eps);
         }
       }
-      *reinterpret_cast<float4*>(p + e0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-      *reinterpret_cast<float4*>(m + e0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-      *reinterpret_cast<float4*>(v + e0) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+      ntstore(p + e0, make_float4(pp[0], pp[1], pp[2], pp[3]));
+      ntstore(m + e0, make_float4(mm[0], mm[1], mm[2], mm[3]));
+      ntstore(v + e0, make_float4(vq[0], vq[1], vq[2], vq[3]));
       if (shadow != nullptr && e0 < n_shadow) store4(shadow + e0, pp);
     }
-    if (zero_grads) *reinterpret_cast<float4*>(g + e0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grads) ntstore(g + e0, make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
 

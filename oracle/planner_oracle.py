@@ -249,9 +249,18 @@ class DropSpec:
         return torch.from_numpy(m).view(*shape).to(dtype)
 
 
+class TorchDrop(DropSpec):
+    """Same sites and rates, masks from torch's RNG (what the reference's nn.Dropout does): not reproducible against
+    the device generator, used only to TIME the train-mode CPU path (bench.py cpu_baseline)."""
+    torch_rng = True
+
+
 def _drop(x: Tensor, drop, p_name: str, mode: int, layer: int, slot: int) -> Tensor:
     if drop is None:
         return x
+    if getattr(drop, "torch_rng", False):
+        p = getattr(drop, p_name)
+        return torch.nn.functional.dropout(x, p, True) if p > 0.0 else x
     m = drop.mult(getattr(drop, p_name), mode, layer, slot, x.shape, x.dtype)
     return x if m is None else x * m
 
