@@ -990,11 +990,83 @@ int64_t etp_nav_ws_bytes(const etp_planner* p, int B, int L, int G) {
   return (int64_t)b.off + 256;
 }
 
-int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
-                const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
-                float* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
-  ETP_REQUIRE(p && p->P && txt && txt_mask && step_ids && img && pos && gmask && visited && out_embeds && out_logits && stash &&
-                  B > 0 && L > 0 && G > 0,
+}  // extern "C"
+namespace {
+// Text K/V cache: the instruction is fixed for a whole episode, yet BertOutAttention re-projects it to
+// keys/values in each of the 4 x-layers at every rollout step (vilmodel_cmt.py:326-328,387-389; ss_trainer_ETP.py:819-822).
+// Layout of the caller-owned cache: [ text in the operand dtype (bf16 mode only) | K|V of x-layer 0 | ... | x-layer n_x-1 ],
+// each K|V block [B*L, 2H] in the operand dtype -- exactly what the cross-attention kernels consume.
+struct KvCache { void* txtT; std::vector<void*> kv; };
+KvCache plan_kv(const etp_planner* pl, void* buf, int Bn, int L) {
+  const etp_config& c = pl->cfg;
+  const size_t es = dtype_size(c.dtype);
+  const long Mt = (long)Bn * L;
+  Bump b(buf);
+  KvCache k;
+  k.txtT = c.dtype == ETP_BF16 ? b.take(Mt * c.hidden * es) : nullptr;
+  for (int l = 0; l < c.n_x; ++l) k.kv.push_back(b.take(Mt * 2 * c.hidden * es));
+  return k;
+}
+int64_t kv_bytes(const etp_planner* pl, int Bn, int L) {
+  const etp_config& c = pl->cfg;
+  const size_t es = dtype_size(c.dtype);
+  const long Mt = (long)Bn * L;
+  Bump b(nullptr);
+  if (c.dtype == ETP_BF16) b.take(Mt * c.hidden * es);
+  for (int l = 0; l < c.n_x; ++l) b.take(Mt * 2 * c.hidden * es);
+  return (int64_t)b.off + 256;
+}
+}  // namespace
+extern "C" {
+
+int64_t etp_nav_kv_bytes(const etp_planner* p, int B, int L) { return p ? kv_bytes(p, B, L) : 0; }
+int64_t etp_nav_kv_offset(const etp_planner* p, int B, int L) {   // byte offset of the first K|V block inside the cache
+  if (!p) return 0;
+  KvCache k = plan_kv(p, reinterpret_cast<void*>(0x1000), B, L);
+  return p->cfg.n_x > 0 ? (int64_t)(reinterpret_cast<char*>(k.kv[0]) - reinterpret_cast<char*>(0x1000)) : 0;
+}
+int64_t etp_nav_kv_grad_elems(const etp_planner* p, int B, int L) {
+  return p ? (int64_t)p->cfg.n_x * B * L * 2 * p->cfg.hidden : 0;
+}
+
+int etp_nav_kv_fwd(etp_planner* p, const float* txt, int B, int L, void* kvbuf, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && txt && kvbuf && B > 0 && L > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  KvCache kc = plan_kv(p, kvbuf, B, L);
+  const int H = c.H, Mt = B * L;
+  const void* txtT = txt;
+  if (c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, kc.txtT, (long)Mt * H, c.st)); txtT = kc.txtT; }
+  for (int l = 0; l < p->cfg.n_x; ++l)
+    ETP_TRY(linear_fwd(c, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, kc.kv[l], 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+  return ETP_OK;
+}
+// d_kv: [n_x][B*L][2H] in the operand dtype = the SUM over the rollout's steps of what etp_nav_bwd_kv returned
+int etp_nav_kv_bwd(etp_planner* p, const float* txt, const void* d_kv, int B, int L, const void* kvbuf, float* d_txt,
+                   etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && txt && d_kv && kvbuf && d_txt && B > 0 && L > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  std::vector<std::function<int()>> pend;
+  if (c.sw != c.st) c.pend = &pend;
+  KvCache kc = plan_kv(p, const_cast<void*>(kvbuf), B, L);
+  const int H = c.H, Mt = B * L;
+  const void* txtT = c.dt == ETP_BF16 ? kc.txtT : (const void*)txt;
+  if (p->cfg.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
+  for (int l = 0; l < p->cfg.n_x; ++l) {
+    const void* d = offs(d_kv, (long)l * Mt * 2 * H, c.es);
+    ETP_TRY(linear_wgrad(c, d, 2 * H, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, Mt, 2 * H, H));
+    ETP_TRY(linear_dgrad_s(c, d, 2 * H, p->xl[l].kv_w, d_txt, Mt, 2 * H, H, nullptr, l == 0 ? 0 : 1));
+  }
+  return join_wgrads(c);
+}
+
+}  // extern "C"
+namespace {
+int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
+                 const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
+                 float* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
+  const bool cached = kvbuf != nullptr;
+  ETP_REQUIRE(p && p->P && (txt || cached) && txt_mask && step_ids && img && pos && gmask && visited && out_embeds && out_logits &&
+                  stash && B > 0 && L > 0 && G > 0,
               "bad arguments");
   ETP_REQUIRE(!p->cfg.use_sprels || dists, "gmap_pair_dists required when graph_sprels is on");
   Ctx c = make_ctx(p, stream);
@@ -1003,8 +1075,10 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
   const etp_config& cf = p->cfg;
   const int H = c.H, Mg = B * G, Mt = B * L, ldL = (int)round_up(L, 8);
   const float eps = cf.ln_eps;
+  KvCache kc;
+  if (cached) kc = plan_kv(p, kvbuf, B, L);
   const void* txtT = txt;
-  if (c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, s.txtT, (long)Mt * H, c.st)); txtT = s.txtT; }
+  if (!cached && c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, s.txtT, (long)Mt * H, c.st)); txtT = s.txtT; }
   ETP_TRY(gmap_embed_fwd(c.dt, img, step_ids, pos, p->pf(p->step_emb), p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g),
                          p->pf(p->gpos_bb), s.x0.f, lp(s.x0, c.dt), s.st0, Mg, H, cf.ang_feat + 3, c.st));
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
@@ -1012,7 +1086,7 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
   Act x = s.x0;
   // The text K/V projections of ALL x-layers depend only on the text (M = B*L rows, the largest GEMMs of this entry
   // point), not on the node chain: with a side stream they are issued up front and each layer waits for its own.
-  const bool kv_side = c.sw != c.st;
+  const bool kv_side = !cached && c.sw != c.st;
   std::vector<hipEvent_t> kv_ready(cf.n_x);
   if (kv_side) {
     ETP_TRY(stream_after(p, c.st, c.sw));
@@ -1031,9 +1105,10 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     // cross attention nodes -> text (BertXAttention :360-363)
     ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     if (kv_side) ETP_CHECK_HIP(hipStreamWaitEvent(c.st, kv_ready[l], 0));
-    else ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
-    AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
-              nullptr, nullptr};
+    else if (!cached)
+      ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    void* kv = cached ? kc.kv[l] : t.cross.kv;
+    AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_fwd_s(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, Mg, H, H, x.f, hid(c, MODE_NAV, l, SITE_X_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y.f, lp(t.cross.y, c.dt), t.cross.st, Mg, H, eps,
@@ -1049,12 +1124,32 @@ int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
   return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
                       out_logits, s.str, Mg, H, c.st, site(c, p->p_head, MODE_NAV, 0, SITE_HEAD));
 }
+}  // namespace
+extern "C" {
+int etp_nav_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
+                const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
+                float* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
+  ETP_REQUIRE(txt, "txt_embeds required");
+  return nav_fwd_impl(p, txt, nullptr, txt_mask, step_ids, img, pos, gmask, visited, dists, B, L, G, out_embeds, out_logits, stash,
+                      stream);
+}
+int etp_nav_fwd_kv(etp_planner* p, const void* kvbuf, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
+                   const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B, int L, int G,
+                   float* out_embeds, float* out_logits, void* stash, etp_stream_t stream) {
+  ETP_REQUIRE(kvbuf, "K/V cache required");
+  return nav_fwd_impl(p, nullptr, const_cast<void*>(kvbuf), txt_mask, step_ids, img, pos, gmask, visited, dists, B, L, G, out_embeds,
+                      out_logits, stash, stream);
+}
+}  // extern "C"
+namespace {
 
-int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, const float* txt, const uint8_t* txt_mask,
-                const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B,
-                int L, int G, float* d_txt, float* d_img, void* stash, void* ws, etp_stream_t stream) {
-  ETP_REQUIRE(p && p->P && p->G && txt && txt_mask && step_ids && pos && gmask && visited && d_txt && d_img && stash && ws &&
-                  B > 0 && L > 0 && G > 0 && (d_embeds || d_logits),
+int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, const float* txt, const void* kvbuf,
+                 const uint8_t* txt_mask, const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited,
+                 const float* dists, int B, int L, int G, float* d_txt, void* d_kv, float* d_img, void* stash, void* ws,
+                 etp_stream_t stream) {
+  const bool cached = kvbuf != nullptr;
+  ETP_REQUIRE(p && p->P && p->G && (cached ? d_kv != nullptr : (txt && d_txt)) && txt_mask && step_ids && pos && gmask && visited &&
+                  d_img && stash && ws && B > 0 && L > 0 && G > 0 && (d_embeds || d_logits),
               "bad arguments");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
@@ -1070,6 +1165,8 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
   float* dspw = cf.use_sprels ? p->gf(p->sp_w) : nullptr;
   float* dspb = cf.use_sprels ? p->gf(p->sp_b) : nullptr;
   const void* txtT = c.dt == ETP_BF16 ? s.txtT : (const void*)txt;
+  KvCache kc;
+  if (cached) kc = plan_kv(p, const_cast<void*>(kvbuf), B, L);
   const Act xlast = cf.n_x == 0 ? s.x0 : s.layers[cf.n_x - 1].ffn.y;
   float* g = n.g;
   if (d_logits) {
@@ -1081,7 +1178,7 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
   } else {
     ETP_CHECK_HIP(hipMemcpyAsync(g, d_embeds, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   }
-  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
+  if (cf.n_x == 0 && !cached) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
   for (int l = cf.n_x - 1; l >= 0; --l) {
     const XLayerP& q = p->xl[l];
     const XStash& t = s.layers[l];
@@ -1098,12 +1195,16 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
     const void* dso = op2(c, w.t1, dx);
     ETP_TRY(linear_wgrad(c, dso, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
     ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
-    AttnBuf a{t.cross.q, (long)H, t.cross.kv, 2L * H, offs(t.cross.kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr,
-              nullptr, nullptr};
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, xc.dkv, 2L * H, offs(xc.dkv, H, c.es), 2L * H,
+    void* kv = cached ? kc.kv[l] : t.cross.kv;
+    // with the cache, dK|dV of this step go straight to the caller's d_kv block of this layer (summed over the rollout's
+    // steps by the caller, projected back to the text once by etp_nav_kv_bwd)
+    void* dkv_out = cached ? offs(d_kv, (long)l * Mt * 2 * H, c.es) : xc.dkv;
+    AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
                           0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, g, Mg, H, H, w.t1.f));
+    if (cached) { ETP_TRY(flush_side(c)); continue; }
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
     // d_txt accumulates over the layers and is consumed only by the caller: like the weight gradients it is a leaf of
     // this entry point, so it follows the K/V weight gradient on the side stream (in order there: the read-modify-write
@@ -1124,5 +1225,21 @@ int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, co
   ETP_CHECK_HIP(hipMemcpyAsync(d_img, g, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   return join_wgrads(c);
 }
+}  // namespace
 
+extern "C" {
+int etp_nav_bwd(etp_planner* p, const float* d_embeds, const float* d_logits, const float* txt, const uint8_t* txt_mask,
+                const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists, int B,
+                int L, int G, float* d_txt, float* d_img, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(txt && d_txt, "txt_embeds and d_txt_embeds required");
+  return nav_bwd_impl(p, d_embeds, d_logits, txt, nullptr, txt_mask, step_ids, pos, gmask, visited, dists, B, L, G, d_txt, nullptr,
+                      d_img, stash, ws, stream);
+}
+int etp_nav_bwd_kv(etp_planner* p, const float* d_embeds, const float* d_logits, const void* kvbuf, const uint8_t* txt_mask,
+                   const int64_t* step_ids, const float* pos, const uint8_t* gmask, const uint8_t* visited, const float* dists,
+                   int B, int L, int G, void* d_kv, float* d_img, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(kvbuf && d_kv, "K/V cache and d_kv required");
+  return nav_bwd_impl(p, d_embeds, d_logits, nullptr, kvbuf, txt_mask, step_ids, pos, gmask, visited, dists, B, L, G, nullptr, d_kv,
+                      d_img, stash, ws, stream);
+}
 }  // extern "C"

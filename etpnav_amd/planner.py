@@ -99,6 +99,7 @@ class Engine:
         self.shadow = (torch.zeros(self.n_matrix, dtype=torch.bfloat16, device=device)
                        if cconf.dtype == _lib.ETP_BF16 else None)
         self._shadow_version = -1
+        self.epoch = 0                  # bumped by optimizers that update the arena outside torch (FusedAdamW)
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.bind()
 
@@ -134,6 +135,7 @@ class Engine:
     def mark_shadow_current(self):
         """Called by FusedAdamW: its kernel wrote the bf16 shadow together with the fp32 masters."""
         self._shadow_version = self.params._version
+        self.epoch += 1
 
     def set_dropout(self, drop):
         """drop = None (eval) or (p_hidden, p_attn, p_head, p_env, seed); read by the next enqueued entry points."""
@@ -246,6 +248,70 @@ class _NavFn(torch.autograd.Function):
         return None, None, None, d_txt, None, None, d_img, None, None, None, None
 
 
+class _NavKVFn(torch.autograd.Function):
+    """txt_embeds -> K|V of every x-layer (etp_nav_kv_fwd).  Output: one tensor [n_x, B*L, 2H] in the operand dtype that
+    the per-step navigation calls consume; autograd sums their d_kv and this backward projects the sum back once."""
+
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, txt_embeds):
+        B, L, H = txt_embeds.shape
+        cache = eng.buf(eng.L.etp_nav_kv_bytes(eng.handle, B, L))
+        check(eng.L.etp_nav_kv_fwd(eng.handle, ptr(txt_embeds), B, L, ptr(cache), eng.stream()), "etp_nav_kv_fwd")
+        n_x = eng.cconf.n_x
+        # the K|V blocks are contiguous inside the cache buffer: expose them as a typed view (no copy)
+        es = 2 if eng.tdtype == torch.bfloat16 else 4
+        off = int(eng.L.etp_nav_kv_offset(eng.handle, B, L))
+        kv = cache[off:off + n_x * B * L * 2 * H * es].view(eng.tdtype).view(n_x, B * L, 2 * H)
+        ctx.eng, ctx.cache, ctx.dims = eng, cache, (B, L)
+        ctx.save_for_backward(txt_embeds)
+        return kv                        # a view into `cache`: its storage keeps the whole buffer (bf16 text included) alive
+
+    @staticmethod
+    def backward(ctx, d_kv):
+        eng, (B, L) = ctx.eng, ctx.dims
+        (txt_embeds,) = ctx.saved_tensors
+        d_kv = d_kv.to(eng.tdtype).contiguous()
+        d_txt = torch.empty(B, L, eng.cconf.hidden, dtype=torch.float32, device=eng.device)
+        check(eng.L.etp_nav_kv_bwd(eng.handle, ptr(txt_embeds), ptr(d_kv), B, L, ptr(ctx.cache), ptr(d_txt), eng.stream()),
+              "etp_nav_kv_bwd")
+        return None, None, d_txt
+
+
+class _NavCachedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, drop, kv, L, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
+        B, G = step_ids.shape
+        H = eng.cconf.hidden
+        cache = ctypes.c_void_p(kv.data_ptr() - int(eng.L.etp_nav_kv_offset(eng.handle, B, L)))   # base of the cache buffer
+        eng.set_dropout(drop)
+        ctx.drop = drop
+        out = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
+        logits = torch.empty(B, G, dtype=torch.float32, device=eng.device)
+        stash = eng.buf(eng.L.etp_nav_stash_bytes(eng.handle, B, L, G))
+        check(eng.L.etp_nav_fwd_kv(eng.handle, cache, ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts), ptr(gmasks),
+                                   ptr(visited), ptr(dists), B, L, G, ptr(out), ptr(logits), ptr(stash), eng.stream()),
+              "etp_nav_fwd_kv")
+        ctx.eng, ctx.stash, ctx.dims, ctx.cache, ctx.kv_shape = eng, stash, (B, L, G), cache, kv.shape
+        ctx.save_for_backward(txt_masks, step_ids, pos_fts, gmasks, visited, dists, kv)
+        return out, logits
+
+    @staticmethod
+    def backward(ctx, d_out, d_logits):
+        eng, (B, L, G) = ctx.eng, ctx.dims
+        txt_masks, step_ids, pos_fts, gmasks, visited, dists, _kv = ctx.saved_tensors
+        H = eng.cconf.hidden
+        d_out = d_out.float().contiguous() if d_out is not None else None
+        d_logits = d_logits.float().contiguous() if d_logits is not None else None
+        d_kv = torch.empty(ctx.kv_shape, dtype=eng.tdtype, device=eng.device)
+        d_img = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
+        ws = eng.ws(("nav", B, L, G), eng.L.etp_nav_ws_bytes(eng.handle, B, L, G))
+        eng.set_dropout(ctx.drop)
+        check(eng.L.etp_nav_bwd_kv(eng.handle, ptr(d_out), ptr(d_logits), ctx.cache, ptr(txt_masks), ptr(step_ids),
+                                   ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_kv), ptr(d_img),
+                                   ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd_kv")
+        return None, None, None, d_kv, None, None, None, d_img, None, None, None, None
+
+
 class GlocalTextPathNavCMT(nn.Module):
     """Drop-in for vilmodel_cmt.py:663 ``GlocalTextPathNavCMT`` (see module docstring)."""
 
@@ -270,6 +336,9 @@ class GlocalTextPathNavCMT(nn.Module):
         self._anchor = torch.zeros(1, device=self._engine.device, requires_grad=True)
         # training-mode dropout (nn.Module.training, as the reference's nn.Dropout layers): rates from the config,
         # masks from a counter-based generator keyed by (seed, call counter, site, element)
+        # text K/V cache across rollout steps; off = the reference's per-step re-projection
+        self.cache_text_kv = False
+        self._kv_cache = None
         self.drop_env_prob = 0.0          # >0 fuses the policy's drop_env (Policy_ViewSelection_ETP.py:102,345) into forward_panorama
         self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self._drop_calls = 0
@@ -406,12 +475,36 @@ class GlocalTextPathNavCMT(nn.Module):
         return _PanoFn.apply(self._anchor, eng, self._dropout(), rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
                              nav_types.long().contiguous(), view_lens.long().contiguous())
 
+    def _text_kv(self, eng, txt_embeds):
+        """K|V projections of `txt_embeds` for all x-layers, computed once per distinct (tensor, weights) pair.  The
+        rollout passes the SAME txt_embeds tensor at every step (ss_trainer_ETP.py:801-805 computes it once, :878 reuses
+        it), so identity + version of the tensor and of the parameter arena is the cache key; anything else (a sliced or
+        re-computed tensor, an optimizer step) misses and re-projects -- results are identical either way."""
+        key = (id(txt_embeds), txt_embeds._version, tuple(txt_embeds.shape), eng.params._version, eng.epoch,
+               torch.is_grad_enabled() and txt_embeds.requires_grad)
+        hit = self._kv_cache
+        if hit is not None and hit[0] == key and hit[1]() is txt_embeds:
+            return hit[2]
+        import weakref
+        x = txt_embeds.to(torch.float32).contiguous()
+        kv = _NavKVFn.apply(self._anchor, eng, x)
+        self._kv_cache = (key, weakref.ref(txt_embeds), kv)
+        return kv
+
     def forward_navigation(self, txt_embeds, txt_masks, gmap_vpids, gmap_step_ids, gmap_img_fts, gmap_pos_fts,
                            gmap_masks, gmap_visited_masks, gmap_pair_dists):
         """vilmodel_cmt.py:721-750 (gmap_vpids is ignored, as in the reference)."""
         eng = self._prep()
         t = torch.float32
         dists = gmap_pair_dists.float().contiguous() if gmap_pair_dists is not None else None
+        if self.cache_text_kv:
+            kv = self._text_kv(eng, txt_embeds)
+            embeds, logits = _NavCachedFn.apply(self._anchor, eng, self._dropout(), kv, txt_embeds.shape[1],
+                                                txt_masks.to(torch.bool).contiguous(), gmap_step_ids.long().contiguous(),
+                                                gmap_img_fts.to(t).contiguous(), gmap_pos_fts.float().contiguous(),
+                                                gmap_masks.to(torch.bool).contiguous(),
+                                                gmap_visited_masks.to(torch.bool).contiguous(), dists)
+            return {"gmap_embeds": embeds, "global_logits": logits}
         embeds, logits = _NavFn.apply(self._anchor, eng, self._dropout(), txt_embeds.to(t).contiguous(),
                                       txt_masks.to(torch.bool).contiguous(), gmap_step_ids.long().contiguous(),
                                       gmap_img_fts.to(t).contiguous(), gmap_pos_fts.float().contiguous(),

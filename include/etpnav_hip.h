@@ -292,6 +292,29 @@ int etp_nav_bwd(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const fl
                 float* d_txt_embeds /*[B,L,H], overwritten*/, float* d_gmap_img_fts /*[B,G,H], overwritten*/, void* stash,
                 void* ws, etp_stream_t stream);
 
+/* Text K/V cache for rollouts.  The instruction is fixed for an episode, but BertOutAttention
+ * (vilmodel_cmt.py:326-328) re-projects it to keys/values in every x-layer at every step (GraphLXRTXLayer :387-389 called
+ * from the per-step loop ss_trainer_ETP.py:819-892).  Compute the projections once per episode batch and reuse them:
+ *   etp_nav_kv_fwd   txt_embeds -> cache (caller-owned, etp_nav_kv_bytes): [bf16 text | K|V of x-layer 0 | ... ]
+ *   etp_nav_fwd_kv   = etp_nav_fwd reading keys/values from the cache (identical results)
+ *   etp_nav_bwd_kv   = etp_nav_bwd, except that dK|dV of each x-layer are WRITTEN to d_kv [n_x][B*L][2H] (operand dtype,
+ *                      etp_nav_kv_grad_elems elements) instead of being projected back immediately
+ *   etp_nav_kv_bwd   once per episode: d_kv summed over the steps -> gradients of the K/V weights and d_txt_embeds. */
+int64_t etp_nav_kv_bytes(const etp_planner* p, int B, int L);
+int64_t etp_nav_kv_grad_elems(const etp_planner* p, int B, int L);
+int64_t etp_nav_kv_offset(const etp_planner* p, int B, int L);   /* byte offset of the K|V blocks (contiguous, layer-major) */
+int etp_nav_kv_fwd(etp_planner* p, const float* txt_embeds, int B, int L, void* kv_cache, etp_stream_t stream);
+int etp_nav_kv_bwd(etp_planner* p, const float* txt_embeds, const void* d_kv, int B, int L, const void* kv_cache,
+                   float* d_txt_embeds /*[B,L,H], overwritten*/, etp_stream_t stream);
+int etp_nav_fwd_kv(etp_planner* p, const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                   const float* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
+                   const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G, float* gmap_embeds,
+                   float* global_logits, void* stash, etp_stream_t stream);
+int etp_nav_bwd_kv(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const float* d_logits /*or NULL*/,
+                   const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
+                   const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L,
+                   int G, void* d_kv /*overwritten*/, float* d_gmap_img_fts, void* stash, void* ws, etp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * hipGraph helpers (launch-bound inner loops are captured once and replayed) and timing.
  * ---------------------------------------------------------------------------------------------------- */

@@ -258,3 +258,55 @@ def test_bf16_train_mode_step_close_to_oracle_with_same_masks():
     torch.cuda.synchronize()
     assert (model.flat_grads - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-4
     step.close()
+
+
+# ---- text K/V cache across rollout steps -----------------------------------------------------------
+def _rollout(model, batches, txt_ids, txt_masks):
+    """ss_trainer_ETP.py:801-892 in miniature: one forward_txt, then T navigation steps on the SAME txt_embeds, losses
+    summed, one backward."""
+    model.zero_grad()
+    txt = model.forward_txt(txt_ids, txt_masks)
+    outs, loss = [], 0.0
+    for b in batches:
+        o = model.forward_navigation(txt, txt_masks, None, b["gmap_step_ids"], b["gmap_img_fts"], b["gmap_pos_fts"],
+                                     b["gmap_masks"], b["gmap_visited_masks"], b["gmap_pair_dists"])
+        outs.append(o)
+        loss = loss + F.cross_entropy(o["global_logits"], b["labels"], reduction="sum", ignore_index=-100) / txt_ids.shape[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach(), [{k: v.detach().clone() for k, v in o.items()} for o in outs], grads_of(model)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_text_kv_cache_rollout_equals_per_step_projection(dtype, tol):
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=9)
+    B, L, G, T = 3, 22, 9, 3
+    base = po.make_batch(cfg, B=B, L=L, V=8, G=G, seed=40, ragged=True)
+    batches = []
+    for t in range(T):
+        bt = po.make_batch(cfg, B=B, L=L, V=8, G=G, seed=41 + t, ragged=True)
+        gen = torch.Generator().manual_seed(100 + t)
+        bt["gmap_img_fts"] = torch.randn(B, G, cfg.hidden_size, generator=gen) * 0.5
+        batches.append({k: v.cuda() for k, v in bt.items()})
+    model = build_model(cfg, P, dtype)
+    ids, masks = base["txt_ids"].cuda(), base["txt_masks"].cuda()
+    model.cache_text_kv = False
+    loss0, outs0, g0 = _rollout(model, batches, ids, masks)
+    model.cache_text_kv = True
+    loss1, outs1, g1 = _rollout(model, batches, ids, masks)
+    kv_first = model._kv_cache[2]
+    assert abs(loss0.item() - loss1.item()) < tol
+    for a, b in zip(outs0, outs1):
+        fin = torch.isfinite(a["global_logits"])
+        assert torch.equal(fin, torch.isfinite(b["global_logits"]))
+        assert (a["global_logits"][fin] - b["global_logits"][fin]).abs().max().item() < tol
+        assert (a["gmap_embeds"] - b["gmap_embeds"]).abs().max().item() < tol
+    for k in g0:
+        err = (g0[k] - g1[k]).abs().max().item()
+        assert err < tol * (1.0 + 10.0 * g0[k].abs().max().item()), f"{k}: {err}"
+    # one projection served all T steps (same tensor object); a new forward_txt result misses and re-projects
+    txt2 = model.forward_txt(ids, masks)
+    model.forward_navigation(txt2, masks, None, batches[0]["gmap_step_ids"], batches[0]["gmap_img_fts"], batches[0]["gmap_pos_fts"],
+                             batches[0]["gmap_masks"], batches[0]["gmap_visited_masks"], batches[0]["gmap_pair_dists"])
+    assert model._kv_cache[2] is not kv_first
