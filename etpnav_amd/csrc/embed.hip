@@ -668,6 +668,12 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = bf16_to_f32(src[i]) * scale;
 }
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long n) {
+  const long n4 = n / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, long n, float scale) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] *= scale;
@@ -823,6 +829,29 @@ int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream
   const int grid = (int)std::min<long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, scale);
   ETP_CHECK_LAUNCH("cast_bf16_f32");
+  return ETP_OK;
+}
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ dst, long n) {
+  const long n4 = n / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    reinterpret_cast<float4*>(dst)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = 0.f;
+}
+int zero_f32(float* dst, long n, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  const int grid = (int)std::min<long>((n / 4 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(grid), dim3(256), 0, st, dst, n);
+  ETP_CHECK_LAUNCH("zero_f32");
+  return ETP_OK;
+}
+// device-to-device copy as an ordinary kernel: hipMemcpyAsync(D2D) goes through the runtime's blit path, which stalled
+// the issuing stream for 100-300 us per copy in the step's kernel trace (tools/timeline.py, round 1)
+int copy_f32(const float* src, float* dst, long n, hipStream_t st) {
+  if (n <= 0 || src == dst) return ETP_OK;
+  ETP_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "copy_f32: 16-byte aligned buffers required");
+  const int grid = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(256), 0, st, src, dst, n);
+  ETP_CHECK_LAUNCH("copy_f32");
   return ETP_OK;
 }
 int scale_f32(float* p, long n, float scale, hipStream_t st) {

@@ -56,6 +56,8 @@ int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);
 int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStream_t st);   // dst(T) = dropout(src)
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st);
 int scale_f32(float* p, long n, float scale, hipStream_t st);
+int copy_f32(const float* src, float* dst, long n, hipStream_t st);
+int zero_f32(float* dst, long n, hipStream_t st);
 
 // optim.hip: fused AdamW (+ bf16 shadow refresh + gradient zeroing) and the gradient norm / non-finite scan
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,

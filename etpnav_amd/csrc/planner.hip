@@ -525,11 +525,11 @@ static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M
   return ln_fwd_s(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y.f, lp(f.y, c.dt), f.st, M, H, eps, c.st);
 }
 static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f, int M, float* g, const BwdWs& w, int mode,
-                   int layer) {
+                   int layer, const float* g_in = nullptr) {
   const int H = c.H, I = c.I;
   etp_planner* pl = c.pl;
   const Drop dh = hid(c, mode, layer, SITE_FFN_O);
-  ETP_TRY(ln_bwd_s(c.dt, g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
+  ETP_TRY(ln_bwd_s(c.dt, g_in ? g_in : g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
                    c.st, dh));
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, f.h, I, p.o_w, p.o_b, M, H, I));
@@ -662,10 +662,11 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
   Act x = t.x0;
   for (int l = 0; l < p->cfg.n_l; ++l) {
     ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps, MODE_TXT, l));
+    if (l == p->cfg.n_l - 1) t.ffn[l].y.f = out;      // the last LayerNorm writes the API tensor itself (backward never reads it)
     ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps, MODE_TXT, l));
     x = t.ffn[l].y;
   }
-  ETP_CHECK_HIP(hipMemcpyAsync(out, x.f, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
+  if (p->cfg.n_l == 0) ETP_TRY(copy_f32(x.f, out, (long)M * H, c.st));
   return ETP_OK;
 }
 
@@ -684,13 +685,14 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
   Bump wb(ws);
   const int H = c.H, M = B * L;
   float* g = (float*)wb.take((size_t)M * H * 4);
-  if (layer_hi == p->cfg.n_l) ETP_CHECK_HIP(hipMemcpyAsync(g, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
+  if (layer_hi == p->cfg.n_l && p->cfg.n_l == 0) ETP_TRY(copy_f32(dout, g, (long)M * H, c.st));
   for (int l = p->cfg.n_l - 1; l >= 0; --l) {
     const Act x = l == 0 ? t.x0 : t.ffn[l - 1].y;
     BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);   // same carving in every call
     BwdWs wa = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
     if (l >= layer_hi || l < layer_lo) continue;
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l));
+    // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     ETP_TRY(flush_side(c));          // this layer's four weight gradients: one fork
   }
@@ -868,7 +870,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     ETP_TRY(ln_bwd_s(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g.f, lp2(c, g, gd), p->gf(p->pn_g), p->gf(p->pn_b), M, H,
                      c.st, gd));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(g.f, dout, (size_t)M * H * 4, hipMemcpyDeviceToDevice, c.st));
+    ETP_TRY(copy_f32(dout, g.f, (long)M * H, c.st));
   }
   for (int l = cf.n_p - 1; l >= 0; --l) {
     const PanoLayerP& q = p->pano[l];
@@ -1115,10 +1117,14 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
                      c.st));
     // graph self attention with the pairwise-distance bias (:391-393)
     ETP_TRY(self_att_fwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, eps, MODE_NAV, l));
+    // bf16 mode: gmap_embeds is the last LayerNorm's own fp32 output (the head and the backward read the bf16 copy y.t);
+    // fp32 mode keeps the stash copy because there y.t IS y.f
+    const bool direct = l == cf.n_x - 1 && c.dt == ETP_BF16;
+    if (direct) t.ffn.y.f = out_embeds;
     ETP_TRY(ffn_fwd(c, q.ffn, t.self.y, t.ffn, Mg, eps, MODE_NAV, l));
     x = t.ffn.y;
   }
-  ETP_CHECK_HIP(hipMemcpyAsync(out_embeds, x.f, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
+  if (cf.n_x == 0 || c.dt != ETP_BF16) ETP_TRY(copy_f32(x.f, out_embeds, (long)Mg * H, c.st));
   // SAP head: Linear -> ReLU (GEMM epilogue) -> LN -> Linear(H->1) -> masks
   ETP_TRY(linear_fwd(c, x.t, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
   return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
@@ -1176,7 +1182,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(linear_wgrad(c, n.head.t2, H, xlast.t, H, p->sap0_w, p->sap0_b, Mg, H, H));
     ETP_TRY(linear_dgrad_s(c, n.head.t2, H, p->sap0_w, g, Mg, H, H, d_embeds));
   } else {
-    ETP_CHECK_HIP(hipMemcpyAsync(g, d_embeds, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
+    ETP_TRY(copy_f32(d_embeds, g, (long)Mg * H, c.st));
   }
   if (cf.n_x == 0 && !cached) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
   for (int l = cf.n_x - 1; l >= 0; --l) {
@@ -1203,7 +1209,8 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
                           0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
-    ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, g, Mg, H, H, w.t1.f));
+    // layer 0 leaves dL/d(node embeddings) = dL/d(gmap_img_fts) in the caller's d_img directly
+    ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, l == 0 ? d_img : g, Mg, H, H, w.t1.f));
     if (cached) { ETP_TRY(flush_side(c)); continue; }
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
     // d_txt accumulates over the layers and is consumed only by the caller: like the weight gradients it is a leaf of
@@ -1219,10 +1226,10 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     }
     ETP_TRY(flush_side(c));          // this layer's weight gradients + the d_txt contribution: one fork
   }
-  ETP_TRY(gmap_embed_bwd(c.dt, g, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
+  if (cf.n_x == 0) ETP_TRY(copy_f32(g, d_img, (long)Mg * H, c.st));
+  ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));
-  ETP_CHECK_HIP(hipMemcpyAsync(d_img, g, (size_t)Mg * H * 4, hipMemcpyDeviceToDevice, c.st));
   return join_wgrads(c);
 }
 }  // namespace

@@ -94,12 +94,18 @@ def main():
     gap_by = defaultdict(int)
     gap_n = defaultdict(int)
     gap_tot = 0
+    pair_by = defaultdict(int)
+    pair_n = defaultdict(int)
     for prev, cur in zip(chain, chain[1:]):
         gp = cur[0] - prev[1]
         if gp > 0:
             gap_tot += gp
             gap_by[short(cur[2])] += gp
             gap_n[short(cur[2])] += 1
+            if gp > 20000:          # > 20 us: a dependency wait, not launch latency
+                key = (short(prev[2])[:44], short(cur[2])[:44])
+                pair_by[key] += gp
+                pair_n[key] += 1
     us = lambda x: x / a.steps / 1e3
     print(f"steps analysed: {a.steps}   wall/step {wall / 1e3:.1f} us   kernels/step {len(win) / a.steps:.0f}")
     print(f"busy (>=1 kernel) {us(busy):.1f} us/step   idle {wall / 1e3 - us(busy):.1f} us/step")
@@ -109,6 +115,9 @@ def main():
           f" (avg {gap_tot / max(len(chain) - 1, 1) / 1e3:.2f} us per kernel); largest gap owners:")
     for k in sorted(gap_by, key=lambda k: -gap_by[k])[:8]:
         print(f"    {k[:72]:72s} {us(gap_by[k]):8.1f} us/step over {gap_n[k] / a.steps:.0f} launches")
+    print("    waits > 20 us on the chain stream, by (previous kernel -> waiting kernel):")
+    for k in sorted(pair_by, key=lambda k: -pair_by[k])[:10]:
+        print(f"      {k[0]:44s} -> {k[1]:44s} {us(pair_by[k]):8.1f} us/step over {pair_n[k] / a.steps:.1f} waits")
     print(f"{'kernel':72s} {'sum us':>8s} {'excl us':>8s} {'n':>5s} {'avg us':>7s} {'avg WGs':>8s}")
     for k in sorted(tot, key=lambda k: -tot[k])[:a.top]:
         print(f"{k[:72]:72s} {us(tot[k]):8.1f} {us(excl[k]):8.1f} {cnt[k] / a.steps:5.0f} {tot[k] / cnt[k] / 1e3:7.1f} {wgs[k] / cnt[k]:8.0f}")
