@@ -69,7 +69,11 @@ struct AttnBuf {
   const void* Q; long ldq; const void* K; long ldk; const void* V; long ldv;
   int B, Lq, Lk, ldS;
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
+  void* Pd = nullptr;      // unfused path only: second [B,heads,Lq,ldS] buffer for the DROPPED probabilities (training mode)
 };
+// shapes the fused kernels do not take (the batched-GEMM path runs them and needs AttnBuf::Pd for dropout)
+inline bool attn_needs_unfused(int dt, int Lq, int Lk) { return Lq > 128 || Lk > 128 || (dt == ETP_F32 && (Lq > 64 || Lk > 64)); }
+int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS, Drop drop, hipStream_t st);
 // fused single-kernel variants (attn.hip) for Lq, Lk <= 128
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);
 int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);

@@ -420,4 +420,32 @@ int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_
   return ETP_OK;
 }
 
+// dst[row, k] = src[row, k] * mask(row*Lk + k)/(1-p) for k < Lk (pad columns copied): attention-probability dropout of the
+// unfused (Lq or Lk > 128) path; dst may alias src.  Element index = the fused kernels' ((b*heads+h)*Lq + q)*Lk + k.
+template <typename T>
+__global__ __launch_bounds__(256) void drop_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int Lk, int ldS,
+                                                        Drop drop) {
+  const int lane = threadIdx.x & 63;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const T* s = src + row * ldS;
+    T* d = dst + row * ldS;
+    const uint32_t base = (uint32_t)(row * Lk);
+    for (int k = lane; k < ldS; k += 64) {
+      float v = Elem<T>::ld(s + k);
+      if (k < Lk) v *= drop_mult(drop.seed, base + k, drop.p, drop.inv_keep);
+      Elem<T>::st(d + k, v);
+    }
+  }
+}
+int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS, Drop drop, hipStream_t st) {
+  ETP_REQUIRE(src && dst && rows > 0 && Lk > 0 && ldS >= Lk, "bad arguments");
+  const int grid = (int)std::min<long>((rows + 3) / 4, 2048);
+  if (dtype == ETP_BF16)
+    hipLaunchKernelGGL((drop_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Lk, ldS, drop);
+  else
+    hipLaunchKernelGGL((drop_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Lk, ldS, drop);
+  ETP_CHECK_LAUNCH("drop_rows");
+  return ETP_OK;
+}
+
 }  // namespace etp

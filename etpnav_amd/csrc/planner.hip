@@ -364,7 +364,7 @@ static inline void* offs(void* p, long elems, size_t es) { return reinterpret_ca
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   const int dh = 64;
   if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st, drop);
-  ETP_REQUIRE(drop.p == 0.f, "attention dropout is implemented in the fused kernels only (Lq, Lk <= 128; fp32: <= 64)");
+  ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
   GemmArgs g = base_args();
   // S = alpha * Q K^T
   g.A = a.Q; g.lda = a.ldq; g.sAo = (long)a.Lq * a.ldq; g.sAi = dh;
@@ -373,9 +373,14 @@ int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc
   g.M = a.Lq; g.N = a.Lk; g.K = dh; g.nb_inner = nh; g.alpha = alpha;
   ETP_TRY(launch_gemm(dt, dt, 0, 0, g, a.B * nh, st));
   ETP_TRY(softmax_fwd(dt, P, a.keymask, a.dist, a.sp_w, a.sp_b, a.B, nh, a.Lq, a.Lk, a.ldS, a.mask_mode, st));
-  // ctx = P V
+  // ctx = dropout(P) V: P stays undropped for the softmax backward, the dropped copy feeds P.V here and dV in backward
+  const void* Pv = P;
+  if (drop.p > 0.f) {
+    ETP_TRY(drop_rows(dt, P, a.Pd, (long)a.B * nh * a.Lq, a.Lk, a.ldS, drop, st));
+    Pv = a.Pd;
+  }
   GemmArgs h = base_args();
-  h.A = P; h.lda = a.ldS; h.sAo = g.sCo; h.sAi = g.sCi;
+  h.A = Pv; h.lda = a.ldS; h.sAo = g.sCo; h.sAi = g.sCi;
   h.B = a.V; h.ldb = a.ldv; h.sBo = (long)a.Lk * a.ldv; h.sBi = dh;
   h.C = ctx; h.ldc = ldc; h.sCo = (long)a.Lq * ldc; h.sCi = dh;
   h.M = a.Lq; h.N = dh; h.K = a.Lk; h.nb_inner = nh;
@@ -391,7 +396,7 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
     if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
       return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
   }
-  ETP_REQUIRE(drop.p == 0.f, "attention dropout is implemented in the fused kernels only (Lq, Lk <= 128; fp32: <= 64)");
+  ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
   const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;
   // dP = dctx V^T
   GemmArgs g = base_args();
@@ -400,9 +405,10 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   g.C = dP; g.ldc = a.ldS; g.sCo = sPo; g.sCi = sPi;
   g.M = a.Lq; g.N = a.Lk; g.K = dh; g.nb_inner = nh;
   ETP_TRY(launch_gemm(dt, dt, 0, 0, g, a.B * nh, st));
-  // dV = P^T dctx
+  if (drop.p > 0.f) ETP_TRY(drop_rows(dt, dP, dP, (long)a.B * nh * a.Lq, a.Lk, a.ldS, drop, st));   // dP = dP_dropped * mask/(1-p)
+  // dV = dropout(P)^T dctx
   GemmArgs v = base_args();
-  v.A = P; v.lda = a.ldS; v.sAo = sPo; v.sAi = sPi;
+  v.A = drop.p > 0.f ? a.Pd : P; v.lda = a.ldS; v.sAo = sPo; v.sAi = sPi;
   v.B = dctx; v.ldb = ldd; v.sBo = (long)a.Lq * ldd; v.sBi = dh;
   v.C = dV; v.ldc = lddv; v.sCo = (long)a.Lk * lddv; v.sCi = dh;
   v.M = a.Lk; v.N = dh; v.K = a.Lq; v.nb_inner = nh;
@@ -447,9 +453,9 @@ static inline void* lp2(const Ctx& c, const Act& a, const Drop& d) { return (c.d
 static inline const void* op2(const Ctx& c, const Act& a, const Drop& d) { return (c.dt == ETP_BF16 || d.p > 0.f) ? a.t : (void*)a.f; }
 
 // ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
-struct SelfAttStash { void *qkv, *P, *ctx; float* s; float* st; Act y; };
+struct SelfAttStash { void *qkv, *P, *ctx; float* s; float* st; Act y; void* Pd; };
 struct FfnStash { void *z, *h; float* s; float* st; Act y; };
-struct CrossStash { void *q, *kv, *P, *ctx; float* s; float* st; Act y; };
+struct CrossStash { void *q, *kv, *P, *ctx; float* s; float* st; Act y; void* Pd; };
 
 static SelfAttStash plan_self(Bump& b, int dt, long M, int Bn, int nh, int L, int ldS, int H) {
   const size_t es = dtype_size(dt);
@@ -460,6 +466,7 @@ static SelfAttStash plan_self(Bump& b, int dt, long M, int Bn, int nh, int L, in
   s.s = (float*)b.take(M * H * 4);
   s.st = (float*)b.take(M * 2 * sizeof(float));
   s.y = take_act(b, dt, M * H);
+  s.Pd = attn_needs_unfused(dt, L, L) ? b.take((size_t)Bn * nh * L * ldS * es) : nullptr;   // dropped P (training, unfused path)
   return s;
 }
 static FfnStash plan_ffn(Bump& b, int dt, long M, int H, int I) {
@@ -494,6 +501,7 @@ static int self_att_fwd(const Ctx& c, const AttnP& p, const Act& x, SelfAttStash
   ETP_TRY(linear_fwd(c, x.t, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
+  a.Pd = s.Pd;
   ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_fwd_s(c, s.ctx, H, p.o_w, p.o_b, s.s, M, H, H, x.f, hid(c, mode, layer, SITE_ATT_O)));
   return ln_fwd_s(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y.f, lp(s.y, c.dt), s.st, M, H, eps, c.st);
@@ -512,6 +520,7 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
   ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t2 = dctx
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
+  a.Pd = s.Pd;
   ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, w.t2, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
                         offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
@@ -712,7 +721,7 @@ int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uin
 // forward_panorama
 // ======================================================================================
 namespace {
-struct PanoLayerStash { void* a; float* st1; void *qkv, *P, *ctx; float* x1; void* f; float* st2; void *z, *h; float* x2; };
+struct PanoLayerStash { void* a; float* st1; void *qkv, *P, *ctx; float* x1; void* f; float* st2; void *z, *h; float* x2; void* Pd; };
 struct PanoStash {
   void *rgbT, *depT, *a, *d; float* est; float* x0; uint8_t* mask;
   std::vector<PanoLayerStash> layers;
@@ -744,6 +753,7 @@ PanoStash plan_pano(const etp_planner* pl, Bump& b, int Bn, int V) {
     q.z = b.take(M * I * es);
     q.h = b.take(M * I * es);
     q.x2 = (float*)b.take(M * H * 4);
+    q.Pd = attn_needs_unfused(c.dtype, V, V) ? b.take((size_t)Bn * c.heads * V * ldS * es) : nullptr;
     s.layers.push_back(q);
   }
   s.stn = (float*)b.take(M * 2 * sizeof(float));
@@ -838,6 +848,7 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
     ETP_TRY(linear_fwd(c, t.a, H, q.in_w, q.in_b, t.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
+    a.Pd = t.Pd;
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));   // MHA dropout = hidden rate
     ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x, hid(c, MODE_PANO, l, SITE_ATT_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), c.dt == ETP_BF16 ? nullptr : (float*)t.f,
@@ -893,6 +904,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     ETP_TRY(linear_dgrad(c, t2op, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
+    a.Pd = t.Pd;
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
                           offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
@@ -946,6 +958,7 @@ NavStash plan_nav(const etp_planner* pl, Bump& b, int Bn, int L, int G) {
     x.cross.s = (float*)b.take(Mg * H * 4);
     x.cross.st = (float*)b.take(Mg * 2 * sizeof(float));
     x.cross.y = take_act(b, dt, Mg * H);
+    x.cross.Pd = attn_needs_unfused(dt, G, L) ? b.take((size_t)Bn * c.heads * G * ldL * es) : nullptr;
     x.self = plan_self(b, dt, Mg, Bn, c.heads, G, ldG, H);
     x.ffn = plan_ffn(b, dt, Mg, H, c.inter);
     s.layers.push_back(x);
@@ -1111,6 +1124,7 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
       ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     void* kv = cached ? kc.kv[l] : t.cross.kv;
     AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
+    a.Pd = t.cross.Pd;
     ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.cross.P, t.cross.ctx, H, 0.125f, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_fwd_s(c, t.cross.ctx, H, q.xo_w, q.xo_b, t.cross.s, Mg, H, H, x.f, hid(c, MODE_NAV, l, SITE_X_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.cross.s, p->pf(q.xln_g), p->pf(q.xln_b), t.cross.y.f, lp(t.cross.y, c.dt), t.cross.st, Mg, H, eps,
@@ -1206,6 +1220,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     // steps by the caller, projected back to the text once by etp_nav_kv_bwd)
     void* dkv_out = cached ? offs(d_kv, (long)l * Mt * 2 * H, c.es) : xc.dkv;
     AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
+    a.Pd = t.cross.Pd;
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
                           0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));

@@ -240,7 +240,8 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
  *   p_head    ClsPrediction dropout (:657, pred_head_dropout_prob);
  *   p_env     the policy's drop_env on the RGB features (Policy_ViewSelection_ETP.py:102,345) fused into the operand
  *             cast of forward_panorama (0 = leave it to the caller, as the reference does).
- * Needs the fused attention kernels (Lq, Lk <= 128; fp32 mode <= 64): the unfused fallback returns an error. */
+ * Sequences beyond the fused attention kernels (Lq or Lk > 128; fp32 mode > 64, e.g. the 512-token RxR instruction) take
+ * the batched-GEMM attention path, whose stash then carries a second probability buffer for the dropped copy. */
 int etp_planner_set_dropout(etp_planner* p, float p_hidden, float p_attn, float p_head, float p_env, uint64_t seed);
 /* Host-side view of the mask generator (tests, debugging): out_host[i] = multiplier (0 or 1/(1-p)) of element i (row-major
  * index into the site's tensor) at site (mode 1=txt 2=panorama 3=navigation, layer, slot) for step seed `seed`.  Slots:

@@ -160,13 +160,14 @@ def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3):
         assert err < atol + rel * g.abs().max().item(), f"{k}: {err}"
 
 
-def test_fp32_train_mode_step_matches_oracle_with_same_masks():
+@pytest.mark.parametrize("L", [21, 70])      # 70 > 64: fp32 mode leaves the fused attention kernels (batched-GEMM path + drop_rows)
+def test_fp32_train_mode_step_matches_oracle_with_same_masks(L):
     """policy.train() (ss_trainer_ETP.py:483): every dropout of the path active.  The oracle applies the same masks at
     the reference's dropout sites, so outputs and all gradients must agree to fp32 accuracy; two steps draw different
     masks; rates 0 reproduce eval."""
     cfg = po.PlannerConfig.r2r(vocab_size=2048)
     P = po.init_params(cfg, seed=4)
-    batch = po.make_batch(cfg, B=3, L=21, V=12, G=9, seed=17, ragged=True)
+    batch = po.make_batch(cfg, B=3, L=L, V=12, G=9, seed=17, ragged=True)
     model = build_model(cfg, P, torch.float32)
     step = PlannerStep(model, batch, dropout=RATES, drop_seed=77)
     for k in (1, 2):
