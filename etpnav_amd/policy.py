@@ -14,10 +14,13 @@ from .vlnbert_init import get_vlnbert_models
 
 
 class ETP(nn.Module):
-    def __init__(self, model_config=None, dtype: torch.dtype = torch.bfloat16, device=None):
+    def __init__(self, model_config=None, dtype: torch.dtype = torch.bfloat16, device=None, fuse_drop_env: bool = True):
         super().__init__()
         self.vln_bert = get_vlnbert_models(config=model_config, dtype=dtype, device=device)
         self.drop_env = nn.Dropout(p=0.4)          # Policy_ViewSelection_ETP.py:102
+        # fused: the p=0.4 feature dropout rides in forward_panorama's operand cast (and its mask is recomputed for the
+        # img_linear weight gradient and d rgb_fts) instead of a separate elementwise pass over [B,V,F] + a saved mask
+        self.fuse_drop_env = fuse_drop_env
 
     def forward(self, mode=None, txt_ids=None, txt_masks=None, txt_embeds=None, waypoint_predictor=None,
                 observations=None, in_train=True, rgb_fts=None, dep_fts=None, loc_fts=None, nav_types=None,
@@ -26,7 +29,11 @@ class ETP(nn.Module):
         if mode == "language":
             return self.vln_bert.forward_txt(txt_ids, txt_masks)
         if mode == "panorama":
-            rgb_fts = self.drop_env(rgb_fts)       # :345 (identity in eval())
+            if self.fuse_drop_env:
+                self.vln_bert.drop_env_prob = self.drop_env.p if self.training else 0.0
+            else:
+                self.vln_bert.drop_env_prob = 0.0
+                rgb_fts = self.drop_env(rgb_fts)   # :345 (identity in eval())
             return self.vln_bert.forward_panorama(rgb_fts, dep_fts, loc_fts, nav_types, view_lens)
         if mode == "navigation":
             return self.vln_bert.forward_navigation(txt_embeds, txt_masks, gmap_vp_ids, gmap_step_ids, gmap_img_fts,
