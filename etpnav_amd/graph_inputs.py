@@ -1,0 +1,224 @@
+"""Graph inputs of forward_navigation assembled on the device.
+
+The reference rebuilds, at every rollout step and on the host, everything forward_navigation needs besides the node
+embeddings: ``RLTrainer._nav_gmap_variable`` (ss_trainer_ETP.py:344-417) walks Python dicts of every episode's
+``GraphMap``, which itself re-runs networkx all-pairs Dijkstra after every update (graph_utils.py:256-257), fills the
+pairwise distance matrix in an O(G^2) Python loop and copies six tensors to the GPU.  Here the host only keeps COMPACT
+arrays per episode (positions, edge lengths, ghost fronts) and one kernel launch (``etp_gmap_assemble``) produces the padded
+device tensors.
+
+* ``pack_episode(gmap, cur_vp, cur_pos, cur_heading)`` reads any object with the reference GraphMap's attributes
+  (``node_pos, node_stepId, ghost_aug_pos, ghost_fronts`` and either ``graph_nx`` or ``edges``) — so the reference's own
+  GraphMap can be used unchanged;
+* ``GraphMapLite`` is a numpy-only GraphMap with the same update rules (graph_utils.py:118-257) that simply skips the
+  per-step Dijkstra (the device does the shortest paths);
+* ``nav_gmap_variable(gmaps, cur_vp, cur_pos, cur_heading, device)`` returns the same dict as the reference method
+  (without ``gmap_img_fts``, which is a stack of embedding tensors and stays a torch op / ``etp_gather_sum``).
+
+``cur_heading`` is the scalar heading (radians) that the reference obtains with ``heading_from_quaternion(cur_ori)``
+(graph_utils.py:54-59); quaternion handling belongs to the simulator side and is out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+MAX_NODES, MAX_GHOSTS = 64, 192      # limits of etp_gmap_assemble (csrc/graph.hip)
+
+
+def _dist(a, b) -> float:
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(((b - a) ** 2).sum()))          # calc_position_distance graph_utils.py:13-19
+
+
+class GraphMapLite:
+    """GraphMap (graph_utils.py:118-257) without networkx: same node / ghost bookkeeping, edges kept as a dict; shortest
+    paths are left to the device.  Embeddings are stored as given (tensors), exactly like the reference."""
+
+    def __init__(self, has_real_pos: bool, loc_noise: float, merge_ghost: bool, ghost_aug: float, rng=None):
+        self.node_pos: Dict[str, np.ndarray] = {}
+        self.node_embeds: Dict[str, object] = {}
+        self.node_stepId: Dict[str, int] = {}
+        self.edges: Dict[tuple, float] = {}
+        self.ghost_cnt = 0
+        self.ghost_pos: Dict[str, list] = {}
+        self.ghost_mean_pos: Dict[str, np.ndarray] = {}
+        self.ghost_aug_pos: Dict[str, np.ndarray] = {}
+        self.ghost_embeds: Dict[str, list] = {}
+        self.ghost_fronts: Dict[str, list] = {}
+        self.ghost_real_pos: Dict[str, list] = {}
+        self.has_real_pos, self.merge_ghost, self.ghost_aug, self.loc_noise = has_real_pos, merge_ghost, ghost_aug, loc_noise
+        self.rng = rng if rng is not None else np.random
+
+    def _localize(self, qpos, kpos_dict):                   # graph_utils.py:146-158
+        min_dis, min_vp = 10000, None
+        for kvp, kpos in kpos_dict.items():
+            dis = float(((np.asarray(qpos) - np.asarray(kpos)) ** 2).sum() ** 0.5)
+            if dis < min_dis:
+                min_dis, min_vp = dis, kvp
+        return None if min_dis > self.loc_noise else min_vp
+
+    def identify_node(self, cur_pos, cur_heading, cand_ang, cand_dis):      # :160-166 + estimate_cand_pos :61-71
+        cur_vp = str(len(self.node_pos))
+        cand_vp = [f"{cur_vp}_{i}" for i in range(len(cand_ang))]
+        ang = (float(cur_heading) + np.asarray(cand_ang, dtype=np.float64)) % (2 * np.pi)
+        dis = np.asarray(cand_dis, dtype=np.float64)
+        cand_pos = np.zeros((len(cand_vp), 3))
+        cand_pos[:, 0] = cur_pos[0] - dis * np.sin(ang)
+        cand_pos[:, 1] = cur_pos[1]
+        cand_pos[:, 2] = cur_pos[2] - dis * np.cos(ang)
+        return cur_vp, cand_vp, [p for p in cand_pos]
+
+    def _add_edge(self, u, v, w):
+        self.edges[(u, v) if u <= v else (v, u)] = float(w)
+
+    def delete_ghost(self, vp):                              # :168-175
+        for d in (self.ghost_pos, self.ghost_mean_pos, self.ghost_embeds, self.ghost_fronts):
+            d.pop(vp)
+        self.ghost_aug_pos.pop(vp, None)
+        if self.has_real_pos:
+            self.ghost_real_pos.pop(vp)
+
+    def update_graph(self, prev_vp, step_id, cur_vp, cur_pos, cur_embeds, cand_vp, cand_pos, cand_embeds, cand_real_pos):
+        """graph_utils.py:177-257 minus the two networkx calls at the end."""
+        if prev_vp is not None:
+            self._add_edge(prev_vp, cur_vp, _dist(self.node_pos[prev_vp], cur_pos))
+        self.node_pos[cur_vp] = np.asarray(cur_pos, dtype=np.float64)
+        self.node_embeds[cur_vp] = cur_embeds
+        self.node_stepId[cur_vp] = step_id
+        for i, (cvp, cpos, cembeds) in enumerate(zip(cand_vp, cand_pos, cand_embeds)):
+            cpos = np.asarray(cpos, dtype=np.float64)
+            localized_nvp = self._localize(cpos, self.node_pos)
+            if localized_nvp is not None:
+                self._add_edge(cur_vp, localized_nvp, _dist(cur_pos, self.node_pos[localized_nvp]))
+                continue
+            localized_gvp = self._localize(cpos, self.ghost_mean_pos) if self.merge_ghost else None
+            if localized_gvp is None:
+                gvp = f"g{self.ghost_cnt}"
+                self.ghost_cnt += 1
+                self.ghost_pos[gvp] = [cpos]
+                self.ghost_mean_pos[gvp] = cpos
+                self.ghost_embeds[gvp] = [cembeds, 1]
+                self.ghost_fronts[gvp] = [cur_vp]
+                if self.has_real_pos:
+                    self.ghost_real_pos[gvp] = [cand_real_pos[i]]
+            else:
+                gvp = localized_gvp
+                self.ghost_pos[gvp].append(cpos)
+                self.ghost_mean_pos[gvp] = np.mean(self.ghost_pos[gvp], axis=0)
+                self.ghost_embeds[gvp][0] = self.ghost_embeds[gvp][0] + cembeds
+                self.ghost_embeds[gvp][1] += 1
+                self.ghost_fronts[gvp].append(cur_vp)
+                if self.has_real_pos:
+                    self.ghost_real_pos[gvp].append(cand_real_pos[i])
+        self.ghost_aug_pos = {k: np.array(v, dtype=np.float64) for k, v in self.ghost_mean_pos.items()}
+        if self.ghost_aug != 0:                              # :246-252
+            for gvp, gpos in self.ghost_aug_pos.items():
+                noise = self.rng.normal(loc=(0, 0, 0), scale=(self.ghost_aug, 0, self.ghost_aug), size=(3,))
+                noise = np.clip(noise, -self.ghost_aug, self.ghost_aug)
+                self.ghost_aug_pos[gvp] = gpos + noise
+
+    def get_node_embeds(self, vp):                           # :272-276
+        if not vp.startswith("g"):
+            return self.node_embeds[vp]
+        return self.ghost_embeds[vp][0] / self.ghost_embeds[vp][1]
+
+
+def pack_episode(gmap, cur_vp: str, cur_pos, cur_heading: float) -> dict:
+    """Compact arrays of one episode from a GraphMap-like object (reference GraphMap or GraphMapLite)."""
+    nodes = list(gmap.node_pos.keys())
+    ghosts = list(gmap.ghost_pos.keys())
+    idx = {vp: i for i, vp in enumerate(nodes)}
+    n, m = len(nodes), len(ghosts)
+    adj = np.full((n, n), -1.0, dtype=np.float64)
+    if hasattr(gmap, "graph_nx"):
+        edge_iter = ((u, v, w) for u, v, w in gmap.graph_nx.edges(data="weight"))
+    else:
+        edge_iter = ((u, v, w) for (u, v), w in gmap.edges.items())
+    for u, v, w in edge_iter:
+        adj[idx[u], idx[v]] = adj[idx[v], idx[u]] = w
+    return {
+        "n_nodes": n, "n_ghost": m,
+        "node_pos": np.array([gmap.node_pos[vp] for vp in nodes], dtype=np.float64).reshape(n, 3),
+        "node_step": np.array([gmap.node_stepId[vp] for vp in nodes], dtype=np.int64),
+        "adj": adj,
+        "ghost_pos": np.array([gmap.ghost_aug_pos[vp] for vp in ghosts], dtype=np.float64).reshape(m, 3),
+        "ghost_fronts": [[idx[f] for f in gmap.ghost_fronts[vp]] for vp in ghosts],
+        "cur_node": idx[cur_vp], "cur_pos": np.asarray(cur_pos, dtype=np.float64), "cur_heading": float(cur_heading),
+    }
+
+
+def pack_batch(episodes: Sequence[dict]) -> Dict[str, np.ndarray]:
+    """Pad the per-episode arrays to batch maxima (host side, O(total nodes + edges))."""
+    B = len(episodes)
+    Nmax = max(1, max(e["n_nodes"] for e in episodes))
+    Mmax = max(e["n_ghost"] for e in episodes)
+    Fmax = max(1, max(sum(len(f) for f in e["ghost_fronts"]) for e in episodes))
+    if Nmax > MAX_NODES or Mmax > MAX_GHOSTS:
+        raise ValueError(f"etp_gmap_assemble handles <= {MAX_NODES} visited nodes and <= {MAX_GHOSTS} ghosts per episode")
+    out = {
+        "node_pos": np.zeros((B, Nmax, 3), np.float32), "node_step": np.zeros((B, Nmax), np.int32),
+        "n_nodes": np.zeros(B, np.int32), "adj": np.full((B, Nmax, Nmax), -1.0, np.float32),
+        "ghost_pos": np.zeros((B, max(Mmax, 1), 3), np.float32), "n_ghost": np.zeros(B, np.int32),
+        "front_ptr": np.zeros((B, Mmax + 1), np.int32), "front_idx": np.zeros((B, Fmax), np.int32),
+        "cur_node": np.zeros(B, np.int32), "cur_pos": np.zeros((B, 3), np.float32), "cur_heading": np.zeros(B, np.float32),
+    }
+    for b, e in enumerate(episodes):
+        n, m = e["n_nodes"], e["n_ghost"]
+        out["n_nodes"][b], out["n_ghost"][b] = n, m
+        out["node_pos"][b, :n] = e["node_pos"]
+        out["node_step"][b, :n] = e["node_step"]
+        out["adj"][b, :n, :n] = e["adj"]
+        if m:
+            out["ghost_pos"][b, :m] = e["ghost_pos"]
+        q = 0
+        for g, fr in enumerate(e["ghost_fronts"]):
+            out["front_idx"][b, q:q + len(fr)] = fr
+            q += len(fr)
+            out["front_ptr"][b, g + 1] = q
+        out["front_ptr"][b, m + 1:] = q
+        out["cur_node"][b], out["cur_pos"][b], out["cur_heading"][b] = e["cur_node"], e["cur_pos"], e["cur_heading"]
+    out["_dims"] = (B, Nmax, Mmax, Fmax)
+    return out
+
+
+def assemble_on_device(batch: Dict[str, np.ndarray], device, G: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """One H2D copy per compact array + one kernel.  Raises without the HIP library / a GPU (no CPU fallback)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.EtpError("etp_gmap_assemble needs an MI355X (cuda/hip device); no CPU fallback exists")
+    L = _lib.lib()
+    B, Nmax, Mmax, Fmax = batch["_dims"]
+    need = int((1 + batch["n_nodes"] + batch["n_ghost"]).max())
+    G = need if G is None else G
+    if G < need:
+        raise ValueError(f"G={G} < 1 + nodes + ghosts = {need}")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch.items() if k != "_dims"}
+    out = {
+        "gmap_step_ids": torch.empty(B, G, dtype=torch.int64, device=dev),
+        "gmap_masks": torch.empty(B, G, dtype=torch.bool, device=dev),
+        "gmap_visited_masks": torch.empty(B, G, dtype=torch.bool, device=dev),
+        "gmap_pos_fts": torch.empty(B, G, 7, dtype=torch.float32, device=dev),
+        "gmap_pair_dists": torch.empty(B, G, G, dtype=torch.float32, device=dev),
+    }
+    check(L.etp_gmap_assemble(ptr(t["node_pos"]), ptr(t["node_step"]), ptr(t["n_nodes"]), ptr(t["adj"]), ptr(t["ghost_pos"]),
+                              ptr(t["n_ghost"]), ptr(t["front_ptr"]), ptr(t["front_idx"]), ptr(t["cur_node"]), ptr(t["cur_pos"]),
+                              ptr(t["cur_heading"]), B, Nmax, Mmax, Fmax, G, ptr(out["gmap_step_ids"]), ptr(out["gmap_masks"]),
+                              ptr(out["gmap_visited_masks"]), ptr(out["gmap_pos_fts"]), ptr(out["gmap_pair_dists"]),
+                              torch.cuda.current_stream(dev).cuda_stream), "etp_gmap_assemble")
+    return out
+
+
+def nav_gmap_variable(gmaps: Sequence, cur_vp: Sequence[str], cur_pos, cur_heading: Sequence[float], device) -> dict:
+    """Drop-in for RLTrainer._nav_gmap_variable (ss_trainer_ETP.py:344-417) minus ``gmap_img_fts`` (see module docstring);
+    ``cur_heading[i]`` replaces ``cur_ori[i]`` (= heading_from_quaternion(cur_ori[i]))."""
+    eps = [pack_episode(g, cur_vp[i], cur_pos[i], cur_heading[i]) for i, g in enumerate(gmaps)]
+    out = assemble_on_device(pack_batch(eps), device)
+    out["gmap_vp_ids"] = [[None] + list(g.node_pos.keys()) + list(g.ghost_pos.keys()) for g in gmaps]
+    out["no_vp_left"] = [len(g.ghost_pos) == 0 for g in gmaps]
+    return out

@@ -316,6 +316,23 @@ int etp_nav_bwd_kv(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const
                    const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L,
                    int G, void* d_kv /*overwritten*/, float* d_gmap_img_fts, void* stash, void* ws, etp_stream_t stream);
 
+/* Device-side graph-input assembly: everything RLTrainer._nav_gmap_variable computes on the host
+ * besides the node embeddings (ss_trainer_ETP.py:344-417) -- all-pairs shortest paths over the visited-node graph
+ * (GraphMap.update_graph's networkx Dijkstra, graph_utils.py:256-257), nearest front of each ghost (:259-270), the 7-d
+ * position features of GraphMap.get_pos_fts (:278-322), step ids, masks and the pairwise distance matrix (:371-387) --
+ * from compact per-episode arrays.  One workgroup per episode; <= 64 visited nodes and <= 192 ghosts per episode.
+ *   node_pos [B,Nmax,3], node_step [B,Nmax], n_nodes [B], adj [B,Nmax,Nmax] (edge length, < 0 = no edge, symmetric),
+ *   ghost_pos [B,Mmax,3] (ghost_aug_pos), n_ghost [B], front_ptr [B,Mmax+1] + front_idx [B,Fmax] (CSR per episode: node
+ *   indices of each ghost's fronts, in the reference's list order), cur_node [B], cur_pos [B,3], cur_heading [B] (radians;
+ *   heading_from_quaternion stays with the caller).  Outputs padded to G >= 1 + n_nodes + n_ghost entries per episode,
+ *   ordered [stop], visited nodes, ghosts: gmap_step_ids [B,G] i64, gmap_masks / gmap_visited_masks [B,G] u8,
+ *   gmap_pos_fts [B,G,7] f32, gmap_pair_dists [B,G,G] f32. */
+int etp_gmap_assemble(const float* node_pos, const int32_t* node_step, const int32_t* n_nodes, const float* adj,
+                      const float* ghost_pos, const int32_t* n_ghost, const int32_t* front_ptr, const int32_t* front_idx,
+                      const int32_t* cur_node, const float* cur_pos, const float* cur_heading, int B, int Nmax, int Mmax,
+                      int Fmax, int G, int64_t* gmap_step_ids, uint8_t* gmap_masks, uint8_t* gmap_visited_masks,
+                      float* gmap_pos_fts, float* gmap_pair_dists, etp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * hipGraph helpers (launch-bound inner loops are captured once and replayed) and timing.
  * ---------------------------------------------------------------------------------------------------- */

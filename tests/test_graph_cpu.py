@@ -1,0 +1,57 @@
+"""Graph-input assembly: the CPU oracle and the host-side GraphMapLite against golden vectors produced
+by the reference's REAL GraphMap class (tests/golden/graph_inputs.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph_oracle as go
+from tests.graph_util import load_episodes
+from etpnav_amd import _lib
+from etpnav_amd.graph_inputs import GraphMapLite, pack_episode, pack_batch, assemble_on_device
+
+
+def test_oracle_matches_real_graphmap_outputs():
+    eps, outs = load_episodes()
+    assert len(eps) == len(go.GOLDEN_EPISODES)
+    for ep, want in zip(eps, outs):
+        L = 1 + ep["n_nodes"] + ep["n_ghost"]
+        got = go.assemble(ep, G=L + 3)                       # 3 padded entries: must come out as zeros / False
+        assert np.array_equal(got["gmap_step_ids"][:L], want["gmap_step_ids"]) and not got["gmap_step_ids"][L:].any()
+        assert np.array_equal(got["gmap_visited_masks"][:L], want["gmap_visited_masks"])
+        assert got["gmap_masks"][:L].all() and not got["gmap_masks"][L:].any()
+        assert np.abs(got["gmap_pos_fts"][:L] - want["gmap_pos_fts"]).max() < 2e-6
+        assert not got["gmap_pos_fts"][L:].any()
+        assert np.abs(got["gmap_pair_dists"][:L, :L] - want["gmap_pair_dists"]).max() < 2e-6
+        assert not got["gmap_pair_dists"][L:].any() and not got["gmap_pair_dists"][:, L:].any()
+
+
+def test_graphmaplite_replays_the_reference_bookkeeping():
+    """Same synthetic episodes, same driver, our numpy-only GraphMapLite instead of the reference class: node / ghost
+    sets, positions, edges, ghost fronts and step ids must come out identical (localisation, ghost merging, deletion)."""
+    eps, _ = load_episodes()
+    for e, (seed, steps) in enumerate(go.GOLDEN_EPISODES):
+        gmap, cur_vp, cur_pos, cur_heading = go.simulate(GraphMapLite, seed, steps, merge_ghost=(e % 2 == 0))
+        mine = pack_episode(gmap, cur_vp, cur_pos, cur_heading)
+        ref = eps[e]
+        assert mine["n_nodes"] == ref["n_nodes"] and mine["n_ghost"] == ref["n_ghost"] and mine["cur_node"] == ref["cur_node"]
+        for k in ("node_pos", "node_step", "adj", "ghost_pos", "cur_pos"):
+            assert np.allclose(mine[k], ref[k], atol=1e-12), (e, k)
+        assert [list(f) for f in mine["ghost_fronts"]] == [list(f) for f in ref["ghost_fronts"]]
+        assert abs(mine["cur_heading"] - ref["cur_heading"]) < 1e-12
+
+
+def test_pack_batch_layout_and_limits():
+    eps, _ = load_episodes()
+    b = pack_batch(eps)
+    B, Nmax, Mmax, Fmax = b["_dims"]
+    assert B == len(eps) and Nmax == max(e["n_nodes"] for e in eps) and Mmax == max(e["n_ghost"] for e in eps)
+    assert b["adj"].shape == (B, Nmax, Nmax) and (b["adj"][0, 1:, :] == -1).all()           # padded rows: no edges
+    for i, e in enumerate(eps):
+        assert b["front_ptr"][i, e["n_ghost"]] == sum(len(f) for f in e["ghost_fronts"])
+        assert (b["front_ptr"][i, e["n_ghost"]:] == b["front_ptr"][i, e["n_ghost"]]).all()
+    big = dict(eps[0]); big["n_nodes"] = 65
+    with pytest.raises(ValueError):
+        pack_batch([big])
+    assert _lib.lib().etp_gmap_assemble is not None
+    with pytest.raises(_lib.EtpError):
+        assemble_on_device(b, "cpu")                          # no CPU fallback
