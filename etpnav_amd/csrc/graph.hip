@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void gmap_assemble_kernel(const GmapArgs a) {
   }
   // pairwise distances (ss_trainer_ETP.py:371-387): anchor node + extra distance of every entry
   for (int e = tid; e < G * G; e += 256) {
-    const int j = e / G, k = e % G;
-    float v = 0.f;
-    if (j >= 1 && k >= 1 && j < L && k < L && j != k) {
+    const int j = min(e / G, e % G), k = max(e / G, e % G);        // evaluate (j<k) once: the matrix is exactly symmetric,
+    float v = 0.f;                                                 // as the reference's pair[j,k] = pair[k,j] = dist
+    if (j >= 1 && k < L && j != k) {
       const int aj = j <= n ? j - 1 : fv[j - 1 - n], ak = k <= n ? k - 1 : fv[k - 1 - n];
       const float dj = j <= n ? 0.f : fd[j - 1 - n], dk = k <= n ? 0.f : fd[k - 1 - n];
       v = (dj + D[aj][ak] + dk) / G_MAX_DIST;
