@@ -130,6 +130,37 @@ __global__ __launch_bounds__(256) void gmap_assemble_kernel(const GmapArgs a) {
   }
 }
 
+// RLTrainer._vp_feature_variable (ss_trainer_ETP.py:308-342): per episode, the candidate-view features first, then the
+// panorama views that are not a candidate's image in index order; zero-padded to the batch maximum; nav_types 1 / 0.
+// One workgroup per output row.  cand: packed [sum K, F] with cand_ptr [B+1]; pano: [B, P, F] (pano_bstride = P*F) or one
+// shared [P, F] table (pano_bstride = 0, the pano_angle_fts case); cand_mask [B, P].
+__global__ __launch_bounds__(256) void vp_gather_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cand_ptr,
+                                                        const float* __restrict__ pano, long pano_bstride,
+                                                        const uint8_t* __restrict__ cand_mask, int P, int F, int V,
+                                                        float* __restrict__ out, int64_t* __restrict__ nav_types,
+                                                        int64_t* __restrict__ view_lens) {
+  const int b = blockIdx.x / V, v = blockIdx.x % V;
+  const int K = cand_ptr[b + 1] - cand_ptr[b];
+  const uint8_t* m = cand_mask + (long)b * P;
+  int free_views = 0;
+  for (int j = 0; j < P; ++j) free_views += m[j] ? 0 : 1;
+  const int len = K + free_views;
+  const float* src = nullptr;
+  if (v < K) src = cand + ((long)cand_ptr[b] + v) * F;
+  else if (v < len) {
+    int want = v - K, j = 0;
+    for (; j < P; ++j)
+      if (!m[j] && want-- == 0) break;
+    src = pano + b * pano_bstride + (long)j * F;
+  }
+  float* dst = out + ((long)b * V + v) * F;
+  for (int c = threadIdx.x; c < F; c += 256) dst[c] = src ? src[c] : 0.f;
+  if (threadIdx.x == 0) {
+    if (nav_types) nav_types[(long)b * V + v] = v < K ? 1 : 0;
+    if (view_lens && v == 0) view_lens[b] = len;
+  }
+}
+
 int gmap_assemble(const GmapArgs& a, int B, hipStream_t st) {
   ETP_REQUIRE(B > 0 && a.Nmax >= 1 && a.Nmax <= GN && a.Mmax >= 0 && a.Mmax <= GM && a.G >= 1 && a.Fmax >= 0,
               "graph limits: <= 64 visited nodes and <= 192 ghosts per episode");
@@ -157,4 +188,15 @@ extern "C" int etp_gmap_assemble(const float* node_pos, const int32_t* node_step
   a.Nmax = Nmax; a.Mmax = Mmax; a.Fmax = Fmax; a.G = G;
   a.step_ids = gmap_step_ids; a.gmask = gmap_masks; a.visited = gmap_visited_masks; a.pos_fts = gmap_pos_fts; a.pair = gmap_pair_dists;
   return gmap_assemble(a, B, (hipStream_t)stream);
+}
+
+extern "C" int etp_vp_gather(const float* cand_fts, const int32_t* cand_ptr, const float* pano_fts, int64_t pano_batch_stride,
+                             const uint8_t* cand_mask, int B, int P, int F, int V, float* out_fts, int64_t* nav_types,
+                             int64_t* view_lens, etp_stream_t stream) {
+  using namespace etp;
+  ETP_REQUIRE(cand_ptr && pano_fts && cand_mask && out_fts && B > 0 && P > 0 && F > 0 && V > 0, "bad arguments");
+  hipLaunchKernelGGL(vp_gather_kernel, dim3(B * V), dim3(256), 0, (hipStream_t)stream, cand_fts, cand_ptr, pano_fts,
+                     (long)pano_batch_stride, cand_mask, P, F, V, out_fts, nav_types, view_lens);
+  ETP_CHECK_LAUNCH("vp_gather");
+  return ETP_OK;
 }

@@ -13,7 +13,12 @@ device tensors.
 * ``GraphMapLite`` is a numpy-only GraphMap with the same update rules (graph_utils.py:118-257) that simply skips the
   per-step Dijkstra (the device does the shortest paths);
 * ``nav_gmap_variable(gmaps, cur_vp, cur_pos, cur_heading, device)`` returns the same dict as the reference method
-  (without ``gmap_img_fts``, which is a stack of embedding tensors and stays a torch op / ``etp_gather_sum``).
+  (without ``gmap_img_fts``; see the next item);
+* ``gmap_img_fts``: the reference stacks per-node tensors in Python (``get_node_embeds``, ss_trainer_ETP.py:360-365).  In
+  **device-store mode** GraphMapLite is given ROW INDICES into one embedding store tensor instead of tensors
+  (``update_graph(..., cur_embeds=row, cand_embeds=[rows])``); ``pack_img_csr`` turns the graphs into a CSR and
+  ``gather_rows`` (autograd wrapper of ``etp_gather_sum``) produces the padded ``[B,G,H]`` tensor in one launch, with
+  the gradient flowing back into the store through the transposed CSR.
 
 ``cur_heading`` is the scalar heading (radians) that the reference obtains with ``heading_from_quaternion(cur_ori)``
 (graph_utils.py:54-59); quaternion handling belongs to the simulator side and is out of scope.
@@ -29,6 +34,10 @@ from . import _lib
 from ._lib import check, ptr
 
 MAX_NODES, MAX_GHOSTS = 64, 192      # limits of etp_gmap_assemble (csrc/graph.hip)
+
+
+def _is_row(x) -> bool:
+    return isinstance(x, (int, np.integer))
 
 
 def _dist(a, b) -> float:
@@ -103,7 +112,7 @@ class GraphMapLite:
                 self.ghost_cnt += 1
                 self.ghost_pos[gvp] = [cpos]
                 self.ghost_mean_pos[gvp] = cpos
-                self.ghost_embeds[gvp] = [cembeds, 1]
+                self.ghost_embeds[gvp] = [[int(cembeds)] if _is_row(cembeds) else cembeds, 1]
                 self.ghost_fronts[gvp] = [cur_vp]
                 if self.has_real_pos:
                     self.ghost_real_pos[gvp] = [cand_real_pos[i]]
@@ -111,7 +120,10 @@ class GraphMapLite:
                 gvp = localized_gvp
                 self.ghost_pos[gvp].append(cpos)
                 self.ghost_mean_pos[gvp] = np.mean(self.ghost_pos[gvp], axis=0)
-                self.ghost_embeds[gvp][0] = self.ghost_embeds[gvp][0] + cembeds
+                if _is_row(cembeds):
+                    self.ghost_embeds[gvp][0].append(int(cembeds))       # device-store mode: remember the rows, sum later
+                else:
+                    self.ghost_embeds[gvp][0] = self.ghost_embeds[gvp][0] + cembeds
                 self.ghost_embeds[gvp][1] += 1
                 self.ghost_fronts[gvp].append(cur_vp)
                 if self.has_real_pos:
@@ -123,10 +135,17 @@ class GraphMapLite:
                 noise = np.clip(noise, -self.ghost_aug, self.ghost_aug)
                 self.ghost_aug_pos[gvp] = gpos + noise
 
-    def get_node_embeds(self, vp):                           # :272-276
+    def get_node_embeds(self, vp):                           # :272-276 (tensor mode only)
         if not vp.startswith("g"):
             return self.node_embeds[vp]
         return self.ghost_embeds[vp][0] / self.ghost_embeds[vp][1]
+
+    def embed_rows(self, vp):
+        """Device-store mode: (rows of the embedding store, weight) whose weighted sum is get_node_embeds(vp)."""
+        if not vp.startswith("g"):
+            return [int(self.node_embeds[vp])], 1.0
+        rows, cnt = self.ghost_embeds[vp]
+        return list(rows), 1.0 / cnt
 
 
 def pack_episode(gmap, cur_vp: str, cur_pos, cur_heading: float) -> dict:
@@ -221,4 +240,105 @@ def nav_gmap_variable(gmaps: Sequence, cur_vp: Sequence[str], cur_pos, cur_headi
     out = assemble_on_device(pack_batch(eps), device)
     out["gmap_vp_ids"] = [[None] + list(g.node_pos.keys()) + list(g.ghost_pos.keys()) for g in gmaps]
     out["no_vp_left"] = [len(g.ghost_pos) == 0 for g in gmaps]
+    return out
+
+
+# ---- node embeddings from a device-resident store (device-store mode) ---------------------------------------------------
+def pack_img_csr(gmaps: Sequence, row_offsets: Sequence[int], G: int, n_store_rows: int):
+    """CSR over the embedding store for the padded [B*G] node list ([stop] and padding: empty rows -> zeros), plus its
+    transpose for the backward.  row_offsets[b] shifts episode b's row ids into the concatenated store."""
+    ptr_f, idx_f, w_f = [0], [], []
+    rev: List[list] = [[] for _ in range(n_store_rows)]
+    for b, g in enumerate(gmaps):
+        vps = [None] + list(g.node_pos.keys()) + list(g.ghost_pos.keys())
+        if len(vps) > G:
+            raise ValueError(f"G={G} < {len(vps)} graph entries")
+        for t in range(G):
+            if 1 <= t < len(vps):
+                rows, w = g.embed_rows(vps[t])
+                for r in rows:
+                    idx_f.append(row_offsets[b] + r); w_f.append(w); rev[row_offsets[b] + r].append((b * G + t, w))
+            ptr_f.append(len(idx_f))
+    ptr_b, idx_b, w_b = [0], [], []
+    for r in rev:
+        for n, w in r:
+            idx_b.append(n); w_b.append(w)
+        ptr_b.append(len(idx_b))
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    return (i32(ptr_f), i32(idx_f), f32(w_f)), (i32(ptr_b), i32(idx_b), f32(w_b))
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, store, n_out, fwd, bwd):
+        L = _lib.lib()
+        R, H = store.shape
+        out = torch.empty(n_out, H, dtype=torch.float32, device=store.device)
+        s = torch.cuda.current_stream(store.device).cuda_stream
+        check(L.etp_gather_sum(_lib.ETP_F32, ptr(store), ptr(fwd[0]), ptr(fwd[1]), ptr(fwd[2]), ptr(out), n_out, H, 0, s),
+              "etp_gather_sum")
+        ctx.bwd, ctx.R = bwd, R
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _lib.lib()
+        d_out = d_out.float().contiguous()
+        H = d_out.shape[1]
+        d_store = torch.empty(ctx.R, H, dtype=torch.float32, device=d_out.device)
+        s = torch.cuda.current_stream(d_out.device).cuda_stream
+        b = ctx.bwd
+        check(L.etp_gather_sum(_lib.ETP_F32, ptr(d_out), ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(d_store), ctx.R, H, 0, s),
+              "etp_gather_sum (transposed)")
+        return d_store, None, None, None
+
+
+def gather_rows(store: torch.Tensor, gmaps: Sequence, row_offsets: Sequence[int], G: int) -> torch.Tensor:
+    """gmap_img_fts [B,G,H] (fp32) from the embedding store [R,H] on the device; differentiable w.r.t. the store."""
+    if store.device.type != "cuda":
+        raise _lib.EtpError("etp_gather_sum needs an MI355X (cuda/hip device); no CPU fallback exists")
+    fwd, bwd = pack_img_csr(gmaps, row_offsets, G, store.shape[0])
+    dev = store.device
+    fwd = tuple(x.to(dev) for x in fwd)
+    bwd = tuple(x.to(dev) for x in bwd)
+    out = _GatherRows.apply(store.float().contiguous(), len(gmaps) * G, fwd, bwd)
+    return out.view(len(gmaps), G, store.shape[1])
+
+
+# ---- panorama inputs: candidate views first, then the remaining panorama views (row a13, first half) -------------------
+def vp_feature_variable(obs: dict, device) -> dict:
+    """Drop-in for RLTrainer._vp_feature_variable (ss_trainer_ETP.py:308-342) on the device: three gathers
+    (etp_vp_gather) instead of per-episode torch.cat / pad loops.  `obs` keys as in the reference: cand_img_idxes,
+    cand_rgb, cand_depth, cand_angle_fts (lists of per-episode tensors), pano_rgb [B,12,F], pano_depth [B,12,Fd],
+    pano_angle_fts [12,4].  (Forward only: these are detached perception features in the reference as well.)"""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.EtpError("etp_vp_gather needs an MI355X (cuda/hip device); no CPU fallback exists")
+    L = _lib.lib()
+    B = len(obs["cand_rgb"])
+    P = obs["pano_rgb"].shape[1]
+    ks = [int(x.shape[0]) for x in obs["cand_rgb"]]
+    cand_ptr = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32, device=dev)
+    mask = torch.zeros(B, P, dtype=torch.uint8)
+    for i in range(B):
+        mask[i, torch.as_tensor(np.asarray(obs["cand_img_idxes"][i], dtype=np.int64))] = 1
+    V = max(k + P - int(mask[i].sum()) for i, k in enumerate(ks))
+    mask = mask.to(dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    nav_types = torch.empty(B, V, dtype=torch.int64, device=dev)
+    view_lens = torch.empty(B, dtype=torch.int64, device=dev)
+    out = {}
+    for name, cand_key, pano_key in (("rgb_fts", "cand_rgb", "pano_rgb"), ("dep_fts", "cand_depth", "pano_depth"),
+                                     ("loc_fts", "cand_angle_fts", "pano_angle_fts")):
+        cand = torch.cat([torch.as_tensor(x, dtype=torch.float32) for x in obs[cand_key]], 0).to(dev).contiguous()
+        pano = torch.as_tensor(obs[pano_key], dtype=torch.float32).to(dev).contiguous()
+        F = pano.shape[-1]
+        stride = 0 if pano.dim() == 2 else P * F
+        o = torch.empty(B, V, F, dtype=torch.float32, device=dev)
+        first = name == "rgb_fts"
+        check(L.etp_vp_gather(ptr(cand), ptr(cand_ptr), ptr(pano), stride, ptr(mask), B, P, F, V, ptr(o),
+                              ptr(nav_types) if first else None, ptr(view_lens) if first else None, s), "etp_vp_gather")
+        out[name] = o
+    out["nav_types"], out["view_lens"] = nav_types, view_lens
     return out

@@ -12,6 +12,7 @@ allocated or synchronised inside ``run_eager`` so the step can be captured into 
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -208,7 +209,7 @@ class PlannerStep:
         """Warm up eagerly (sets kernel attributes), then capture the step into hipGraph(s) on a private stream.
         With split_text_bwd the text-encoder backward is a second graph so that a gradient all-reduce of everything
         else can be issued between the two (data-parallel overlap)."""
-        if self.aux is not None and self.s2 is not None:
+        if self.aux is not None and self.s2 is not None and not os.environ.get("ETP_GRAPH_FORCE"):
             raise _lib.EtpError("hipGraph capture with two side streams crashes hipStreamEndCapture on ROCm 7.2; "
                                 "build the PlannerStep with overlap='s2', 'aux' or False for graph replay "
                                 "(measured on MI355X: eager two-stream issue is the fastest mode anyway)")

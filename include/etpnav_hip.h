@@ -333,6 +333,14 @@ int etp_gmap_assemble(const float* node_pos, const int32_t* node_step, const int
                       int Fmax, int G, int64_t* gmap_step_ids, uint8_t* gmap_masks, uint8_t* gmap_visited_masks,
                       float* gmap_pos_fts, float* gmap_pair_dists, etp_stream_t stream);
 
+/* RLTrainer._vp_feature_variable (ss_trainer_ETP.py:308-342): out[b] = [candidate-view features (K_b rows) ; panorama
+ * views whose index is not a candidate's image, in index order], zero-padded to V rows; nav_types 1 for the candidate rows
+ * (NULL to skip), view_lens[b] = K_b + #free views (NULL to skip).  cand_fts packed [sum K, F] with cand_ptr [B+1];
+ * pano_fts [B,P,F] with pano_batch_stride = P*F, or one shared [P,F] table with stride 0 (pano_angle_fts); cand_mask [B,P]. */
+int etp_vp_gather(const float* cand_fts, const int32_t* cand_ptr, const float* pano_fts, int64_t pano_batch_stride,
+                  const uint8_t* cand_mask, int B, int P, int F, int V, float* out_fts, int64_t* nav_types, int64_t* view_lens,
+                  etp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * hipGraph helpers (launch-bound inner loops are captured once and replayed) and timing.
  * ---------------------------------------------------------------------------------------------------- */

@@ -31,30 +31,15 @@ def load_reference_graph_utils():
     return gu
 
 
-def reference_outputs(gu, gmap, cur_vp, cur_pos, cur_heading):
-    """ss_trainer_ETP.py:350-394 for one episode, on the real object."""
-    node_vp_ids = list(gmap.node_pos.keys())
-    ghost_vp_ids = list(gmap.ghost_pos.keys())
-    gmap_vp_ids = [None] + node_vp_ids + ghost_vp_ids
-    step_ids = [0] + [gmap.node_stepId[vp] for vp in node_vp_ids] + [0] * len(ghost_vp_ids)
-    visited = [0] + [1] * len(node_vp_ids) + [0] * len(ghost_vp_ids)
-    pos_fts = gmap.get_pos_fts(cur_vp, cur_pos, cur_heading, gmap_vp_ids)
-    n = len(gmap_vp_ids)
-    pair = np.zeros((n, n), dtype=np.float32)
-    for j in range(1, n):
-        for k in range(j + 1, n):
-            vp1, vp2 = gmap_vp_ids[j], gmap_vp_ids[k]
-            if not vp1.startswith('g') and not vp2.startswith('g'):
-                dist = gmap.shortest_dist[vp1][vp2]
-            elif not vp1.startswith('g') and vp2.startswith('g'):
-                fd2, fv2 = gmap.front_to_ghost_dist(vp2)
-                dist = gmap.shortest_dist[vp1][fv2] + fd2
-            else:
-                fd1, fv1 = gmap.front_to_ghost_dist(vp1)
-                fd2, fv2 = gmap.front_to_ghost_dist(vp2)
-                dist = fd1 + gmap.shortest_dist[fv1][fv2] + fd2
-            pair[j, k] = pair[k, j] = dist / gu.MAX_DIST
-    return np.array(step_ids), np.array(visited, dtype=bool), pos_fts.astype(np.float32), pair
+def reference_batch_outputs(gu, gmaps, cur_vp, cur_pos, cur_heading):
+    """The REAL RLTrainer._nav_gmap_variable (ss_trainer_ETP.py:344-417), cut out of the trainer source and run on a
+    stand-in `self` holding the real GraphMap objects (oracle/ref_trainer_fns.py)."""
+    import types
+    from oracle import ref_trainer_fns as rt
+    fn = rt.extract(["_nav_gmap_variable"], {"MAX_DIST": gu.MAX_DIST})["_nav_gmap_variable"]
+    fake = types.SimpleNamespace(gmaps=gmaps, envs=types.SimpleNamespace(num_envs=len(gmaps)))
+    with rt.shims():
+        return fn(fake, cur_vp, cur_pos, cur_heading)
 
 
 def main():
@@ -62,10 +47,10 @@ def main():
     from etpnav_amd.graph_inputs import pack_episode
     from oracle.graph_oracle import simulate, GOLDEN_EPISODES
     z = {}
-    specs = GOLDEN_EPISODES
-    for e, (seed, steps) in enumerate(specs):
-        gmap, cur_vp, cur_pos, cur_heading = simulate(gu.GraphMap, seed, steps, merge_ghost=(e % 2 == 0))
-        step_ids, visited, pos_fts, pair = reference_outputs(gu, gmap, cur_vp, cur_pos, cur_heading)
+    sims = [simulate(gu.GraphMap, seed, steps, merge_ghost=(e % 2 == 0)) for e, (seed, steps) in enumerate(GOLDEN_EPISODES)]
+    gmaps, vps, poss, heads = [s[0] for s in sims], [s[1] for s in sims], [s[2] for s in sims], [s[3] for s in sims]
+    ref = reference_batch_outputs(gu, gmaps, vps, poss, heads)
+    for e, (gmap, cur_vp, cur_pos, cur_heading, store) in enumerate(sims):
         ep = pack_episode(gmap, cur_vp, cur_pos, cur_heading)
         for k, v in ep.items():
             if k == "ghost_fronts":
@@ -73,10 +58,16 @@ def main():
                 z[f"ep{e}/ghost_front_idx"] = np.array([x for f in v for x in f], dtype=np.int32)
             else:
                 z[f"ep{e}/{k}"] = np.asarray(v)
-        z[f"ep{e}/out_step_ids"], z[f"ep{e}/out_visited"] = step_ids, visited
-        z[f"ep{e}/out_pos_fts"], z[f"ep{e}/out_pair_dists"] = pos_fts, pair
-        print(f"episode {e}: {len(gmap.node_pos)} nodes, {len(gmap.ghost_pos)} ghosts")
-    z["n_episodes"] = np.array(len(specs))
+        L = 1 + ep["n_nodes"] + ep["n_ghost"]
+        z[f"ep{e}/out_step_ids"] = ref["gmap_step_ids"][e, :L].numpy()
+        z[f"ep{e}/out_visited"] = ref["gmap_visited_masks"][e, :L].numpy()
+        z[f"ep{e}/out_pos_fts"] = ref["gmap_pos_fts"][e, :L].numpy().astype(np.float32)
+        z[f"ep{e}/out_pair_dists"] = ref["gmap_pair_dists"][e, :L, :L].numpy()
+        z[f"ep{e}/out_img_fts"] = ref["gmap_img_fts"][e, :L].numpy().astype(np.float32)
+        assert ref["gmap_masks"][e, :L].all() and not ref["gmap_masks"][e, L:].any()
+        assert not ref["gmap_pos_fts"][e, L:].any() and not ref["gmap_pair_dists"][e, L:].any()
+        print(f"episode {e}: {len(gmap.node_pos)} nodes, {len(gmap.ghost_pos)} ghosts, {len(store)} embedding rows")
+    z["n_episodes"] = np.array(len(sims))
     out = os.path.join(ROOT, "tests", "golden", "graph_inputs.npz")
     np.savez_compressed(out, **z)
     print("wrote", out, os.path.getsize(out), "bytes")

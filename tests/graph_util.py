@@ -1,4 +1,5 @@
-"""Loader for tests/golden/graph_inputs.npz (outputs of the REAL GraphMap; generator oracle/make_golden_graph.py)."""
+"""Loader for tests/golden/graph_inputs.npz: outputs of the REAL RLTrainer._nav_gmap_variable on REAL GraphMap objects
+(generator oracle/make_golden_graph.py)."""
 import os
 
 import numpy as np
@@ -18,5 +19,6 @@ def load_episodes():
                     "ghost_fronts": [list(idx[ptr[i]:ptr[i + 1]]) for i in range(m)],
                     "cur_node": int(g("cur_node")), "cur_pos": g("cur_pos"), "cur_heading": float(g("cur_heading"))})
         outs.append({"gmap_step_ids": g("out_step_ids"), "gmap_visited_masks": g("out_visited"),
-                     "gmap_pos_fts": g("out_pos_fts"), "gmap_pair_dists": g("out_pair_dists")})
+                     "gmap_pos_fts": g("out_pos_fts"), "gmap_pair_dists": g("out_pair_dists"),
+                     "gmap_img_fts": g("out_img_fts")})
     return eps, outs

@@ -30,7 +30,7 @@ def test_graphmaplite_replays_the_reference_bookkeeping():
     sets, positions, edges, ghost fronts and step ids must come out identical (localisation, ghost merging, deletion)."""
     eps, _ = load_episodes()
     for e, (seed, steps) in enumerate(go.GOLDEN_EPISODES):
-        gmap, cur_vp, cur_pos, cur_heading = go.simulate(GraphMapLite, seed, steps, merge_ghost=(e % 2 == 0))
+        gmap, cur_vp, cur_pos, cur_heading, _store = go.simulate(GraphMapLite, seed, steps, merge_ghost=(e % 2 == 0))
         mine = pack_episode(gmap, cur_vp, cur_pos, cur_heading)
         ref = eps[e]
         assert mine["n_nodes"] == ref["n_nodes"] and mine["n_ghost"] == ref["n_ghost"] and mine["cur_node"] == ref["cur_node"]
@@ -55,3 +55,34 @@ def test_pack_batch_layout_and_limits():
     assert _lib.lib().etp_gmap_assemble is not None
     with pytest.raises(_lib.EtpError):
         assemble_on_device(b, "cpu")                          # no CPU fallback
+
+
+def test_embedding_csr_reproduces_the_reference_node_embeddings():
+    """Device-store mode: the CSR packed from GraphMapLite (rows instead of tensors), applied to the store on the CPU,
+    equals the gmap_img_fts the REAL _nav_gmap_variable stacked from GraphMap.get_node_embeds (node rows, ghost means,
+    zero [stop] row, zero padding); the transposed CSR is its exact adjoint."""
+    from etpnav_amd.graph_inputs import pack_img_csr
+    eps, outs = load_episodes()
+    gmaps, stores, offs = [], [], [0]
+    for e, (seed, steps) in enumerate(go.GOLDEN_EPISODES):
+        g, _, _, _, store = go.simulate(GraphMapLite, seed, steps, merge_ghost=(e % 2 == 0), rows_mode=True)
+        gmaps.append(g); stores.append(store); offs.append(offs[-1] + len(store))
+    store = torch.from_numpy(np.concatenate(stores))
+    G = max(1 + e["n_nodes"] + e["n_ghost"] for e in eps) + 2
+    (pf, xf, wf), (pb, xb, wb) = pack_img_csr(gmaps, offs[:-1], G, store.shape[0])
+    out = torch.zeros(len(gmaps) * G, store.shape[1])
+    for n in range(len(gmaps) * G):
+        for q in range(int(pf[n]), int(pf[n + 1])):
+            out[n] += wf[q] * store[xf[q]]
+    out = out.view(len(gmaps), G, -1)
+    for b, want in enumerate(outs):
+        L = want["gmap_img_fts"].shape[0]
+        assert np.abs(out[b, :L].numpy() - want["gmap_img_fts"]).max() < 1e-6, b
+        assert not out[b, L:].any() and not out[b, 0].any()
+    # adjoint: <A x, y> == <x, A^T y>
+    y = torch.randn(len(gmaps) * G, store.shape[1])
+    aty = torch.zeros_like(store)
+    for r in range(store.shape[0]):
+        for q in range(int(pb[r]), int(pb[r + 1])):
+            aty[r] += wb[q] * y[xb[q]]
+    assert abs(float((out.view(-1, store.shape[1]) * y).sum()) - float((store * aty).sum())) < 1e-3

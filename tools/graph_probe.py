@@ -9,7 +9,7 @@ from oracle.graph_oracle import simulate          # synthetic episode driver (te
 from etpnav_amd.graph_inputs import GraphMapLite, pack_episode, pack_batch, assemble_on_device
 
 B = 32
-eps = [simulate(GraphMapLite, 100 + i, 15, True) for i in range(B)]
+eps = [simulate(GraphMapLite, 100 + i, 15, True)[:4] for i in range(B)]
 t0 = time.perf_counter()
 for _ in range(20):
     batch = pack_batch([pack_episode(g, vp, pos, h) for g, vp, pos, h in eps])
