@@ -198,7 +198,14 @@ def main():
     # ---- roofline leg: HIP-event timing of every GEMM launch over eager steps (rank 0) ----
     roofline, gemm_table = None, []
     if rank == 0:
+        # Per-launch HIP events need a stream on which nothing else can delay the kernel between its two events: with the
+        # three-stream schedule an event pair also spans cross-stream dependency waits of the kernel it brackets (measured:
+        # 165 us "per launch" for kernels rocprofv3 times at 27 us).  The same step is therefore replayed on ONE stream for
+        # this leg; rocprofv3's average for the three-stream run (profiles/) is the contended counterpart.
         L = _lib.lib()
+        torch.cuda.synchronize()
+        step.close()
+        step = PlannerStep(model, batch, overlap=False, dropout="config" if args.mode == "train" else None, drop_seed=rank)
         step.run_eager(); torch.cuda.synchronize()
         L.etp_prof_reset(); L.etp_prof_enable(1)
         nprof = 3
@@ -223,7 +230,8 @@ def main():
                         "traffic": None,
                         "alg_bytes_per_launch": round(d["alg_gbs"] * 1e9 * d["avg_us"] * 1e-6),
                         "note": "achieved = algorithmic 2MNK FLOPs of every launch of this kernel in a step / summed "
-                                "HIP-event durations (events on the launch stream, eager replays after the timed region)"}
+                                "HIP-event durations (events on the launch stream; single-stream eager replays of the "
+                                "same step after the timed region, so the pairs bracket the kernel alone)"}
             # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
             # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on the weight-shadow cast: tools/pmc_traffic.py)
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")

@@ -48,6 +48,9 @@ struct etp_planner {
   float* P = nullptr; void* S = nullptr; float* G = nullptr;
   // training-mode dropout (0 = eval): hidden / attention-probability / RGB-feature ("drop_env") rates and the step seed
   float p_hidden = 0.f, p_attn = 0.f, p_env = 0.f, p_head = 0.f;
+  // 1: etp_nav_bwd / etp_pano_bwd leave their weight-gradient GEMMs running on the aux stream instead of joining them
+  // before returning; the caller joins later (etp_txt_bwd* always joins, or etp_planner_join_aux)
+  bool lazy_join = false;
   uint64_t drop_seed = 0;
   // optional second stream: weight-gradient GEMMs (leaves of the backward graph) run beside the dgrad chain
   hipStream_t aux = nullptr;
@@ -280,6 +283,11 @@ static int on_side(const Ctx& c, std::function<int()> f) {
 static int join_wgrads(const Ctx& c) {
   ETP_TRY(flush_side(c));
   return stream_after(c.pl, c.sw, c.st);
+}
+// end of a backward entry point whose weight gradients nobody downstream of it reads (navigation, panorama)
+static int finish_wgrads(const Ctx& c) {
+  if (c.pl->lazy_join) return flush_side(c);
+  return join_wgrads(c);
 }
 
 static GemmArgs base_args() {
@@ -612,6 +620,17 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux) {
   p->aux = reinterpret_cast<hipStream_t>(aux);
   return ETP_OK;
 }
+int etp_planner_set_lazy_join(etp_planner* p, int lazy) {
+  ETP_REQUIRE(p, "null planner");
+  p->lazy_join = lazy != 0;
+  return ETP_OK;
+}
+int etp_planner_join_aux(etp_planner* p, etp_stream_t stream) {
+  ETP_REQUIRE(p, "null planner");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->aux == nullptr || p->aux == st) return ETP_OK;
+  return stream_after(p, p->aux, st);
+}
 int etp_planner_set_dropout(etp_planner* p, float p_hidden, float p_attn, float p_head, float p_env, uint64_t seed) {
   ETP_REQUIRE(p && p_hidden >= 0.f && p_hidden < 1.f && p_attn >= 0.f && p_attn < 1.f && p_env >= 0.f && p_env < 1.f &&
                   p_head >= 0.f && p_head < 1.f,
@@ -925,7 +944,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
   if (cf.use_depth) ETP_TRY(linear_wgrad(c, w.dI, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
   if (d_rgb) ETP_TRY(linear_dgrad_s(c, w.t1, H, p->img_w, d_rgb, M, H, cf.img_feat, nullptr, 0, denv));
-  return join_wgrads(c);
+  return finish_wgrads(c);
 }
 
 // ======================================================================================
@@ -1228,24 +1247,16 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, l == 0 ? d_img : g, Mg, H, H, w.t1.f));
     if (cached) { ETP_TRY(flush_side(c)); continue; }
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
-    // d_txt accumulates over the layers and is consumed only by the caller: like the weight gradients it is a leaf of
-    // this entry point, so it follows the K/V weight gradient on the side stream (in order there: the read-modify-write
-    // accumulation over layers stays serial) and is joined by join_wgrads below
-    {
-      Ctx cs = c;
-      cs.st = c.sw;
-      cs.pend = nullptr;
-      void* dkv = xc.dkv;
-      const int kvw = q.kv_w, mode = l == cf.n_x - 1 ? 0 : 1;
-      ETP_TRY(on_side(c, [=]() -> int { return linear_dgrad_s(cs, dkv, 2 * H, kvw, d_txt, Mt, 2 * H, H, nullptr, mode); }));
-    }
-    ETP_TRY(flush_side(c));          // this layer's weight gradients + the d_txt contribution: one fork
+    // d_txt (consumed by the text backward right after this entry point) stays on the main stream: on the side stream it
+    // would queue behind this entry point's weight gradients and the text backward would wait for all of them
+    ETP_TRY(linear_dgrad_s(c, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
+    ETP_TRY(flush_side(c));          // this layer's weight gradients: one fork
   }
   if (cf.n_x == 0) ETP_TRY(copy_f32(g, d_img, (long)Mg * H, c.st));
   ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));
-  return join_wgrads(c);
+  return finish_wgrads(c);
 }
 }  // namespace
 

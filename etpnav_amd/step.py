@@ -112,6 +112,9 @@ class PlannerStep:
             check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
             self.s2 = b2.value
         check(self.L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
+        # navigation / panorama weight gradients keep running on the aux stream while the text backward starts; the text
+        # backward's own join (or the explicit one in enqueue_main) completes them
+        check(self.L.etp_planner_set_lazy_join(h, 1 if self.aux is not None else 0), "set_lazy_join")
         self._pano_pending = False
         self.graph = None
         self.graphs = []
@@ -164,6 +167,7 @@ class PlannerStep:
                              ptr(self.st_pano), ptr(self.ws_pano), s2), "pano_bwd")
         if join_pano:
             check(L.etp_stream_after(s2, s), "join")
+            check(L.etp_planner_join_aux(h, s), "join aux")      # callers of this mode read the non-text gradients next
         else:
             self._pano_pending = True
 
@@ -253,6 +257,7 @@ class PlannerStep:
         self.graphs, self.graph = [], None
         if self.stream is not None:
             self.L.etp_stream_destroy(self.stream); self.stream = None
+        self.L.etp_planner_set_lazy_join(self.eng.handle, 0)
         self.L.etp_planner_set_aux_stream(self.eng.handle, None)
         for st in (self.aux, self.s2):
             if st is not None:

@@ -229,6 +229,12 @@ int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads);
  * on `aux` after their dY producer and joined back before the call returns to `stream`, so they overlap the dgrad
  * chain (works eagerly and under hipGraph capture: the fork/join become graph edges).  NULL = single stream. */
 int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
+/* With an aux stream: lazy = 1 lets etp_nav_bwd* / etp_pano_bwd return WITHOUT joining their weight-gradient GEMMs back
+ * (nothing downstream of them reads weight gradients), so the text backward does not wait for the navigation weight
+ * gradients; the gradients are complete in `stream` order only after a later joining call: etp_txt_bwd / etp_txt_bwd_range
+ * / etp_nav_kv_bwd (always join) or etp_planner_join_aux.  Default 0: every backward entry point joins before it returns. */
+int etp_planner_set_lazy_join(etp_planner* p, int lazy);
+int etp_planner_join_aux(etp_planner* p, etp_stream_t stream);
 /* Training-mode dropout (all rates 0 = eval, the default).  Masks are a counter-based hash of (seed, site, element index):
  * nothing is stored, the backward entry points recompute the masks, so a backward call must see the same rates and seed as
  * its forward (the state is read at enqueue time; change it between calls freely).  Sites mirror the reference:
