@@ -399,8 +399,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  // tile / batch / split-K coordinates.  blockIdx.x walks N fastest so that consecutive blocks share the
-  // A row-panel; TODO(round 2): XCD-aware remap.
+  // tile / batch / split-K coordinates (XCD-aware workgroup -> tile map: tile_of_block)
   const int tiles_n = (g.N + BN - 1) / BN;
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);

@@ -79,7 +79,8 @@ bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);
 int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
 int attn_fused_bwd(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK,
                    long lddk, void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop);
-// drop = dropout on the attention probabilities (vilmodel_cmt.py:127,346; MHA dropout); only the fused kernels implement it
+// drop = dropout on the attention probabilities (vilmodel_cmt.py:127,346; MHA dropout): inside the fused kernels, or via
+// drop_rows + AttnBuf::Pd on the batched-GEMM path
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st,
                   Drop drop = drop_none());
 int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dP, void* dQ, long lddq,
