@@ -342,3 +342,55 @@ def vp_feature_variable(obs: dict, device) -> dict:
         out[name] = o
     out["nav_types"], out["view_lens"] = nav_types, view_lens
     return out
+
+
+# ---- pre-training: GlobalMapEncoder._aggregate_gmap_features (pretrain_src/pretrain_src/model/vilmodel.py:585-619) ------
+def pack_traj_csr(traj_vp_lens: Sequence[Sequence[int]], traj_vpids: Sequence[Sequence[str]],
+                  traj_cand_vpids: Sequence[Sequence[Sequence[str]]], gmap_vpids: Sequence[Sequence], V: int, G: int):
+    """CSR (+ transpose) that turns the flat panorama embeddings [sum_i T_i, V, H] of a batch of trajectories into the
+    padded node features [B, G, H]: a visited node = mean of the valid views of the step that visited it (a later visit
+    overwrites an earlier one); an unvisited node = mean of the candidate-view embeddings (view j of step t) over the
+    steps at which it was seen while not yet visited; entry 0 ([stop]) and padding are zero rows."""
+    ptr_f, idx_f, w_f = [0], [], []
+    n_rows = sum(len(x) for x in traj_vp_lens) * V
+    rev: List[list] = [[] for _ in range(n_rows)]
+    base = 0
+    for i in range(len(traj_vp_lens)):
+        visited, unvisited = {}, {}
+        for t, vp in enumerate(traj_vpids[i]):
+            n = int(traj_vp_lens[i][t])
+            visited[vp] = ([(base + t) * V + j for j in range(n)], 1.0 / n)
+            for j, cvp in enumerate(traj_cand_vpids[i][t]):
+                if cvp not in visited:
+                    unvisited.setdefault(cvp, []).append((base + t) * V + j)
+        if len(gmap_vpids[i]) > G:
+            raise ValueError(f"G={G} < {len(gmap_vpids[i])} graph entries")
+        for g in range(G):
+            if 1 <= g < len(gmap_vpids[i]):
+                vp = gmap_vpids[i][g]
+                rows, w = visited[vp] if vp in visited else (unvisited[vp], 1.0 / len(unvisited[vp]))
+                for r in rows:
+                    idx_f.append(r); w_f.append(w); rev[r].append((i * G + g, w))
+            ptr_f.append(len(idx_f))
+        base += len(traj_vp_lens[i])
+    ptr_b, idx_b, w_b = [0], [], []
+    for r in rev:
+        for n, w in r:
+            idx_b.append(n); w_b.append(w)
+        ptr_b.append(len(idx_b))
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    return (i32(ptr_f), i32(idx_f), f32(w_f)), (i32(ptr_b), i32(idx_b), f32(w_b))
+
+
+def aggregate_gmap_features(traj_embeds: torch.Tensor, traj_vp_lens, traj_vpids, traj_cand_vpids, gmap_vpids, G: int):
+    """Device version of GlobalMapEncoder._aggregate_gmap_features: traj_embeds [sum T, V, H] (output of the panorama
+    encoder for every trajectory step) -> gmap_img_fts [B, G, H] incl. the zero [stop] row; differentiable."""
+    if traj_embeds.device.type != "cuda":
+        raise _lib.EtpError("etp_gather_sum needs an MI355X (cuda/hip device); no CPU fallback exists")
+    R, V, H = traj_embeds.shape
+    fwd, bwd = pack_traj_csr(traj_vp_lens, traj_vpids, traj_cand_vpids, gmap_vpids, V, G)
+    dev = traj_embeds.device
+    fwd, bwd = tuple(x.to(dev) for x in fwd), tuple(x.to(dev) for x in bwd)
+    out = _GatherRows.apply(traj_embeds.float().contiguous().view(R * V, H), len(traj_vp_lens) * G, fwd, bwd)
+    return out.view(len(traj_vp_lens), G, H)

@@ -86,3 +86,31 @@ def test_embedding_csr_reproduces_the_reference_node_embeddings():
         for q in range(int(pb[r]), int(pb[r + 1])):
             aty[r] += wb[q] * y[xb[q]]
     assert abs(float((out.view(-1, store.shape[1]) * y).sum()) - float((store * aty).sum())) < 1e-3
+
+
+def test_trajectory_aggregation_csr_matches_the_real_pretraining_method():
+    """pack_traj_csr applied on the CPU == GlobalMapEncoder._aggregate_gmap_features (pretrain vilmodel.py:585-619) run
+    from its own source (tests/golden/traj_agg.npz): revisited nodes, candidates seen before/after being visited,
+    ragged view counts, zero [stop] row and padding; the transposed CSR is the exact adjoint."""
+    import os
+    from oracle.make_golden_traj import make_case
+    from etpnav_amd.graph_inputs import pack_traj_csr
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "traj_agg.npz"))["out"]
+    embeds, lens, vpids, cands, gvps = make_case()
+    V, H = embeds[0].shape[1], embeds[0].shape[2]
+    G = want.shape[1] + 2
+    store = torch.cat(embeds, 0).reshape(-1, H)
+    (pf, xf, wf), (pb, xb, wb) = pack_traj_csr([l.tolist() for l in lens], vpids, cands, gvps, V, G)
+    out = torch.zeros(len(embeds) * G, H)
+    for n in range(out.shape[0]):
+        for q in range(int(pf[n]), int(pf[n + 1])):
+            out[n] += wf[q] * store[xf[q]]
+    out = out.view(len(embeds), G, H)
+    assert np.abs(out[:, :want.shape[1]].numpy() - want).max() < 1e-6
+    assert not out[:, want.shape[1]:].any() and not out[:, 0].any()
+    y = torch.randn(len(embeds) * G, H)
+    aty = torch.zeros_like(store)
+    for r in range(store.shape[0]):
+        for q in range(int(pb[r]), int(pb[r + 1])):
+            aty[r] += wb[q] * y[xb[q]]
+    assert abs(float((out.view(-1, H) * y).sum()) - float((store * aty).sum())) < 1e-3
