@@ -36,15 +36,19 @@ WORKLOADS = {
     "c5": dict(task="r2r", B=8, L=80, V=36, G=64, image_feat_size=768),
     # configs[3] per-GPU shape
     "c4": dict(task="rxr", B=16, L=512, V=36, G=16, image_feat_size=768),
+    # the pre-training SAP task (SURVEY.md §8d "second unit", pretrain_cmt.py:223-283): T-step trajectories, one 36-view
+    # panorama per step through the panorama encoder, node features aggregated over the steps; G follows from the graphs
+    "sap": dict(task="r2r", B=32, L=80, V=36, G=None, T=5, image_feat_size=768),
 }
 
 
 def flops_per_step(w, cfg):
     """Algorithmic FLOPs (2MNK per product, bwd = 2x fwd) — SURVEY.md Appendix C."""
     H, I, B, L, V, G = cfg.hidden_size, cfg.intermediate_size, w["B"], w["L"], w["V"], w["G"]
+    Bp = B * w.get("T", 1)                                        # panoramas per step (SAP: one per trajectory step)
     lin = 8 * H * H + 4 * H * I
     lang = cfg.num_l_layers * (B * L * lin + B * 4 * L * L * H)
-    pano = B * V * 2 * H * (cfg.image_feat_size + cfg.depth_feat_size + 4) + cfg.num_pano_layers * (B * V * lin + B * 4 * V * V * H)
+    pano = Bp * V * 2 * H * (cfg.image_feat_size + cfg.depth_feat_size + 4) + cfg.num_pano_layers * (Bp * V * lin + Bp * 4 * V * V * H)
     xl = cfg.num_x_layers * (B * G * 4 * H * H + B * L * 4 * H * H + B * 4 * G * L * H + B * G * 8 * H * H + B * 4 * G * G * H
                              + B * G * 4 * H * I)
     head = B * G * (2 * H * H + 2 * H)
@@ -138,8 +142,14 @@ def main():
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = GlocalTextPathNavCMT(cfg, dtype=tdt, device=f"cuda:{local_rank}")
     model.init_weights(seed=0)                                   # same weights on every rank (DDP's broadcast)
-    batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
-                       seed=1234 + rank)                          # each rank owns its episodes
+    if args.workload == "sap":
+        from etpnav_amd.synthetic import make_sap_batch
+        batch = make_sap_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["T"], w["V"],
+                               seed=1234 + rank)
+        w = dict(w, G=int(batch["gmap_step_ids"].shape[1]))
+    else:
+        batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
+                           seed=1234 + rank)                      # each rank owns its episodes
     use_graph = args.graph
     step = PlannerStep(model, batch, overlap="s2" if use_graph else True,
                        dropout="config" if args.mode == "train" else None, drop_seed=rank)
@@ -274,8 +284,10 @@ def main():
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
-                                   f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
+            "config": {"workload": (f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
+                                    if args.workload != "sap" else
+                                    f"pre-training SAP task (pretrain_cmt.py:223-283), T={w['T']} panoramas per episode: ")
+                                   + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
                        "global_batch": w["B"] * world, "parallelism": f"dp{world}",
                        "graph": use_graph, "mode": args.mode,
@@ -289,7 +301,7 @@ def main():
             "optimizer": optimizer,
             "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "sap":
             out["cpu_baseline"] = cpu_baseline(w, dict(image_feat_size=w["image_feat_size"]), train=args.mode == "train")
         else:
             out["cpu_baseline"] = None

@@ -84,21 +84,33 @@ class PlannerStep:
             "visited": mv(batch["gmap_visited_masks"], torch.bool), "dists": mv(batch["gmap_pair_dists"], torch.float32),
             "labels": mv(batch["labels"], torch.int64),
         }
-        (pf, xf, wf), (pb, xb, wb) = build_node_csr(batch["view_lens"].cpu(), V, G)
+        # Panorama batch: B (one panorama per episode, the fine-tuning rollout step) or sum of trajectory steps (the
+        # pre-training SAP task, pretrain_cmt.py:223-283: one panorama per step of every episode); the node features are a
+        # CSR gather over all panorama embeddings either way.
+        Bp = self.Bp = batch["rgb_fts"].shape[0]
+        if "traj" in batch:
+            from .graph_inputs import pack_traj_csr
+            tr = batch["traj"]
+            (pf, xf, wf), (pb, xb, wb) = pack_traj_csr(tr["traj_vp_lens"], tr["traj_vpids"], tr["traj_cand_vpids"],
+                                                       tr["gmap_vpids"], V, G)
+        else:
+            if Bp != B:
+                raise ValueError("rgb_fts batch differs from txt_ids batch: pass the trajectory lists as batch['traj']")
+            (pf, xf, wf), (pb, xb, wb) = build_node_csr(batch["view_lens"].cpu(), V, G)
         self.csr_f = tuple(x.to(dev) for x in (pf, xf, wf))
         self.csr_b = tuple(x.to(dev) for x in (pb, xb, wb))
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)   # API tensors are fp32 in both modes
-        self.txt = e(B, Lt, H); self.pano = e(B, V, H); self.pmask = e(B, V, dt=torch.bool)
+        self.txt = e(B, Lt, H); self.pano = e(Bp, V, H); self.pmask = e(Bp, V, dt=torch.bool)
         self.gimg = e(B, G, H); self.gemb = e(B, G, H); self.logits = e(B, G, dt=torch.float32)
         self.dlogits = e(B, G, dt=torch.float32); self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.d_txt = e(B, Lt, H); self.d_gimg = e(B, G, H); self.d_pano = e(B, V, H)
+        self.d_txt = e(B, Lt, H); self.d_gimg = e(B, G, H); self.d_pano = e(Bp, V, H)
         h = eng.handle
         self.st_txt = eng.buf(self.L.etp_txt_stash_bytes(h, B, Lt))
-        self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, B, V))
+        self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, Bp, V))
         self.st_nav = eng.buf(self.L.etp_nav_stash_bytes(h, B, Lt, G))
         # separate backward workspaces: the three backward passes may run on parallel streams
         self.ws_txt = eng.buf(self.L.etp_txt_ws_bytes(h, B, Lt))
-        self.ws_pano = eng.buf(self.L.etp_pano_ws_bytes(h, B, V))
+        self.ws_pano = eng.buf(self.L.etp_pano_ws_bytes(h, Bp, V))
         self.ws_nav = eng.buf(self.L.etp_nav_ws_bytes(h, B, Lt, G))
         # side streams: `aux` carries the weight-gradient GEMMs, `s2` the panorama branch (independent of the text branch)
         self.overlap = overlap
@@ -144,7 +156,7 @@ class PlannerStep:
         if backward and self.zero_grads:
             check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
-        check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), B, V,
+        check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), self.Bp, V,
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
         check(L.etp_stream_after(s2, s), "join")
         pf, xf, wf = self.csr_f
@@ -160,10 +172,10 @@ class PlannerStep:
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
         pb, xb, wb = self.csr_b
-        check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), B * V, H, 0, s),
+        check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s),
               "node assembly bwd")
         check(L.etp_stream_after(s, s2), "fork")
-        check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), B, V, None,
+        check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), self.Bp, V, None,
                              ptr(self.st_pano), ptr(self.ws_pano), s2), "pano_bwd")
         if join_pano:
             check(L.etp_stream_after(s2, s), "join")

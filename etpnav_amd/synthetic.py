@@ -45,3 +45,62 @@ def make_batch(vocab_size: int, image_feat_size: int, depth_feat_size: int, B: i
     return {"txt_ids": ids, "txt_masks": tmask, "rgb_fts": rgb, "dep_fts": dep, "loc_fts": loc, "nav_types": nav,
             "view_lens": vl, "gmap_step_ids": step_ids, "gmap_pos_fts": pos, "gmap_masks": gmask,
             "gmap_visited_masks": visited, "gmap_pair_dists": d, "labels": labels}
+
+
+def make_sap_batch(vocab_size: int, image_feat_size: int, depth_feat_size: int, B: int, L: int, T: int, V: int = 36,
+                   n_cand: int = 4, seed: int = 1234, ragged: bool = False) -> dict:
+    """One pre-training SAP step (pretrain_cmt.py:223-283): per episode a T-step trajectory with one V-view panorama per
+    step (the first n_cand views are candidates: the next node of the path + new ghost nodes), the graph of everything
+    seen so far, and the index of a ghost as the action label.  Tensors are flattened over steps as the reference's
+    collate does (tasks.py:322-364): rgb_fts [B*T, V, F] etc.; the "traj" entry carries the id lists the aggregation needs."""
+    g = torch.Generator().manual_seed(seed)
+    base = make_batch(vocab_size, image_feat_size, depth_feat_size, B * T, L, V, 4, seed=seed, ragged=ragged, n_cand=n_cand)
+    tl = torch.randint(max(L // 2, 1), L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    tl[0] = L
+    ids = torch.randint(1000, vocab_size - 1, (B, L), generator=g)
+    tmask = torch.arange(L)[None, :] < tl[:, None]
+    vpids, cands, gvps, lens = [], [], [], []
+    for i in range(B):
+        path = [f"e{i}_n{t}" for t in range(T)]
+        ep_c, seen = [], [path[0]]
+        for t in range(T):
+            c = []
+            for j in range(n_cand):
+                if j == 0 and t + 1 < T:
+                    c.append(path[t + 1])                       # the next node is first seen as a candidate
+                elif j == 1 and t > 0:
+                    c.append(path[t - 1])                       # looking back at a visited node
+                else:
+                    c.append(f"e{i}_g{t}_{j % 3}")              # ghosts; some are re-seen from the next step
+            if t > 0 and n_cand > 2:
+                c[2] = f"e{i}_g{t - 1}_2"                       # same ghost seen from two steps -> mean of two views
+            ep_c.append(c)
+            for vp in [path[t]] + c:
+                if vp not in seen:
+                    seen.append(vp)
+        vpids.append(path); cands.append(ep_c); gvps.append([None] + seen)
+        lens.append([int(x) for x in base["view_lens"][i * T:(i + 1) * T]])
+    G = max(len(x) for x in gvps)
+    gl = torch.tensor([len(x) for x in gvps])
+    gmask = torch.arange(G)[None, :] < gl[:, None]
+    step_ids = torch.zeros(B, G, dtype=torch.long)
+    visited = torch.zeros(B, G, dtype=torch.bool)
+    labels = torch.zeros(B, dtype=torch.long)
+    for i in range(B):
+        for gidx, vp in enumerate(gvps[i]):
+            if vp in vpids[i]:
+                step_ids[i, gidx] = vpids[i].index(vp) + 1
+                visited[i, gidx] = True
+        ghosts = [k for k in range(1, len(gvps[i])) if not visited[i, k]]
+        labels[i] = ghosts[i % len(ghosts)]
+    pos = torch.randn(B, G, 7, generator=g) * gmask[..., None]
+    d = torch.rand(B, G, G, generator=g)
+    d = (d + d.transpose(1, 2)) * 0.5
+    d[:, 0, :] = 0; d[:, :, 0] = 0
+    d = d * (1 - torch.eye(G))[None] * gmask[:, :, None] * gmask[:, None, :]
+    out = {k: base[k] for k in ("rgb_fts", "dep_fts", "loc_fts", "nav_types", "view_lens")}
+    out.update({"txt_ids": ids * tmask, "txt_masks": tmask, "gmap_step_ids": step_ids, "gmap_pos_fts": pos, "gmap_masks": gmask,
+                "gmap_visited_masks": visited, "gmap_pair_dists": d, "labels": labels,
+                "traj": {"traj_step_lens": [T] * B, "traj_vp_lens": lens, "traj_vpids": vpids, "traj_cand_vpids": cands,
+                         "gmap_vpids": gvps}})
+    return out

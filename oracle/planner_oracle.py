@@ -552,6 +552,56 @@ def make_batch(cfg: PlannerConfig, B: int, L: int, V: int, G: int, seed: int = 1
             "gmap_pair_dists": d.to(dtype), "labels": labels}
 
 
+def aggregate_gmap_features(traj_embeds: Tensor, traj) -> Tensor:
+    """GlobalMapEncoder._aggregate_gmap_features pretrain_src/pretrain_src/model/vilmodel.py:585-619 (+ the [stop] row
+    :611-616), from the flat panorama embeddings [sum T, V, H].  Pinned by tests/golden/traj_agg.npz (output of the real
+    method; tests/test_oracle_golden.py)."""
+    split = torch.split(traj_embeds, traj["traj_step_lens"], 0)
+    out = []
+    for i, emb in enumerate(split):
+        lens = torch.tensor(traj["traj_vp_lens"][i])
+        masks = gen_seq_masks(lens, int(lens.max()))
+        e = emb[:, :int(lens.max())] * masks.unsqueeze(2).to(emb.dtype)
+        visited, unvisited = {}, {}
+        for t in range(len(emb)):
+            visited[traj["traj_vpids"][i][t]] = e[t].sum(0) / lens[t]
+            for j, vp in enumerate(traj["traj_cand_vpids"][i][t]):
+                if vp not in visited:
+                    unvisited.setdefault(vp, []).append(e[t][j])
+        rows = [torch.zeros_like(e[0][0])]
+        for vp in traj["gmap_vpids"][i][1:]:
+            rows.append(visited[vp] if vp in visited else torch.stack(unvisited[vp], 0).mean(0))
+        out.append(torch.stack(rows, 0))
+    G = max(len(x) for x in out)
+    return torch.stack([torch.cat([x, torch.zeros(G - len(x), x.shape[1], dtype=x.dtype)], 0) for x in out], 0)
+
+
+def sap_step(P, cfg: PlannerConfig, batch, drop=None):
+    """The pre-training SAP task (pretrain_cmt.py:223-283 -> vilmodel.py:670-705): text encoder, panorama encoder over
+    every trajectory step, node aggregation, global encoder, SAP head, mean cross-entropy (train_r2r.py:247)."""
+    txt = forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"], drop)
+    pano, pmask = forward_panorama(P, cfg, batch["rgb_fts"], batch["dep_fts"], batch["loc_fts"], batch["nav_types"],
+                                   batch["view_lens"], drop)
+    gimg = aggregate_gmap_features(pano, batch["traj"])
+    G = batch["gmap_step_ids"].shape[1]
+    if gimg.shape[1] < G:
+        gimg = torch.cat([gimg, torch.zeros(gimg.shape[0], G - gimg.shape[1], gimg.shape[2], dtype=gimg.dtype)], 1)
+    outs = forward_navigation(P, cfg, txt, batch["txt_masks"], batch["gmap_step_ids"], gimg, batch["gmap_pos_fts"],
+                              batch["gmap_masks"], batch["gmap_visited_masks"], batch["gmap_pair_dists"], drop)
+    B = batch["txt_ids"].shape[0]
+    loss = cross_entropy_sum(outs["global_logits"], batch["labels"]) / B
+    return {"txt_embeds": txt, "pano_embeds": pano, "pano_masks": pmask, "gmap_img_fts": gimg,
+            "gmap_embeds": outs["gmap_embeds"], "global_logits": outs["global_logits"], "loss": loss}
+
+
+def sap_step_with_grads(P, cfg: PlannerConfig, batch, drop=None):
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    outs = sap_step(Pg, cfg, batch, drop)
+    outs["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in outs.items()}, grads
+
+
 def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4, drop=None):
     """Run planner_step with autograd; returns (outputs, {name: grad})."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}

@@ -15,3 +15,19 @@ def test_oracle_matches_reference_golden(name):
     outs, grads = po.step_with_grads(P, cfg, batch)
     compare_outputs(z, outs, atol=2e-5)
     compare_grads(z, grads, atol=2e-5, rel=1e-4)
+
+
+def test_oracle_trajectory_aggregation_matches_the_real_pretraining_method():
+    """oracle aggregate_gmap_features == GlobalMapEncoder._aggregate_gmap_features run from its own source
+    (tests/golden/traj_agg.npz, generator oracle/make_golden_traj.py)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import planner_oracle as po
+    from oracle.make_golden_traj import make_case
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "traj_agg.npz"))["out"]
+    embeds, lens, vpids, cands, gvps = make_case()
+    traj = {"traj_step_lens": [len(e) for e in embeds], "traj_vp_lens": [l.tolist() for l in lens], "traj_vpids": vpids,
+            "traj_cand_vpids": cands, "gmap_vpids": gvps}
+    got = po.aggregate_gmap_features(torch.cat(embeds, 0), traj)
+    assert got.shape == want.shape and np.abs(got.numpy() - want).max() < 1e-6

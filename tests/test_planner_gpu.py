@@ -311,3 +311,25 @@ def test_text_kv_cache_rollout_equals_per_step_projection(dtype, tol):
     model.forward_navigation(txt2, masks, None, batches[0]["gmap_step_ids"], batches[0]["gmap_img_fts"], batches[0]["gmap_pos_fts"],
                              batches[0]["gmap_masks"], batches[0]["gmap_visited_masks"], batches[0]["gmap_pair_dists"])
     assert model._kv_cache[2] is not kv_first
+
+
+# ---- the pre-training SAP unit (SURVEY.md §8d second unit; pretrain_cmt.py:223-283) -----------------------------------
+@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 8e-2, 0.1)])
+def test_sap_pretraining_step_matches_oracle(dtype, atol, rel):
+    """T-step trajectories: panorama encoder over every step, node features aggregated over the steps (visited = pano
+    mean, unvisited = mean of the candidate views that saw it), global encoder, SAP head, mean CE -- outputs and all
+    gradients vs the oracle composition (each part pinned to the reference: forward_* by the golden fixtures,
+    _aggregate_gmap_features by tests/golden/traj_agg.npz)."""
+    from etpnav_amd.synthetic import make_sap_batch
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=12)
+    batch = make_sap_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, B=3, L=19, T=3, V=9, n_cand=4, seed=77,
+                           ragged=True)
+    outs, grads = po.sap_step_with_grads(P, cfg, batch)
+    model = build_model(cfg, P, dtype)
+    step = PlannerStep(model, batch)
+    step.run_eager()
+    got = step_outputs(step)
+    _assert_step_matches(outs, grads, got, grads_of(model), atol=atol, rel=rel)
+    assert (step.gimg.cpu() - outs["gmap_img_fts"]).abs().max().item() < atol
+    step.close()
