@@ -49,6 +49,9 @@ class PlannerConfig:
     use_depth_embedding: bool = True
     graph_sprels: bool = True
     layer_norm_eps: float = 1e-12
+    # pre-training variant (run_pt/r2r_model_config_dep.json "use_lang2visn_attn": true): language-side x-layer weights
+    # + the tied MLM head (pretrain_cmt.py:57-58, vilmodel.py:258-299,371-376)
+    use_lang2visn_attn: bool = False
 
     @staticmethod
     def r2r(**kw) -> "PlannerConfig":
@@ -161,6 +164,16 @@ def param_shapes(cfg: PlannerConfig) -> Dict[str, tuple]:
     s["global_sap_head.net.2.bias"] = (H,)
     s["global_sap_head.net.4.weight"] = (1, H)
     s["global_sap_head.net.4.bias"] = (1,)
+    if cfg.use_lang2visn_attn:      # appended LAST so that init_params(seed) leaves every fine-tuning parameter unchanged
+        for l in range(cfg.num_x_layers):
+            p = f"{g}.encoder.x_layers.{l}"
+            bert_attention(f"{p}.lang_self_att")
+            ffn(f"{p}.lang_inter", f"{p}.lang_output")
+        s["mlm_head.predictions.transform.dense.weight"] = (H, H)
+        s["mlm_head.predictions.transform.dense.bias"] = (H,)
+        s["mlm_head.predictions.transform.LayerNorm.weight"] = (H,)
+        s["mlm_head.predictions.transform.LayerNorm.bias"] = (H,)
+        s["mlm_head.predictions.bias"] = (cfg.vocab_size,)
     return s
 
 
@@ -205,7 +218,7 @@ def init_params(cfg: PlannerConfig, seed: int = 0, dtype=torch.float32,
 # --------------------------------------------------------------------------
 import numpy as _np
 
-MODE_TXT, MODE_PANO, MODE_NAV = 1, 2, 3
+MODE_TXT, MODE_PANO, MODE_NAV, MODE_MLM = 1, 2, 3, 4
 SITE_EMBED, SITE_ATT_P, SITE_ATT_O, SITE_FFN_O, SITE_FFN_I, SITE_X_P, SITE_X_O, SITE_HEAD, SITE_ENV = range(9)
 
 
@@ -592,6 +605,64 @@ def sap_step(P, cfg: PlannerConfig, batch, drop=None):
     loss = cross_entropy_sum(outs["global_logits"], batch["labels"]) / B
     return {"txt_embeds": txt, "pano_embeds": pano, "pano_masks": pmask, "gmap_img_fts": gimg,
             "gmap_embeds": outs["gmap_embeds"], "global_logits": outs["global_logits"], "loss": loss}
+
+
+def gmap_input_embedding(P, cfg: PlannerConfig, gmap_img_fts, gmap_step_ids, gmap_pos_fts) -> Tensor:
+    """GlobalMapEncoder.gmap_input_embedding vilmodel.py:621-632 (same sum as forward_navigation's first lines)."""
+    g = "global_encoder"
+    return (gmap_img_fts + P[f"{g}.gmap_step_embeddings.weight"][gmap_step_ids]
+            + layer_norm(linear(gmap_pos_fts, P[f"{g}.gmap_pos_embeddings.0.weight"], P[f"{g}.gmap_pos_embeddings.0.bias"]),
+                         P[f"{g}.gmap_pos_embeddings.1.weight"], P[f"{g}.gmap_pos_embeddings.1.bias"], 1e-12))
+
+
+def forward_mlm_hidden(P, cfg: PlannerConfig, txt_embeds, txt_masks, gmap_input_embeds, gmap_masks, drop=None) -> Tensor:
+    """GlocalTextPathCMT.forward_mlm vilmodel.py:727-737: the text attends to the (unchanging) graph-node inputs through
+    every x-layer's forward_lang2visn (:400-411): visual_attention (lang -> nodes), lang_self_att, lang_inter/lang_output."""
+    g = "global_encoder"
+    dt = txt_embeds.dtype
+    txt_m, node_m = extend_neg_masks(txt_masks, dt), extend_neg_masks(gmap_masks, dt)
+    x = txt_embeds
+    for l in range(cfg.num_x_layers):
+        p = f"{g}.encoder.x_layers.{l}"
+        x = cross_attention_block(P, f"{p}.visual_attention", x, gmap_input_embeds, node_m, cfg, drop, MODE_MLM, l)
+        x = bert_self_attention_block(P, f"{p}.lang_self_att", x, txt_m, cfg, drop, MODE_MLM, l)
+        x = bert_ffn_block(P, f"{p}.lang_inter", f"{p}.lang_output", x, cfg, drop, MODE_MLM, l)
+    return x
+
+
+def mlm_head(P, cfg: PlannerConfig, hidden: Tensor) -> Tensor:
+    """BertOnlyMLMHead vilmodel.py:258-299: dense -> gelu -> LayerNorm -> decoder tied to the word embeddings + bias."""
+    h = gelu_erf(linear(hidden, P["mlm_head.predictions.transform.dense.weight"], P["mlm_head.predictions.transform.dense.bias"]))
+    h = layer_norm(h, P["mlm_head.predictions.transform.LayerNorm.weight"], P["mlm_head.predictions.transform.LayerNorm.bias"],
+                   cfg.layer_norm_eps)
+    return h @ P["embeddings.word_embeddings.weight"].t() + P["mlm_head.predictions.bias"]
+
+
+def mlm_step(P, cfg: PlannerConfig, batch, drop=None):
+    """The pre-training MLM task (pretrain_cmt.py:141-163): masked-token prediction from the text after it has attended
+    to the trajectory graph; txt_labels = -1 on unmasked positions; loss = mean over masked tokens (train_r2r.py:247)."""
+    txt = forward_txt(P, cfg, batch["txt_ids"], batch["txt_masks"], drop)
+    pano, _ = forward_panorama(P, cfg, batch["rgb_fts"], batch["dep_fts"], batch["loc_fts"], batch["nav_types"],
+                               batch["view_lens"], drop)
+    gimg = aggregate_gmap_features(pano, batch["traj"])
+    G = batch["gmap_step_ids"].shape[1]
+    if gimg.shape[1] < G:
+        gimg = torch.cat([gimg, torch.zeros(gimg.shape[0], G - gimg.shape[1], gimg.shape[2], dtype=gimg.dtype)], 1)
+    nodes = gmap_input_embedding(P, cfg, gimg, batch["gmap_step_ids"], batch["gmap_pos_fts"])
+    hid = forward_mlm_hidden(P, cfg, txt, batch["txt_masks"], nodes, batch["gmap_masks"], drop)
+    sel = batch["txt_labels"] != -1
+    logits = mlm_head(P, cfg, hid[sel])
+    labels = batch["txt_labels"][sel]
+    loss = cross_entropy_sum(logits, labels) / max(int(sel.sum()), 1)
+    return {"txt_embeds": txt, "mlm_hidden": hid, "mlm_logits": logits, "loss": loss}
+
+
+def mlm_step_with_grads(P, cfg: PlannerConfig, batch, drop=None):
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    outs = mlm_step(Pg, cfg, batch, drop)
+    outs["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in outs.items()}, grads
 
 
 def sap_step_with_grads(P, cfg: PlannerConfig, batch, drop=None):
