@@ -67,7 +67,7 @@ class Config(ctypes.Structure):
                 ("vocab", ctypes.c_int32), ("max_pos", ctypes.c_int32), ("type_vocab", ctypes.c_int32),
                 ("img_feat", ctypes.c_int32), ("dep_feat", ctypes.c_int32), ("ang_feat", ctypes.c_int32),
                 ("max_steps", ctypes.c_int32), ("use_depth", ctypes.c_int32), ("use_sprels", ctypes.c_int32),
-                ("ln_eps", ctypes.c_float), ("dtype", ctypes.c_int32)]
+                ("ln_eps", ctypes.c_float), ("dtype", ctypes.c_int32), ("use_lang2visn", ctypes.c_int32)]
 
 
 class ParamInfo(ctypes.Structure):

@@ -572,6 +572,49 @@ __global__ __launch_bounds__(256) void sap_ce_kernel(const float* __restrict__ l
   }
 }
 
+// Masked-LM cross-entropy over the vocabulary (pretrain_cmt.py:155-159, reduction 'none' then .mean()): one workgroup per
+// masked token.  logits fp32 [Nm, ldv] (columns >= V are padding); writes dlogits = scale*(softmax - onehot) in the
+// operand dtype (padding columns 0) and accumulates scale * nll into *loss.
+template <typename T>
+__global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                       float* __restrict__ loss, T* __restrict__ dl, int V, int ldv, float scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* s = logits + (long)row * ldv;
+  float mx = -INFINITY;
+  for (int k = tid; k < V; k += 256) mx = fmaxf(mx, s[k]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = tid; k < V; k += 256) sum += expf(s[k] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float lse = mx + logf(red[0] + red[1] + red[2] + red[3]);
+  const long y = labels[row];
+  T* d = dl + (long)row * ldv;
+  for (int k = tid; k < ldv; k += 256) {
+    float g = 0.f;
+    if (k < V) g = scale * (expf(s[k] - lse) - (k == y ? 1.f : 0.f));
+    Elem<T>::st(d + k, g);
+  }
+  if (tid == 0) atomicAdd(loss, scale * (lse - s[y]));
+}
+
+// d <- d * gelu'(z)   (BertPredictionHeadTransform's activation, between a LayerNorm backward and a weight gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(T* __restrict__ d, const T* __restrict__ z, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = Elem<T>::ld(z + i);
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    Elem<T>::st(d + i, Elem<T>::ld(d + i) * (cdf + x * pdf));
+  }
+}
+
 // --------------------------------------------------------------------------------------
 // Weighted gather-sum (node aggregation and its transpose for backward):
 //   out[n,:] (+)= sum_{j in [ptr[n],ptr[n+1])} w[j] * src[idx[j],:]
@@ -785,6 +828,23 @@ int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogi
   ETP_REQUIRE(B > 0 && G > 0, "bad dims");
   hipLaunchKernelGGL(sap_ce_kernel, dim3(row_grid(B, 1024)), dim3(256), 0, st, logits, labels, loss, dlogits, B, G, scale, ignore_index);
   ETP_CHECK_LAUNCH("sap_ce");
+  return ETP_OK;
+}
+
+int vocab_ce(int dtype, const float* logits, const int64_t* labels, float* loss, void* dl, int Nm, int V, int ldv, float scale,
+             hipStream_t st) {
+  ETP_REQUIRE(logits && labels && loss && dl && Nm > 0 && V > 0 && ldv >= V, "bad arguments");
+  if (dtype == ETP_BF16) hipLaunchKernelGGL((vocab_ce_kernel<bf16_t>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (bf16_t*)dl, V, ldv, scale);
+  else hipLaunchKernelGGL((vocab_ce_kernel<float>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (float*)dl, V, ldv, scale);
+  ETP_CHECK_LAUNCH("vocab_ce");
+  return ETP_OK;
+}
+int gelu_bwd_inplace(int dtype, void* d, const void* z, long n, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  const int grid = (int)std::min<long>((n + 255) / 256, 2048);
+  if (dtype == ETP_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)d, (const bf16_t*)z, n);
+  else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)d, (const float*)z, n);
+  ETP_CHECK_LAUNCH("gelu_bwd");
   return ETP_OK;
 }
 

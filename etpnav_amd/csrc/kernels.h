@@ -57,6 +57,9 @@ int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStre
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st);
 int scale_f32(float* p, long n, float scale, hipStream_t st);
 int copy_f32(const float* src, float* dst, long n, hipStream_t st);
+int vocab_ce(int dtype, const float* logits, const int64_t* labels, float* loss, void* dl, int Nm, int V, int ldv, float scale,
+             hipStream_t st);
+int gelu_bwd_inplace(int dtype, void* d, const void* z, long n, hipStream_t st);
 int zero_f32(float* dst, long n, hipStream_t st);
 
 // optim.hip: fused AdamW (+ bf16 shadow refresh + gradient zeroing) and the gradient norm / non-finite scan

@@ -25,7 +25,8 @@ struct AttnP { int qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
 struct FfnP { int i_w, i_b, o_w, o_b, ln_g, ln_b; };
 struct TxtLayerP { AttnP att; FfnP ffn; };
 struct PanoLayerP { int in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_g, n1_b, n2_g, n2_b; };
-struct XLayerP { int q_w, q_b, kv_w, kv_b, xo_w, xo_b, xln_g, xln_b; AttnP self; FfnP ffn; };
+struct XLayerP { int q_w, q_b, kv_w, kv_b, xo_w, xo_b, xln_g, xln_b; AttnP self; FfnP ffn;
+                 AttnP lself; FfnP lffn; };      // language side (forward_lang2visn), pre-training variant only
 
 struct PInfo { std::string name; int ndim; long shape[2]; int region; long offset; long numel; };
 
@@ -44,6 +45,7 @@ struct etp_planner {
   int gpos_w, gpos_b, gpos_g, gpos_bb, step_emb, sp_w, sp_b;
   std::vector<etp::XLayerP> xl;
   int sap0_w, sap0_b, sap2_g, sap2_b, sap4_w, sap4_b;
+  int mlm_w, mlm_b, mlm_g, mlm_bb, mlm_vb;       // MLM head (pre-training variant), -1 otherwise
   // bound arenas
   float* P = nullptr; void* S = nullptr; float* G = nullptr;
   // training-mode dropout (0 = eval): hidden / attention-probability / RGB-feature ("drop_env") rates and the step seed
@@ -195,6 +197,10 @@ static void build_layout(etp_planner* pl) {
     x.xo_b = vec(p + ".visual_attention.output.dense.bias", H);
     x.xln_g = vec(p + ".visual_attention.output.LayerNorm.weight", H);
     x.xln_b = vec(p + ".visual_attention.output.LayerNorm.bias", H);
+    if (c.use_lang2visn) {     // GraphLXRTXLayer.__init__ pretrain vilmodel.py:371-376
+      x.lself = self_att(p + ".lang_self_att");
+      x.lffn = ffn(p + ".lang_inter", p + ".lang_output");
+    }
     pl->xl.push_back(x);
   }
   if (c.use_sprels) {
@@ -209,6 +215,15 @@ static void build_layout(etp_planner* pl) {
   pl->sap2_b = vec("global_sap_head.net.2.bias", H);
   pl->sap4_w = small("global_sap_head.net.4.weight", 1, H);
   pl->sap4_b = vec("global_sap_head.net.4.bias", 1);
+  if (c.use_lang2visn) {       // BertOnlyMLMHead vilmodel.py:258-299; the decoder weight is the word-embedding table (tied)
+    pl->mlm_w = mat("mlm_head.predictions.transform.dense.weight", H, H);
+    pl->mlm_b = vec("mlm_head.predictions.transform.dense.bias", H);
+    pl->mlm_g = vec("mlm_head.predictions.transform.LayerNorm.weight", H);
+    pl->mlm_bb = vec("mlm_head.predictions.transform.LayerNorm.bias", H);
+    pl->mlm_vb = vec("mlm_head.predictions.bias", c.vocab);
+  } else {
+    pl->mlm_w = pl->mlm_b = pl->mlm_g = pl->mlm_bb = pl->mlm_vb = -1;
+  }
 
   long off = 0;
   for (int region = 0; region < 3; ++region) {
@@ -1274,5 +1289,220 @@ int etp_nav_bwd_kv(etp_planner* p, const float* d_embeds, const float* d_logits,
   ETP_REQUIRE(kvbuf && d_kv, "K/V cache and d_kv required");
   return nav_bwd_impl(p, d_embeds, d_logits, nullptr, kvbuf, txt_mask, step_ids, pos, gmask, visited, dists, B, L, G, nullptr, d_kv,
                       d_img, stash, ws, stream);
+}
+}  // extern "C"
+
+// ======================================================================================
+// Pre-training MLM task: GlocalTextPathCMT.forward_mlm pretrain vilmodel.py:708-754 ->
+// GraphLXRTXLayer.forward_lang2visn :400-411 in every x-layer (the text attends to the UNCHANGING graph-node inputs) ->
+// BertOnlyMLMHead :258-299 on the masked positions (pretrain_cmt.py:141-163) -> cross-entropy over the vocabulary.
+// The decoder is tied to the word-embedding table: its gradient accumulates into that table's gradient.
+// ======================================================================================
+namespace {
+constexpr int MODE_MLM = 4;
+struct MlmLayerStash { void *q, *kv, *P, *ctx; float* s; float* st; Act y; void* Pd; SelfAttStash self; FfnStash ffn; };
+struct MlmStash {
+  void* langT; Act nodes; float* st0;
+  std::vector<MlmLayerStash> layers;
+  void *wordT, *hm, *tz, *tg, *hn, *dl; float* stn; float* logits;
+};
+MlmStash plan_mlm(const etp_planner* pl, Bump& b, int Bn, int L, int G, int Nm) {
+  const etp_config& c = pl->cfg;
+  const int dt = c.dtype;
+  const size_t es = dtype_size(dt);
+  const long Mt = (long)Bn * L, Mg = (long)Bn * G;
+  const int H = c.hidden, ldG = (int)round_up(G, 8), ldL = (int)round_up(L, 8);
+  const long ldv = round_up(c.vocab, 8);
+  MlmStash s;
+  s.langT = dt == ETP_BF16 ? b.take(Mt * H * es) : nullptr;
+  s.nodes = take_act(b, dt, Mg * H);
+  s.st0 = (float*)b.take(Mg * 2 * sizeof(float));
+  for (int l = 0; l < c.n_x; ++l) {
+    MlmLayerStash x;
+    x.q = b.take(Mt * H * es);
+    x.kv = b.take(Mg * 2 * H * es);
+    x.P = b.take((size_t)Bn * c.heads * L * ldG * es);
+    x.ctx = b.take(Mt * H * es);
+    x.s = (float*)b.take(Mt * H * 4);
+    x.st = (float*)b.take(Mt * 2 * sizeof(float));
+    x.y = take_act(b, dt, Mt * H);
+    x.Pd = attn_needs_unfused(dt, L, G) ? b.take((size_t)Bn * c.heads * L * ldG * es) : nullptr;
+    x.self = plan_self(b, dt, Mt, Bn, c.heads, L, ldL, H);
+    x.ffn = plan_ffn(b, dt, Mt, H, c.inter);
+    s.layers.push_back(x);
+  }
+  s.wordT = dt == ETP_BF16 ? b.take((size_t)c.vocab * H * es) : nullptr;
+  s.hm = b.take((size_t)Nm * H * es);
+  s.tz = b.take((size_t)Nm * H * es);
+  s.tg = b.take((size_t)Nm * H * es);
+  s.hn = b.take((size_t)Nm * H * es);
+  s.stn = (float*)b.take((size_t)Nm * 2 * sizeof(float));
+  s.dl = b.take((size_t)Nm * ldv * es);
+  s.logits = (float*)b.take((size_t)Nm * ldv * 4);
+  return s;
+}
+struct MlmWs { float* g; float* d_nodes; void *d_hn, *d_tg; float* d_hm; std::vector<BwdWs> ffn, self, cross; std::vector<void*> dq, dkv, dPx; };
+MlmWs plan_mlm_ws(const etp_planner* pl, Bump& b, int Bn, int L, int G, int Nm) {
+  const etp_config& c = pl->cfg;
+  const int dt = c.dtype;
+  const size_t es = dtype_size(dt);
+  const long Mt = (long)Bn * L, Mg = (long)Bn * G;
+  const int H = c.hidden, ldL = (int)round_up(L, 8), ldG = (int)round_up(G, 8);
+  MlmWs w;
+  w.g = (float*)b.take(Mt * H * 4);
+  w.d_nodes = (float*)b.take(Mg * H * 4);
+  w.d_hn = b.take((size_t)Nm * H * es);
+  w.d_tg = b.take((size_t)Nm * H * es);
+  w.d_hm = (float*)b.take((size_t)Nm * H * 4);
+  for (int l = 0; l < c.n_x; ++l) {
+    w.ffn.push_back(plan_ws(b, dt, Mt, Bn, c.heads, L, ldL, H, c.inter));
+    w.self.push_back(plan_ws(b, dt, Mt, Bn, c.heads, L, ldL, H, c.inter));
+    w.cross.push_back(plan_ws(b, dt, Mt, Bn, c.heads, L, ldL, H, c.inter));
+    w.dq.push_back(b.take(Mt * H * es));
+    w.dkv.push_back(b.take(Mg * 2 * H * es));
+    w.dPx.push_back(b.take((size_t)Bn * c.heads * L * ldG * es));
+  }
+  return w;
+}
+}  // namespace
+
+extern "C" {
+int64_t etp_mlm_stash_bytes(const etp_planner* p, int B, int L, int G, int Nm) {
+  if (!p || !p->cfg.use_lang2visn) return 0;
+  Bump b(nullptr);
+  plan_mlm(p, b, B, L, G, Nm);
+  return (int64_t)b.off + 256;
+}
+int64_t etp_mlm_ws_bytes(const etp_planner* p, int B, int L, int G, int Nm) {
+  if (!p || !p->cfg.use_lang2visn) return 0;
+  Bump b(nullptr);
+  plan_mlm_ws(p, b, B, L, G, Nm);
+  return (int64_t)b.off + 256;
+}
+
+int etp_mlm_fwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const int64_t* step_ids, const float* img,
+                const float* pos, const uint8_t* gmask, const int32_t* sel_ptr, const int32_t* sel_idx, const float* sel_w,
+                const int64_t* labels, int B, int L, int G, int Nm, float scale, float* loss, void* stash, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->cfg.use_lang2visn, "planner was not built with use_lang2visn (pre-training variant)");
+  ETP_REQUIRE(txt && txt_mask && step_ids && img && pos && gmask && sel_ptr && sel_idx && sel_w && labels && loss && stash &&
+                  B > 0 && L > 0 && G > 0 && Nm > 0,
+              "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  Bump b(stash);
+  MlmStash s = plan_mlm(p, b, B, L, G, Nm);
+  const etp_config& cf = p->cfg;
+  const int H = c.H, Mt = B * L, Mg = B * G, ldG = (int)round_up(G, 8);
+  const float eps = cf.ln_eps;
+  const long ldv = round_up(cf.vocab, 8);
+  Act x;
+  x.f = const_cast<float*>(txt);
+  x.t = x.f;
+  if (c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, s.langT, (long)Mt * H, c.st)); x.t = s.langT; }
+  ETP_TRY(gmap_embed_fwd(c.dt, img, step_ids, pos, p->pf(p->step_emb), p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g),
+                         p->pf(p->gpos_bb), s.nodes.f, lp(s.nodes, c.dt), s.st0, Mg, H, cf.ang_feat + 3, c.st));
+  for (int l = 0; l < cf.n_x; ++l) {
+    const XLayerP& q = p->xl[l];
+    MlmLayerStash& t = s.layers[l];
+    // visual_attention with the roles swapped: queries from the text, keys/values from the node inputs
+    ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.q, H, Mt, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    ETP_TRY(linear_fwd(c, s.nodes.t, H, q.kv_w, q.kv_b, t.kv, 2 * H, Mg, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+    AttnBuf a{t.q, (long)H, t.kv, 2L * H, offs(t.kv, H, c.es), 2L * H, B, L, G, ldG, gmask, 0, nullptr, nullptr, nullptr};
+    a.Pd = t.Pd;
+    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st, att(c, MODE_MLM, l, SITE_X_P)));
+    ETP_TRY(linear_fwd_s(c, t.ctx, H, q.xo_w, q.xo_b, t.s, Mt, H, H, x.f, hid(c, MODE_MLM, l, SITE_X_O)));
+    ETP_TRY(ln_fwd_s(c.dt, t.s, p->pf(q.xln_g), p->pf(q.xln_b), t.y.f, lp(t.y, c.dt), t.st, Mt, H, eps, c.st));
+    ETP_TRY(self_att_fwd(c, q.lself, t.y, t.self, B, L, txt_mask, nullptr, nullptr, nullptr, eps, MODE_MLM, l));
+    ETP_TRY(ffn_fwd(c, q.lffn, t.self.y, t.ffn, Mt, eps, MODE_MLM, l));
+    x = t.ffn.y;
+  }
+  // masked positions only (pretrain_cmt.py:148-149), then the MLM head
+  ETP_TRY(gather_sum(c.dt, x.t, sel_ptr, sel_idx, sel_w, s.hm, Nm, H, 0, c.st));
+  ETP_TRY(linear_fwd(c, s.hm, H, p->mlm_w, p->mlm_b, s.tg, H, Nm, H, H, ETP_ACT_GELU, s.tz, nullptr, 0));
+  ETP_TRY(ln_fwd(c.dt, s.tg, p->pf(p->mlm_g), p->pf(p->mlm_bb), s.hn, s.stn, Nm, H, eps, c.st));
+  const void* wordT = p->pf(p->word);
+  if (c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(p->pf(p->word), s.wordT, (long)cf.vocab * H, c.st)); wordT = s.wordT; }
+  {
+    GemmArgs g = base_args();      // logits[Nm, V] = hn . word^T + bias   (decoder tied to the embedding table)
+    g.A = s.hn; g.lda = H; g.B = wordT; g.ldb = H; g.C = s.logits; g.ldc = ldv;
+    g.M = Nm; g.N = cf.vocab; g.K = H; g.bias = p->pf(p->mlm_vb);
+    ETP_TRY(launch_gemm(c.dt, ETP_F32, 0, 0, g, 1, c.st));
+  }
+  return vocab_ce(c.dt, s.logits, labels, loss, s.dl, Nm, cf.vocab, (int)ldv, scale, c.st);
+}
+
+int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const int64_t* step_ids, const float* pos,
+                const uint8_t* gmask, const int32_t* selT_ptr, const int32_t* selT_idx, const float* selT_w, int B, int L, int G,
+                int Nm, float* d_txt, float* d_img, void* stash, void* ws, etp_stream_t stream) {
+  ETP_REQUIRE(p && p->P && p->G && p->cfg.use_lang2visn, "planner was not built with use_lang2visn (pre-training variant)");
+  ETP_REQUIRE(txt && txt_mask && step_ids && pos && gmask && selT_ptr && selT_idx && selT_w && d_txt && d_img && stash && ws &&
+                  B > 0 && L > 0 && G > 0 && Nm > 0,
+              "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  std::vector<std::function<int()>> pend;
+  if (c.sw != c.st) c.pend = &pend;
+  Bump b(stash);
+  MlmStash s = plan_mlm(p, b, B, L, G, Nm);
+  Bump wb(ws);
+  MlmWs w = plan_mlm_ws(p, wb, B, L, G, Nm);
+  const etp_config& cf = p->cfg;
+  const int H = c.H, Mt = B * L, Mg = B * G, ldG = (int)round_up(G, 8);
+  const long ldv = round_up(cf.vocab, 8);
+  const void* wordT = c.dt == ETP_BF16 ? s.wordT : (const void*)p->pf(p->word);
+  // head: dlogits (saved by the forward CE) -> tied decoder / bias gradients, d hn
+  ETP_TRY(linear_wgrad(c, s.dl, ldv, s.hn, H, p->word, -1, Nm, cf.vocab, H));
+  {
+    const int dt = c.dt;
+    hipStream_t sw = c.sw;
+    const void* dlp = s.dl;
+    float* dvb = p->gf(p->mlm_vb);                 // the bias slot is padded to ldv entries in the arena (64-element alignment)
+    ETP_TRY(on_side(c, [=]() -> int { return colsum(dt, dlp, ldv, dvb, Nm, (int)ldv, sw); }));
+  }
+  {
+    GemmArgs g = base_args();      // d hn[Nm, H] = dlogits[Nm, V] . word[V, H]
+    g.A = s.dl; g.lda = ldv; g.B = wordT; g.ldb = H; g.C = w.d_hn; g.ldc = H;
+    g.M = Nm; g.N = H; g.K = cf.vocab;
+    ETP_TRY(launch_gemm(c.dt, c.dt, 0, 1, g, 1, c.st));
+  }
+  ETP_TRY(ln_bwd(c.dt, w.d_hn, s.tg, s.stn, p->pf(p->mlm_g), nullptr, w.d_tg, p->gf(p->mlm_g), p->gf(p->mlm_bb), Nm, H, c.st));
+  ETP_TRY(gelu_bwd_inplace(c.dt, w.d_tg, s.tz, (long)Nm * H, c.st));
+  ETP_TRY(linear_wgrad(c, w.d_tg, H, s.hm, H, p->mlm_w, p->mlm_b, Nm, H, H));
+  ETP_TRY(linear_dgrad_s(c, w.d_tg, H, p->mlm_w, w.d_hm, Nm, H, H, nullptr));
+  // scatter the masked rows back into the text gradient (zero elsewhere)
+  float* g = w.g;
+  ETP_TRY(gather_sum(ETP_F32, w.d_hm, selT_ptr, selT_idx, selT_w, g, Mt, H, 0, c.st));
+  for (int l = cf.n_x - 1; l >= 0; --l) {
+    const XLayerP& q = p->xl[l];
+    const MlmLayerStash& t = s.layers[l];
+    Act x;
+    if (l == 0) { x.f = const_cast<float*>(txt); x.t = c.dt == ETP_BF16 ? s.langT : (void*)x.f; }
+    else x = s.layers[l - 1].ffn.y;
+    const BwdWs& wc = w.cross[l];
+    ETP_TRY(ffn_bwd(c, q.lffn, t.self.y, t.ffn, Mt, g, w.ffn[l], MODE_MLM, l));
+    ETP_TRY(self_att_bwd(c, q.lself, t.y, t.self, B, L, txt_mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, w.self[l],
+                         MODE_MLM, l));
+    const Drop dx = hid(c, MODE_MLM, l, SITE_X_O);
+    ETP_TRY(ln_bwd_s(c.dt, g, t.s, t.st, p->pf(q.xln_g), nullptr, wc.t1.f, lp2(c, wc.t1, dx), p->gf(q.xln_g), p->gf(q.xln_b), Mt, H,
+                     c.st, dx));
+    const void* dso = op2(c, wc.t1, dx);
+    ETP_TRY(linear_wgrad(c, dso, H, t.ctx, H, q.xo_w, q.xo_b, Mt, H, H));
+    ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, wc.t2, H, Mt, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+    AttnBuf a{t.q, (long)H, t.kv, 2L * H, offs(t.kv, H, c.es), 2L * H, B, L, G, ldG, gmask, 0, nullptr, nullptr, nullptr};
+    a.Pd = t.Pd;
+    void* dq = w.dq[l]; void* dkv = w.dkv[l];
+    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, wc.t2, H, w.dPx[l], dq, H, dkv, 2L * H, offs(dkv, H, c.es), 2L * H, 0.125f, nullptr,
+                          nullptr, c.st, att(c, MODE_MLM, l, SITE_X_P)));
+    ETP_TRY(linear_wgrad(c, dq, H, x.t, H, q.q_w, q.q_b, Mt, H, H));
+    ETP_TRY(linear_dgrad_s(c, dq, H, q.q_w, g, Mt, H, H, wc.t1.f));
+    ETP_TRY(linear_wgrad(c, dkv, 2 * H, s.nodes.t, H, q.kv_w, q.kv_b, Mg, 2 * H, H));
+    ETP_TRY(linear_dgrad_s(c, dkv, 2 * H, q.kv_w, w.d_nodes, Mg, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
+    ETP_TRY(flush_side(c));
+  }
+  ETP_TRY(copy_f32(g, d_txt, (long)Mt * H, c.st));
+  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(w.d_nodes, 0, (size_t)Mg * H * 4, c.st));
+  ETP_TRY(copy_f32(w.d_nodes, d_img, (long)Mg * H, c.st));
+  ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
+                         p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
+                         cf.ang_feat + 3, c.st));
+  return join_wgrads(c);
 }
 }  // extern "C"

@@ -54,6 +54,7 @@ def make_c_config(config, dtype: torch.dtype) -> _lib.Config:
     c.use_depth = 1 if _cfg_get(config, "use_depth_embedding", True) else 0
     c.use_sprels = 1 if _cfg_get(config, "graph_sprels", True) else 0
     c.ln_eps = float(_cfg_get(config, "layer_norm_eps", 1e-12))
+    c.use_lang2visn = 1 if _cfg_get(config, "use_lang2visn_attn", False) else 0
     if dtype == torch.float32:
         c.dtype = _lib.ETP_F32
     elif dtype == torch.bfloat16:

@@ -1,0 +1,103 @@
+"""The pre-training MLM task as one device-side step, straight through the C ABI.
+
+Mirrors ``GlocalTextPathCMTPreTraining.forward(batch, 'mlm')`` + ``.mean()`` + ``backward()``
+(pretrain_src/pretrain_src/model/pretrain_cmt.py:141-163, train_r2r.py:240-250): text encoder, panorama encoder over every
+trajectory step, node aggregation, ``forward_lang2visn`` through every x-layer, tied MLM head on the masked tokens, mean
+token cross-entropy, gradients of every parameter.  The model must be built with ``use_lang2visn_attn=True`` (the
+pre-training config, run_pt/r2r_model_config_dep.json).  The SAP task of the same model is ``PlannerStep`` with
+``batch['traj']`` (etpnav_amd/step.py).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+from .graph_inputs import pack_traj_csr
+from .planner import GlocalTextPathNavCMT
+
+
+class MlmStep:
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], dropout=None, drop_seed: int = 0):
+        """batch: etpnav_amd.synthetic.make_sap_batch layout + ``txt_labels`` [B,L] (-1 = not masked, else the token id)."""
+        eng = self.eng = model._engine
+        eng.require_gpu()
+        if not eng.cconf.use_lang2visn:
+            raise _lib.EtpError("the MLM task needs a model built with use_lang2visn_attn=True (pre-training config)")
+        self.model, self.L = model, eng.L
+        dev = eng.device
+        if dropout == "config":
+            c = model.config
+            g = lambda k: float(c[k] if isinstance(c, dict) and k in c else getattr(c, k, 0.1))
+            dropout = (g("hidden_dropout_prob"), g("attention_probs_dropout_prob"), g("pred_head_dropout_prob"), 0.0)
+        self.dropout, self.drop_seed, self.step_no = dropout, int(drop_seed) & 0xFFFFFFFF, 0
+        B, Lt = batch["txt_ids"].shape
+        Bp, V = batch["rgb_fts"].shape[:2]
+        G = batch["gmap_step_ids"].shape[1]
+        H = eng.cconf.hidden
+        self.dims = (B, Lt, Bp, V, G, H)
+        mv = lambda x, dt=None: (x.to(dt) if dt is not None else x).contiguous().to(dev)
+        self.inp = {
+            "txt_ids": mv(batch["txt_ids"], torch.int64), "txt_masks": mv(batch["txt_masks"], torch.bool),
+            "rgb": mv(batch["rgb_fts"], torch.float32), "dep": mv(batch["dep_fts"], torch.float32),
+            "loc": mv(batch["loc_fts"], torch.float32), "nav": mv(batch["nav_types"], torch.int64),
+            "view_lens": mv(batch["view_lens"], torch.int64), "step_ids": mv(batch["gmap_step_ids"], torch.int64),
+            "pos": mv(batch["gmap_pos_fts"], torch.float32), "gmask": mv(batch["gmap_masks"], torch.bool),
+        }
+        tr = batch["traj"]
+        fwd, bwd = pack_traj_csr(tr["traj_vp_lens"], tr["traj_vpids"], tr["traj_cand_vpids"], tr["gmap_vpids"], V, G)
+        self.csr_f, self.csr_b = tuple(x.to(dev) for x in fwd), tuple(x.to(dev) for x in bwd)
+        # masked positions: row gather of the text (and its transpose for the backward)
+        sel = (batch["txt_labels"] != -1).reshape(-1)
+        rows = torch.nonzero(sel).reshape(-1).to(torch.int32)
+        Nm = self.Nm = int(rows.numel())
+        if Nm == 0:
+            raise ValueError("no masked tokens in the batch")
+        i32 = lambda x: torch.as_tensor(x, dtype=torch.int32).to(dev)
+        self.sel = (i32(torch.arange(Nm + 1)), rows.to(dev), torch.ones(Nm, dtype=torch.float32, device=dev))
+        ptr_t = torch.zeros(B * Lt + 1, dtype=torch.int32)
+        ptr_t[1:] = torch.cumsum(sel.to(torch.int32), 0)
+        self.selT = (ptr_t.to(dev), i32(torch.arange(Nm)), torch.ones(Nm, dtype=torch.float32, device=dev))
+        self.labels = mv(batch["txt_labels"].reshape(-1)[sel], torch.int64)
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+        self.txt, self.pano, self.pmask = e(B, Lt, H), e(Bp, V, H), e(Bp, V, dt=torch.bool)
+        self.gimg, self.loss = e(B, G, H), torch.zeros(1, dtype=torch.float32, device=dev)
+        self.d_txt, self.d_gimg, self.d_pano = e(B, Lt, H), e(B, G, H), e(Bp, V, H)
+        h = eng.handle
+        self.st_txt = eng.buf(self.L.etp_txt_stash_bytes(h, B, Lt)); self.ws_txt = eng.buf(self.L.etp_txt_ws_bytes(h, B, Lt))
+        self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, Bp, V)); self.ws_pano = eng.buf(self.L.etp_pano_ws_bytes(h, Bp, V))
+        self.st_mlm = eng.buf(self.L.etp_mlm_stash_bytes(h, B, Lt, G, Nm)); self.ws_mlm = eng.buf(self.L.etp_mlm_ws_bytes(h, B, Lt, G, Nm))
+
+    def run_eager(self, backward: bool = True):
+        L, eng, i = self.L, self.eng, self.inp
+        h, s = eng.handle, eng.stream()
+        B, Lt, Bp, V, G, H = self.dims
+        self.step_no += 1
+        eng.set_dropout(None if self.dropout is None else
+                        tuple(self.dropout) + ((self.drop_seed << 32) | (self.step_no & 0xFFFFFFFF),))
+        check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
+        check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
+        if backward:
+            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s), "memset grads")
+        check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
+        check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), Bp, V,
+                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s), "pano_fwd")
+        pf, xf, wf = self.csr_f
+        check(L.etp_gather_sum(_lib.ETP_F32, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "aggregate")
+        check(L.etp_mlm_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
+                            ptr(i["gmask"]), ptr(self.sel[0]), ptr(self.sel[1]), ptr(self.sel[2]), ptr(self.labels), B, Lt, G,
+                            self.Nm, 1.0 / self.Nm, ptr(self.loss), ptr(self.st_mlm), s), "mlm_fwd")
+        if not backward:
+            return
+        check(L.etp_mlm_bwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(i["pos"]), ptr(i["gmask"]),
+                            ptr(self.selT[0]), ptr(self.selT[1]), ptr(self.selT[2]), B, Lt, G, self.Nm, ptr(self.d_txt),
+                            ptr(self.d_gimg), ptr(self.st_mlm), ptr(self.ws_mlm), s), "mlm_bwd")
+        pb, xb, wb = self.csr_b
+        check(L.etp_gather_sum(_lib.ETP_F32, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), Bp * V, H, 0, s),
+              "aggregate bwd")
+        check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), Bp, V, None,
+                             ptr(self.st_pano), ptr(self.ws_pano), s), "pano_bwd")
+        check(L.etp_txt_bwd(h, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.st_txt), ptr(self.ws_txt),
+                            s), "txt_bwd")

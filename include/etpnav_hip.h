@@ -207,6 +207,8 @@ typedef struct etp_config {
   int32_t use_depth, use_sprels;
   float ln_eps;                          /* config.layer_norm_eps (1e-12 bert / 1e-5 xlm-r) */
   int32_t dtype;                         /* ETP_F32 | ETP_BF16 */
+  int32_t use_lang2visn;                 /* pre-training variant (run_pt/r2r_model_config_dep.json use_lang2visn_attn): adds the
+                                          * language-side x-layer weights (vilmodel.py:371-376) and the tied MLM head (:258-299) */
 } etp_config;
 
 typedef struct etp_param_info {
@@ -346,6 +348,25 @@ int etp_gmap_assemble(const float* node_pos, const int32_t* node_step, const int
 int etp_vp_gather(const float* cand_fts, const int32_t* cand_ptr, const float* pano_fts, int64_t pano_batch_stride,
                   const uint8_t* cand_mask, int B, int P, int F, int V, float* out_fts, int64_t* nav_types, int64_t* view_lens,
                   etp_stream_t stream);
+
+/* Pre-training MLM task for a planner created with cfg.use_lang2visn = 1:
+ * GlocalTextPathCMT.forward_mlm (pretrain vilmodel.py:708-754): the text (output of etp_txt_fwd) attends to the graph-node
+ * inputs gmap_img_fts + step + position embeddings through forward_lang2visn of every x-layer (:400-411), then
+ * BertOnlyMLMHead (:258-299, decoder tied to the word embeddings) on the Nm masked positions and
+ * *loss += scale * sum of token cross-entropies (pretrain_cmt.py:141-163; scale = 1/Nm for the reference's .mean()).
+ * The masked positions are given as the CSR of a row gather (sel_ptr = 0..Nm, sel_idx = b*L + l, sel_w = 1) and, for the
+ * backward, its transpose over the B*L rows.  etp_mlm_bwd returns d txt_embeds and d gmap_img_fts and accumulates every
+ * parameter gradient, including the tied decoder's into the word-embedding gradient. */
+int64_t etp_mlm_stash_bytes(const etp_planner* p, int B, int L, int G, int Nm);
+int64_t etp_mlm_ws_bytes(const etp_planner* p, int B, int L, int G, int Nm);
+int etp_mlm_fwd(etp_planner* p, const float* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                const float* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks, const int32_t* sel_ptr,
+                const int32_t* sel_idx, const float* sel_w, const int64_t* labels, int B, int L, int G, int Nm, float scale,
+                float* loss, void* stash, etp_stream_t stream);
+int etp_mlm_bwd(etp_planner* p, const float* txt_embeds, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                const float* gmap_pos_fts, const uint8_t* gmap_masks, const int32_t* selT_ptr, const int32_t* selT_idx,
+                const float* selT_w, int B, int L, int G, int Nm, float* d_txt_embeds, float* d_gmap_img_fts, void* stash,
+                void* ws, etp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * hipGraph helpers (launch-bound inner loops are captured once and replayed) and timing.

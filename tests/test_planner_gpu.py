@@ -333,3 +333,34 @@ def test_sap_pretraining_step_matches_oracle(dtype, atol, rel):
     _assert_step_matches(outs, grads, got, grads_of(model), atol=atol, rel=rel)
     assert (step.gimg.cpu() - outs["gmap_img_fts"]).abs().max().item() < atol
     step.close()
+
+
+# ---- the pre-training MLM task (pretrain_cmt.py:141-163) --------------------------------------------
+@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 3e-4, 2e-3), (torch.bfloat16, 1e-1, 0.1)])
+def test_mlm_pretraining_step_matches_oracle(dtype, atol, rel):
+    """Same case as tests/golden/pretrain_tasks.npz (where the oracle is pinned to the REAL pre-training model): text ->
+    forward_lang2visn through every x-layer -> tied MLM head on the masked tokens -> mean CE; the loss and the gradient of
+    every parameter (incl. the tied decoder's contribution to the word embeddings and the language-side x-layer weights)."""
+    from oracle.make_golden_pretrain import make_case
+    from etpnav_amd.pretrain import MlmStep
+    cfg, P, batch = make_case()
+    outs, grads = po.mlm_step_with_grads(P, cfg, batch)
+    model = build_model(cfg, P, dtype)
+    step = MlmStep(model, batch)
+    step.run_eager()
+    torch.cuda.synchronize()
+    assert abs(step.loss.item() - outs["loss"].item()) < atol * 3
+    mine = grads_of(model)
+    for k, g in grads.items():
+        err = (mine[k] - g).abs().max().item()
+        assert err < atol + rel * g.abs().max().item(), f"{k}: {err}"
+    # train mode: dropout through the language-side blocks with the oracle's masks
+    if dtype == torch.float32:
+        step = MlmStep(model, batch, dropout=(0.1, 0.1, 0.1, 0.0), drop_seed=9)
+        step.run_eager(); torch.cuda.synchronize()
+        outs, grads = po.mlm_step_with_grads(P, cfg, batch, drop=po.DropSpec(0.1, 0.1, 0.1, 0.0, seed=(9 << 32) | 1))
+        assert abs(step.loss.item() - outs["loss"].item()) < atol * 3
+        mine = grads_of(model)
+        for k, g in grads.items():
+            err = (mine[k] - g).abs().max().item()
+            assert err < atol + rel * g.abs().max().item(), f"train {k}: {err}"
