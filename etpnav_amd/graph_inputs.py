@@ -362,7 +362,9 @@ def pack_traj_csr(traj_vp_lens: Sequence[Sequence[int]], traj_vpids: Sequence[Se
             visited[vp] = ([(base + t) * V + j for j in range(n)], 1.0 / n)
             for j, cvp in enumerate(traj_cand_vpids[i][t]):
                 if cvp not in visited:
-                    unvisited.setdefault(cvp, []).append((base + t) * V + j)
+                    # a candidate slot beyond the step's valid views is a zero row in the reference (embeds * vp_masks,
+                    # :599-600) that still counts in the mean: keep the slot, drop the row
+                    unvisited.setdefault(cvp, []).append((base + t) * V + j if j < n else None)
         if len(gmap_vpids[i]) > G:
             raise ValueError(f"G={G} < {len(gmap_vpids[i])} graph entries")
         for g in range(G):
@@ -370,6 +372,8 @@ def pack_traj_csr(traj_vp_lens: Sequence[Sequence[int]], traj_vpids: Sequence[Se
                 vp = gmap_vpids[i][g]
                 rows, w = visited[vp] if vp in visited else (unvisited[vp], 1.0 / len(unvisited[vp]))
                 for r in rows:
+                    if r is None:
+                        continue
                     idx_f.append(r); w_f.append(w); rev[r].append((i * G + g, w))
             ptr_f.append(len(idx_f))
         base += len(traj_vp_lens[i])

@@ -43,6 +43,8 @@ def make_case(seed=11, B=4, V=6, H=8):
             n = rng.randint(3, V + 1)
             ep_lens.append(n)
             k = rng.randint(1, n)                       # the first k views are candidates
+            if i == 1 and t == 1:
+                k = min(n + 1, V)                       # one candidate slot beyond this step's valid views (a zero row)
             ep_c.append([names[rng.randint(0, 12)] for _ in range(k)])
         seen = []
         for t in range(T):
