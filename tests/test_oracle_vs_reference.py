@@ -20,3 +20,24 @@ def test_oracle_equals_reference_small():
     assert float((ro["global_logits"][fin] - oo["global_logits"][fin]).abs().max()) < 2e-5
     for k in rg:
         assert float((rg[k] - og[k]).abs().max()) < 2e-5, k
+
+
+def test_saved_pretraining_checkpoint_loads_strictly_into_the_real_model():
+    """etpnav_amd.checkpoint.pretrain_state_dict writes exactly the key set of the reference pre-training model
+    (utils/save.py:23-46): the REAL GlocalTextPathCMTPreTraining loads it with strict=True and then reproduces the
+    planner's own parameters."""
+    from oracle import ref_pretrain_harness as rp
+    from etpnav_amd import checkpoint as ck
+    from etpnav_amd.planner import GlocalTextPathNavCMT
+    cfg = po.PlannerConfig.r2r(vocab_size=512, num_l_layers=1, num_pano_layers=1, num_x_layers=1, use_lang2visn_attn=True)
+    P = po.init_params(cfg, seed=2)
+    m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.float32, device="cpu")
+    m.load_state_dict(P, strict=True)
+    real = rp.build_pretrain_model(cfg, po.init_params(cfg, seed=5))          # different weights before loading
+    missing, unexpected = real.load_state_dict(ck.pretrain_state_dict(m), strict=True)
+    assert not missing and not unexpected
+    got = {k: v for k, v in real.state_dict().items()}
+    for k, v in P.items():
+        name = k if k.startswith(("mlm_head.", "global_sap_head.")) else "bert." + k
+        assert torch.equal(got[name], v), k
+    assert got["mlm_head.predictions.decoder.weight"].data_ptr() == got["bert.embeddings.word_embeddings.weight"].data_ptr()
