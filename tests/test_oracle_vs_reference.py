@@ -41,3 +41,31 @@ def test_saved_pretraining_checkpoint_loads_strictly_into_the_real_model():
         name = k if k.startswith(("mlm_head.", "global_sap_head.")) else "bert." + k
         assert torch.equal(got[name], v), k
     assert got["mlm_head.predictions.decoder.weight"].data_ptr() == got["bert.embeddings.word_embeddings.weight"].data_ptr()
+
+
+@pytest.mark.parametrize("seed", list(range(30, 42)))
+def test_graph_assembly_randomised_against_the_real_classes(seed):
+    """Beyond the committed golden episodes: random rollouts through the REAL GraphMap and through GraphMapLite must pack
+    identically, and the oracle's assembly must equal the trainer's REAL _nav_gmap_variable on them."""
+    import numpy as np
+    from oracle import graph_oracle as go
+    from oracle.make_golden_graph import load_reference_graph_utils, reference_batch_outputs
+    from etpnav_amd.graph_inputs import GraphMapLite, pack_episode
+    gu = load_reference_graph_utils()
+    steps = 2 + seed % 9
+    merge = bool(seed % 2)
+    real = go.simulate(gu.GraphMap, seed, steps, merge_ghost=merge)
+    lite = go.simulate(GraphMapLite, seed, steps, merge_ghost=merge)
+    a = pack_episode(real[0], real[1], real[2], real[3])
+    b = pack_episode(lite[0], lite[1], lite[2], lite[3])
+    assert a["n_nodes"] == b["n_nodes"] and a["n_ghost"] == b["n_ghost"] and a["cur_node"] == b["cur_node"]
+    for k in ("node_pos", "node_step", "adj", "ghost_pos"):
+        assert np.allclose(a[k], b[k], atol=1e-12), k
+    assert a["ghost_fronts"] == b["ghost_fronts"]
+    ref = reference_batch_outputs(gu, [real[0]], [real[1]], [real[2]], [real[3]])
+    L = 1 + a["n_nodes"] + a["n_ghost"]
+    got = go.assemble(b, G=L)
+    assert np.array_equal(got["gmap_step_ids"], ref["gmap_step_ids"][0].numpy())
+    assert np.array_equal(got["gmap_visited_masks"], ref["gmap_visited_masks"][0].numpy())
+    assert np.abs(got["gmap_pos_fts"] - ref["gmap_pos_fts"][0].numpy()).max() < 2e-6
+    assert np.abs(got["gmap_pair_dists"] - ref["gmap_pair_dists"][0].numpy()).max() < 2e-6
