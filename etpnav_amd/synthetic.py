@@ -104,3 +104,48 @@ def make_sap_batch(vocab_size: int, image_feat_size: int, depth_feat_size: int, 
                 "traj": {"traj_step_lens": [T] * B, "traj_vp_lens": lens, "traj_vpids": vpids, "traj_cand_vpids": cands,
                          "gmap_vpids": gvps}})
     return out
+
+
+# ---- synthetic rollout driver for graph-input assembly (shared by the golden generators, the tests and tools/graph_probe.py)
+import numpy as np  # noqa: E402
+
+
+def simulate_rollout(GraphCls, seed, steps, merge_ghost=True, embed_dim=8, rows_mode=False):
+    """Drive a GraphMap-like class the way the rollout does (ss_trainer_ETP.py:842-871,977): identify_node ->
+    update_graph -> move to one of the ghosts (delete_ghost) -> repeat.  `cur_ori` is passed as a scalar heading.
+    Every node / candidate view gets a random embedding row appended to `store`; the class receives the row tensors
+    (reference behaviour) or, with rows_mode, the row indices (GraphMapLite's device-store mode).
+    Returns (gmap, cur_vp, cur_pos, cur_heading, store [rows, embed_dim] float32)."""
+    rng = np.random.RandomState(seed)
+    erng = np.random.RandomState(seed + 1000)
+    store = []
+
+    def new_row():
+        store.append(erng.standard_normal(embed_dim).astype(np.float32))
+        r = len(store) - 1
+        return r if rows_mode else torch.from_numpy(store[r])
+
+    gmap = GraphCls(False, 0.5, merge_ghost, 0)             # has_real_pos, loc_noise, merge_ghost, ghost_aug
+    pos = np.array([rng.uniform(-2, 2), 0.2, rng.uniform(-2, 2)])
+    heading = rng.uniform(0, 2 * np.pi)
+    prev_vp = None
+    for stepk in range(steps):
+        k = rng.randint(2, 6)
+        ang = list(rng.uniform(0, 2 * np.pi, size=k))
+        dis = list(rng.uniform(0.6, 2.5, size=k))
+        cur_vp, cand_vp, cand_pos = gmap.identify_node(pos, heading, ang, dis)
+        cur_e = new_row()
+        cand_e = [new_row() for _ in range(k)]
+        gmap.update_graph(prev_vp, stepk + 1, cur_vp, pos, cur_e, cand_vp, cand_pos, cand_e, None)
+        prev_vp = cur_vp
+        if stepk == steps - 1:
+            break
+        ghosts = list(gmap.ghost_pos.keys())
+        if not ghosts:
+            break
+        gvp = ghosts[rng.randint(len(ghosts))]              # move to a ghost; it becomes the next node (:977)
+        new_pos = np.array(gmap.ghost_aug_pos[gvp], dtype=np.float64)
+        heading = rng.uniform(0, 2 * np.pi)
+        gmap.delete_ghost(gvp)
+        pos = new_pos + np.array([0.0, rng.uniform(-0.05, 0.05), 0.0])
+    return gmap, prev_vp, pos, heading, np.stack(store)

@@ -5,7 +5,7 @@ per step plus ~20 ms of all-pairs Dijkstra per graph update.    python tools/gra
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from oracle.graph_oracle import simulate          # synthetic episode driver (test infrastructure; timing harness only)
+from etpnav_amd.synthetic import simulate_rollout as simulate
 from etpnav_amd.graph_inputs import GraphMapLite, pack_episode, pack_batch, assemble_on_device
 
 B = 32
