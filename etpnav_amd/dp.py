@@ -126,8 +126,10 @@ def planner_buckets_layered(model, text_groups: int = 3):
     return ranges, (word_off, word_shape[0], word_shape[1]), groups
 
 
-def planner_buckets(model, split_text: bool = True):
+def planner_buckets(model, split_text: bool = True, dense_word_table: bool = False):
     """Dense bucket ranges for GlocalTextPathNavCMT's arena in backward-completion order, and the sparse word table.
+    dense_word_table=True (the pre-training MLM task: the tied decoder makes the word-embedding gradient dense) reduces the
+    table as one more dense range and returns None for the sparse descriptor.
 
     Arena = [GEMM matrices (text layers first, then pano / x-layers / head) | vectors | embedding tables].
     Backward order of a step: navigation -> panorama -> text, so bucket 0 = non-text matrices (ready after the
@@ -149,4 +151,7 @@ def planner_buckets(model, split_text: bool = True):
         ranges.append((eng.n_matrix, word_off))
     if word_end < eng.total:
         ranges.append((word_end, eng.total))
+    if dense_word_table:
+        ranges.append((word_off, word_end))
+        return ranges, None
     return ranges, (word_off, word_shape[0], word_shape[1])

@@ -104,3 +104,23 @@ def test_layered_buckets_cover_the_arena_once_and_follow_backward_order():
                 layer = int(name.split(".")[2])
                 off = (p.data_ptr() - base) // 4
                 assert (s <= off < e) == (lo <= layer < hi), name
+
+
+def test_pretraining_variant_buckets_cover_language_side_weights_and_dense_word_table():
+    """Pre-training model (use_lang2visn_attn): the language-side x-layer weights and the MLM head land in the non-text
+    matrix / vector buckets, and with dense_word_table (MLM: tied decoder) the word table is one more dense range."""
+    from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
+    m = GlocalTextPathNavCMT(default_config(vocab_size=1024, use_lang2visn_attn=True, num_l_layers=2, num_x_layers=2),
+                             dtype=torch.float32, device="cpu")
+    ranges, sparse = dp.planner_buckets(m, dense_word_table=True)
+    assert sparse is None
+    cover = torch.zeros(m.flat_grads.numel(), dtype=torch.int32)
+    for s, e in ranges:
+        cover[s:e] += 1
+    seen_lang = seen_head = False
+    for name, p in m.named_parameters():
+        off = (p.data_ptr() - m.flat_params.data_ptr()) // 4
+        assert bool((cover[off:off + p.numel()] == 1).all()), name
+        seen_lang |= ".lang_self_att." in name
+        seen_head |= name.startswith("mlm_head.")
+    assert seen_lang and seen_head
