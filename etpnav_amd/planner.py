@@ -212,6 +212,9 @@ class _PanoFn(torch.autograd.Function):
         eng.set_dropout(ctx.drop)
         check(eng.L.etp_pano_bwd(eng.handle, ptr(dout), ptr(rgb), ptr(dep), ptr(loc), ptr(nav_types), B, V, ptr(d_rgb),
                                  ptr(ctx.stash), ptr(ws), eng.stream()), "etp_pano_bwd")
+        # a PlannerStep sharing this planner may have switched on lazy joins of the weight-gradient stream: autograd
+        # consumers read .grad right after backward, so join here (no-op without an aux stream)
+        check(eng.L.etp_planner_join_aux(eng.handle, eng.stream()), "join_aux")
         return None, None, None, d_rgb, None, None, None, None
 
 
@@ -246,6 +249,9 @@ class _NavFn(torch.autograd.Function):
         check(eng.L.etp_nav_bwd(eng.handle, ptr(d_out), ptr(d_logits), ptr(txt_embeds), ptr(txt_masks),
                                 ptr(step_ids), ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_txt),
                                 ptr(d_img), ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd")
+        # a PlannerStep sharing this planner may have switched on lazy joins of the weight-gradient stream: autograd
+        # consumers read .grad right after backward, so join here (no-op without an aux stream)
+        check(eng.L.etp_planner_join_aux(eng.handle, eng.stream()), "join_aux")
         return None, None, None, d_txt, None, None, d_img, None, None, None, None
 
 
@@ -310,6 +316,9 @@ class _NavCachedFn(torch.autograd.Function):
         check(eng.L.etp_nav_bwd_kv(eng.handle, ptr(d_out), ptr(d_logits), ctx.cache, ptr(txt_masks), ptr(step_ids),
                                    ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_kv), ptr(d_img),
                                    ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd_kv")
+        # a PlannerStep sharing this planner may have switched on lazy joins of the weight-gradient stream: autograd
+        # consumers read .grad right after backward, so join here (no-op without an aux stream)
+        check(eng.L.etp_planner_join_aux(eng.handle, eng.stream()), "join_aux")
         return None, None, None, d_kv, None, None, None, d_img, None, None, None, None
 
 
