@@ -114,3 +114,41 @@ def test_trajectory_aggregation_csr_matches_the_real_pretraining_method():
         for q in range(int(pb[r]), int(pb[r + 1])):
             aty[r] += wb[q] * y[xb[q]]
     assert abs(float((out.view(-1, H) * y).sum()) - float((store * aty).sum())) < 1e-3
+
+
+def test_trajectory_csr_equals_oracle_aggregation_on_random_trajectories():
+    """Property check beyond the golden case: for random trajectories (revisits, repeated candidates, candidate slots
+    beyond the valid views, ragged view counts) the packed CSR applied to the embeddings equals the oracle's loop
+    restatement of _aggregate_gmap_features (itself pinned to the real method)."""
+    from oracle import planner_oracle as po
+    from etpnav_amd.graph_inputs import pack_traj_csr
+    rng = np.random.RandomState(0)
+    for trial in range(25):
+        B, V, H = rng.randint(1, 5), rng.randint(3, 9), 4
+        lens, vpids, cands, gvps, embeds = [], [], [], [], []
+        for i in range(B):
+            T = rng.randint(1, 6)
+            names = [f"n{i}_{k}" for k in range(8)]
+            path = [names[rng.randint(0, 4)] for _ in range(T)]
+            ep_lens = [int(rng.randint(1, V + 1)) for _ in range(T)]
+            mx = max(ep_lens)
+            ep_c = [[names[rng.randint(0, 8)] for _ in range(rng.randint(0, mx + 1))] for _ in range(T)]
+            seen = []
+            for t in range(T):
+                for vp in [path[t]] + ep_c[t]:
+                    if vp not in seen:
+                        seen.append(vp)
+            lens.append(ep_lens); vpids.append(path); cands.append(ep_c); gvps.append([None] + seen)
+            embeds.append(torch.from_numpy(rng.standard_normal((T, V, H)).astype(np.float32)))
+        flat = torch.cat(embeds, 0)
+        traj = {"traj_step_lens": [len(e) for e in embeds], "traj_vp_lens": lens, "traj_vpids": vpids,
+                "traj_cand_vpids": cands, "gmap_vpids": gvps}
+        want = po.aggregate_gmap_features(flat, traj)
+        G = want.shape[1]
+        (pf, xf, wf), _ = pack_traj_csr(lens, vpids, cands, gvps, V, G)
+        store = flat.reshape(-1, H)
+        out = torch.zeros(B * G, H)
+        for n in range(B * G):
+            for q in range(int(pf[n]), int(pf[n + 1])):
+                out[n] += wf[q] * store[xf[q]]
+        assert (out.view(B, G, H) - want).abs().max().item() < 1e-5, trial
