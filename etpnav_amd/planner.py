@@ -14,7 +14,8 @@ matches the fp32 reference to ~1e-5); ``dtype=torch.bfloat16`` = performance mod
 (bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream, LayerNorm,
 softmax statistics, logits and gradients — the MI355X counterpart of the reference's
 fp16 autocast, ss_trainer_ETP.py:502).  Tensors crossing the API are fp32 in both modes.
-Dropout layers of the reference are identity here (eval semantics) — see DESIGN.md.
+Training mode (``model.train()``) turns on every dropout site of the reference (rates from the config, masks from a
+counter-based generator that the backward recomputes); ``model.eval()`` makes them identity — see DESIGN.md §1.
 """
 from __future__ import annotations
 
@@ -102,7 +103,19 @@ class Engine:
         self._shadow_version = -1
         self.epoch = 0                  # bumped by optimizers that update the arena outside torch (FusedAdamW)
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self.param_views = None         # set by the module after a device move: parameters with their own version counters
         self.bind()
+
+    def weights_version(self) -> int:
+        """Changes whenever the fp32 masters change through torch.  Parameters created as views of the arena share its
+        version counter; after ``module.to(device)`` they are re-pointed with ``p.data = ...``, which keeps each
+        parameter's OWN counter, so in-place optimizer updates no longer bump the arena's -- the per-parameter counters
+        are therefore part of the key."""
+        v = self.params._version
+        if self.param_views is not None:
+            for p in self.param_views:
+                v += p._version
+        return v
 
     def bind(self):
         if self.device.type == "cuda":
@@ -128,14 +141,14 @@ class Engine:
         """bf16 mode: re-cast the GEMM weights when the fp32 masters changed (autocast's per-forward cast)."""
         if self.shadow is None:
             return
-        v = self.params._version
+        v = self.weights_version()
         if force or v != self._shadow_version:
             check(self.L.etp_planner_refresh_weights(self.handle, self.stream()), "refresh_weights")
-            self._shadow_version = self.params._version
+            self._shadow_version = v
 
     def mark_shadow_current(self):
         """Called by FusedAdamW: its kernel wrote the bf16 shadow together with the fp32 masters."""
-        self._shadow_version = self.params._version
+        self._shadow_version = self.weights_version()
         self.epoch += 1
 
     def set_dropout(self, drop):
@@ -451,6 +464,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 eng._ws.clear()
                 for p, off, n, shape in self._views:
                     p.data = eng.params[off:off + n].view(shape)
+                eng.param_views = [v[0] for v in self._views]      # `.data =` keeps each parameter's own version counter
                 del old_params
                 self._anchor = torch.zeros(1, device=eng.device, requires_grad=True)
                 self._attach_grads(force=True)
@@ -490,7 +504,7 @@ class GlocalTextPathNavCMT(nn.Module):
         rollout passes the SAME txt_embeds tensor at every step (ss_trainer_ETP.py:801-805 computes it once, :878 reuses
         it), so identity + version of the tensor and of the parameter arena is the cache key; anything else (a sliced or
         re-computed tensor, an optimizer step) misses and re-projects -- results are identical either way."""
-        key = (id(txt_embeds), txt_embeds._version, tuple(txt_embeds.shape), eng.params._version, eng.epoch,
+        key = (id(txt_embeds), txt_embeds._version, tuple(txt_embeds.shape), eng.weights_version(), eng.epoch,
                torch.is_grad_enabled() and txt_embeds.requires_grad)
         hit = self._kv_cache
         if hit is not None and hit[0] == key and hit[1]() is txt_embeds:

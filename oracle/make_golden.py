@@ -38,7 +38,16 @@ CASES = {
     "c5_g64_b2": (dict(kind="r2r"), dict(B=2, L=24, V=36, G=64, ragged=True)),
     # configs[3]: XLM-R vocabulary / eps 1e-5 (short text to keep the fixture cheap)
     "c4_rxr_b1": (dict(kind="rxr"), dict(B=1, L=48, V=14, G=6, ragged=False)),
+    # configs[3] at its BASELINE per-sample shape: XLM-R, 512-token instructions (ragged: lengths 256..512), 36 views, 16 nodes
+    "c4_rxr_l512_b2": (dict(kind="rxr"), dict(B=2, L=512, V=36, G=16, ragged=True)),
+    # configs[4] at its BASELINE per-sample shape: 80 tokens, 36 views, 64 graph nodes
+    "c5_g64_l80_b2": (dict(kind="r2r"), dict(B=2, L=80, V=36, G=64, ragged=False)),
 }
+
+# Big activations of the large cases are stored as (fingerprint, strided samples) like the gradients: the full
+# [2,512,768] text embeddings would be 3 MB per fixture.
+SAMPLED_OUTPUTS = {"c4_rxr_l512_b2": ("txt_embeds",)}
+N_OUT_SAMPLE = 4096
 
 
 def make_cfg(kind="r2r", **kw):
@@ -58,9 +67,18 @@ def fingerprint(t: torch.Tensor):
     return fp, f[torch.from_numpy(idx)].float().numpy()
 
 
-def pack(outs, grads):
+def out_sample_idx(n: int) -> np.ndarray:
+    return np.unique(np.linspace(0, n - 1, N_OUT_SAMPLE).astype(np.int64))
+
+
+def pack(outs, grads, sampled=()):
     d = {}
     for k in ("txt_embeds", "pano_embeds", "gmap_embeds", "global_logits", "loss", "gmap_img_fts"):
+        if k in sampled:
+            f = outs[k].float().reshape(-1)
+            d[f"osm.{k}"] = f[torch.from_numpy(out_sample_idx(f.numel()))].numpy()
+            d[f"ofp.{k}"] = np.array([float(f.double().sum()), float(f.abs().max()), float(f.double().norm())])
+            continue
         d[f"out.{k}"] = outs[k].float().numpy()
     d["out.pano_masks"] = outs["pano_masks"].numpy()
     for k, g in grads.items():
@@ -83,7 +101,7 @@ def main():
         model = rh.build_reference_model(cfg, P)
         batch = po.make_batch(cfg, seed=1234, **bkw)
         outs, grads = rh.reference_step(model, batch)
-        d = pack(outs, grads)
+        d = pack(outs, grads, SAMPLED_OUTPUTS.get(name, ()))
         d["meta.cfg"] = np.array(repr(ckw))
         d["meta.batch"] = np.array(repr(bkw))
         path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")

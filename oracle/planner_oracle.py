@@ -673,6 +673,45 @@ def sap_step_with_grads(P, cfg: PlannerConfig, batch, drop=None):
     return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in outs.items()}, grads
 
 
+def make_rollout(cfg: PlannerConfig, B: int, L: int, G: int, T: int, seed: int = 40):
+    """Seeded inputs of a T-step rollout on ONE instruction batch: (txt_ids, txt_masks, [per-step navigation inputs]).
+    Node features are random stand-ins for the GraphMap's accumulated panorama embeddings."""
+    base = make_batch(cfg, B=B, L=L, V=8, G=G, seed=seed, ragged=True)
+    steps = []
+    for t in range(T):
+        bt = make_batch(cfg, B=B, L=L, V=8, G=G, seed=seed + 1 + t, ragged=True)
+        gen = torch.Generator().manual_seed(seed + 60 + t)
+        st = {k: bt[k] for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks", "gmap_pair_dists", "labels")}
+        st["gmap_img_fts"] = torch.randn(B, G, cfg.hidden_size, generator=gen) * 0.5
+        steps.append(st)
+    return base["txt_ids"], base["txt_masks"], steps
+
+
+def rollout_step(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor, steps, drops=None):
+    """ss_trainer_ETP.py:801-805 (one forward_txt per episode batch), :878-892 (forward_navigation + CE(sum) at every
+    step on the SAME txt_embeds), :1055 (the step losses are summed before the single backward).  `drops`: optional
+    list [text DropSpec, one DropSpec per step] (train mode)."""
+    txt = forward_txt(P, cfg, txt_ids, txt_masks, drops[0] if drops else None)
+    B = txt_ids.shape[0]
+    loss, outs = 0.0, []
+    for t, st in enumerate(steps):
+        o = forward_navigation(P, cfg, txt, txt_masks, st["gmap_step_ids"], st["gmap_img_fts"], st["gmap_pos_fts"],
+                               st["gmap_masks"], st["gmap_visited_masks"], st["gmap_pair_dists"],
+                               drops[1 + t] if drops else None)
+        loss = loss + cross_entropy_sum(o["global_logits"], st["labels"]) / B
+        outs.append(o)
+    return {"txt_embeds": txt, "loss": loss, "steps": outs}
+
+
+def rollout_with_grads(P, cfg: PlannerConfig, txt_ids, txt_masks, steps, drops=None):
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    outs = rollout_step(Pg, cfg, txt_ids, txt_masks, steps, drops)
+    outs["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    return ({"txt_embeds": outs["txt_embeds"].detach(), "loss": outs["loss"].detach(),
+             "steps": [{k: v.detach() for k, v in o.items()} for o in outs["steps"]]}, grads)
+
+
 def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4, drop=None):
     """Run planner_step with autograd; returns (outputs, {name: grad})."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}

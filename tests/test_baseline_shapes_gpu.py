@@ -1,0 +1,254 @@
+"""Whole-step parity at the BASELINE.json per-sample shapes that round 1 left untested, plus the two drop-in
+surfaces that had no oracle check:
+
+  * configs[3]  RxR: XLM-R vocabulary, L = 512 instruction tokens, V = 36, G = 16           (c4_rxr_l512_b2)
+  * configs[4]  64 graph nodes with L = 80, V = 36                                          (c5_g64_l80_b2)
+  * configs[1]  the benchmarked shape itself, B = 32, bf16, train mode (dropout on), vs the oracle with the same masks
+  * a T-step rollout (one forward_txt, T forward_navigation on the same txt_embeds, summed loss, one backward) with the
+    text-K/V cache ON and OFF, each against the REAL reference's outputs (tests/golden/rollout_t3.npz)
+  * get_vlnbert_models(cfg) -> ETP.forward(mode='language' | 'panorama' | 'navigation') in train mode with drop_env,
+    as ss_trainer_ETP.py:801-892 calls it (Policy_ViewSelection_ETP.py:157-170,344-358)
+
+All through the C ABI of libetpnav_hip.so.  Tolerances as tests/test_planner_gpu.py: fp32 2e-4 abs (+2e-3 relative on
+gradients; BASELINE.json asks 1e-3), bf16 5e-2 outputs / 8e-2 + 10 % of abs-max on gradients.
+"""
+import os
+import tempfile
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import planner_oracle as po  # noqa: E402  (checker only)
+from tests.golden_util import load_case, compare_outputs, compare_grads, load_rollout, compare_rollout  # noqa: E402
+from etpnav_amd.planner import GlocalTextPathNavCMT  # noqa: E402
+from etpnav_amd.step import PlannerStep  # noqa: E402
+
+
+def build_model(cfg, P, dtype):
+    m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=dtype, device="cuda")
+    m.load_state_dict({k: v for k, v in P.items()}, strict=True)
+    return m.eval()
+
+
+def grads_of(model):
+    return {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+
+
+def step_outputs(step):
+    torch.cuda.synchronize()
+    return {"txt_embeds": step.txt, "pano_embeds": step.pano, "gmap_embeds": step.gemb, "global_logits": step.logits,
+            "loss": step.loss.reshape(())}
+
+
+@pytest.mark.parametrize("name", ["c4_rxr_l512_b2", "c5_g64_l80_b2"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_baseline_shape_step_matches_reference_golden(name, dtype):
+    z, cfg, batch = load_case(name)
+    P = po.init_params(cfg, seed=0)
+    model = build_model(cfg, P, dtype)
+    step = PlannerStep(model, batch)
+    step.run_eager()
+    if dtype == torch.float32:
+        worst = compare_outputs(z, step_outputs(step), atol=2e-4)
+        g = compare_grads(z, grads_of(model), atol=2e-4, rel=2e-3, rel_sample=2e-3)
+    else:
+        worst = compare_outputs(z, step_outputs(step), atol=5e-2)
+        g = compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
+    print(name, dtype, "worst output err", worst, "worst grad err", g)
+    step.close()
+
+
+def test_benchmarked_shape_b32_bf16_train_mode_close_to_oracle():
+    """The exact workload of bench.py's default line (B=32, L=80, V=36x768, G=16, bf16, dropout on): loss, logits, embeddings
+    and every parameter gradient against the oracle applying the same dropout masks."""
+    w = dict(B=32, L=80, V=36, G=16, image_feat_size=768)        # bench.py WORKLOADS["c2"] = BASELINE.json configs[1]
+    cfg = po.PlannerConfig.r2r(image_feat_size=w["image_feat_size"])
+    P = po.init_params(cfg, seed=0)
+    batch = po.make_batch(cfg, B=w["B"], L=w["L"], V=w["V"], G=w["G"], seed=1234, ragged=False)
+    rates = (0.1, 0.1, 0.1, 0.4)
+    outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*rates, seed=(3 << 32) | 1))
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch, dropout=rates, drop_seed=3)
+    step.run_eager()
+    got = step_outputs(step)
+    for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
+        assert (got[k].float().cpu() - outs[k]).abs().max().item() < 8e-2, k
+    fin = torch.isfinite(outs["global_logits"])
+    assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
+    assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
+    assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
+    mine = grads_of(model)
+    for k, g in grads.items():
+        if k.startswith("__input__"):
+            continue
+        err = (mine[k] - g).abs().max().item()
+        assert err < 8e-2 + 0.1 * g.abs().max().item(), f"{k}: {err}"
+    step.close()
+
+
+# ---- rollout: text K/V cache on/off vs the real reference ---------------------------------------------------------------
+def _hip_rollout(model, ids, masks, steps):
+    model.zero_grad()
+    txt = model.forward_txt(ids, masks)
+    outs, loss = [], 0.0
+    for st in steps:
+        o = model.forward_navigation(txt, masks, None, st["gmap_step_ids"], st["gmap_img_fts"], st["gmap_pos_fts"],
+                                     st["gmap_masks"], st["gmap_visited_masks"], st["gmap_pair_dists"])
+        outs.append(o)
+        loss = loss + F.cross_entropy(o["global_logits"], st["labels"], reduction="sum", ignore_index=-100) / ids.shape[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    return {"txt_embeds": txt.detach(), "loss": loss.detach(),
+            "steps": [{k: v.detach() for k, v in o.items()} for o in outs]}
+
+
+@pytest.mark.parametrize("cached", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rollout_matches_reference_golden_with_and_without_text_kv_cache(cached, dtype):
+    z, cfg, P, ids, masks, steps = load_rollout()
+    model = build_model(cfg, P, dtype)
+    model.cache_text_kv = cached
+    dsteps = [{k: v.cuda() for k, v in st.items()} for st in steps]
+    outs = _hip_rollout(model, ids.cuda(), masks.cuda(), dsteps)
+    if cached:
+        assert model._kv_cache is not None      # one projection served all T steps
+    if dtype == torch.float32:
+        compare_rollout(z, outs, atol=2e-4)
+        compare_grads(z, grads_of(model), atol=2e-4, rel=2e-3, rel_sample=2e-3)
+    else:
+        compare_rollout(z, outs, atol=5e-2)
+        compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
+
+
+def test_rollout_train_mode_matches_oracle_with_same_masks():
+    """Train-mode rollout through the module API (every entry-point call draws its own mask stream): cached and uncached
+    runs must both match the oracle given the same per-call seeds."""
+    z, cfg, P, ids, masks, steps = load_rollout()
+    dsteps = [{k: v.cuda() for k, v in st.items()} for st in steps]
+    r = (0.1, 0.1, 0.1, 0.0)
+    drops = [po.DropSpec(*r, seed=(77 << 32) | (1 + i)) for i in range(1 + len(steps))]
+    ref, rgrads = po.rollout_with_grads(P, cfg, ids, masks, steps, drops)
+    for cached in (False, True):
+        model = build_model(cfg, P, torch.float32).train()
+        model.cache_text_kv = cached
+        model.seed_dropout(77)
+        outs = _hip_rollout(model, ids.cuda(), masks.cuda(), dsteps)
+        assert abs(outs["loss"].item() - ref["loss"].item()) < 2e-4, cached
+        for a, b in zip(outs["steps"], ref["steps"]):
+            fin = torch.isfinite(b["global_logits"])
+            assert (a["global_logits"].cpu()[fin] - b["global_logits"][fin]).abs().max().item() < 2e-4
+        mine = grads_of(model)
+        for k, g in rgrads.items():
+            err = (mine[k] - g).abs().max().item()
+            assert err < 2e-4 + 2e-3 * g.abs().max().item(), f"cached={cached} {k}: {err}"
+
+
+# ---- the policy-level dispatch (a16) -------------------------------------------------------------------------------------
+def _policy_step(net, b, G):
+    """The three calls of RLTrainer.rollout (ss_trainer_ETP.py:801-805, :837, :878) + the loss of :892."""
+    txt = net(mode="language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+    pano, pmask = net(mode="panorama", rgb_fts=b["rgb_fts"], dep_fts=b["dep_fts"], loc_fts=b["loc_fts"],
+                      nav_types=b["nav_types"], view_lens=b["view_lens"])
+    m = pmask.to(pano.dtype)
+    avg = (pano * m[..., None]).sum(1) / m.sum(1, keepdim=True)
+    idx = torch.arange(G - 2, device=pano.device)[None, :] % b["view_lens"][:, None]
+    views = torch.gather(pano, 1, idx[..., None].expand(-1, -1, pano.shape[-1]))
+    gimg = torch.cat([torch.zeros_like(avg[:, None]), avg[:, None], views], 1)
+    outs = net(mode="navigation", txt_embeds=txt, txt_masks=b["txt_masks"], gmap_vp_ids=None, gmap_step_ids=b["gmap_step_ids"],
+               gmap_img_fts=gimg, gmap_pos_fts=b["gmap_pos_fts"], gmap_masks=b["gmap_masks"],
+               gmap_visited_masks=b["gmap_visited_masks"], gmap_pair_dists=b["gmap_pair_dists"])
+    loss = F.cross_entropy(outs["global_logits"], b["labels"], reduction="sum", ignore_index=-100) / b["txt_ids"].shape[0]
+    return txt, pano, outs, loss
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_etp_forward_modes_train_with_drop_env_match_oracle(fused):
+    """get_vlnbert_models(config) with a pre-training checkpoint on disk ('bert.'-prefixed keys, vlnbert_init.py:20-30)
+    -> PolicyViewSelectionETP.from_config -> net(mode=...) in train mode.  With fuse_drop_env the p=0.4 feature dropout
+    (Policy_ViewSelection_ETP.py:102,345) is applied inside forward_panorama by the documented generator, so the oracle
+    reproduces it (p_env=0.4); unfused it is torch's nn.Dropout on rgb_fts and the oracle gets the SAME dropped features."""
+    from etpnav_amd.policy import PolicyViewSelectionETP
+    from etpnav_amd import checkpoint as ck
+    cfg = po.PlannerConfig.r2r()
+    P = po.init_params(cfg, seed=21)
+    batch = po.make_batch(cfg, B=3, L=18, V=13, G=8, seed=8, ragged=True)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "model_step_1.pt")
+        torch.save({("bert." + k if not k.startswith("global_sap_head.") else k): v for k, v in P.items()}, path)
+        mc = SimpleNamespace(pretrained_path=path, task_type="r2r", use_depth_embedding=True, use_sprels=True,
+                             fix_lang_embedding=False, fix_pano_embedding=False)
+        policy = PolicyViewSelectionETP.from_config(SimpleNamespace(MODEL=mc), dtype=torch.float32, device="cuda")
+    net = policy.net
+    net.fuse_drop_env = fused
+    for k, v in net.vln_bert.state_dict().items():
+        assert torch.equal(v.cpu(), P[k]), k          # checkpoint key remapping loaded every planner weight
+    net.train()
+    net.vln_bert.seed_dropout(5)
+    b = {k: v.cuda() for k, v in batch.items()}
+    G = b["gmap_step_ids"].shape[1]
+    net.vln_bert.zero_grad()
+    torch.manual_seed(123)
+    txt, pano, outs, loss = _policy_step(net, b, G)
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle with the same per-call seeds (call counters 1, 2, 3)
+    r = (0.1, 0.1, 0.1)
+    ob = dict(batch)
+    p_env = 0.4
+    if not fused:
+        torch.manual_seed(123)
+        ob["rgb_fts"] = F.dropout(b["rgb_fts"], 0.4, True).cpu()     # the same torch mask the unfused path drew on the device
+        p_env = 0.0
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    o_txt = po.forward_txt(Pg, cfg, ob["txt_ids"], ob["txt_masks"], po.DropSpec(*r, 0.0, seed=(5 << 32) | 1))
+    o_pano, o_mask = po.forward_panorama(Pg, cfg, ob["rgb_fts"], ob["dep_fts"], ob["loc_fts"], ob["nav_types"], ob["view_lens"],
+                                         po.DropSpec(*r, p_env, seed=(5 << 32) | 2))
+    o_gimg = po.assemble_gmap_img_fts(o_pano, o_mask, ob["view_lens"], G)
+    o = po.forward_navigation(Pg, cfg, o_txt, ob["txt_masks"], ob["gmap_step_ids"], o_gimg, ob["gmap_pos_fts"], ob["gmap_masks"],
+                              ob["gmap_visited_masks"], ob["gmap_pair_dists"], po.DropSpec(*r, 0.0, seed=(5 << 32) | 3))
+    o_loss = po.cross_entropy_sum(o["global_logits"], ob["labels"]) / ob["txt_ids"].shape[0]
+    o_loss.backward()
+    assert abs(loss.item() - o_loss.item()) < 2e-4
+    assert (txt.detach().cpu() - o_txt.detach()).abs().max().item() < 2e-4
+    fin = torch.isfinite(o["global_logits"])
+    assert (outs["global_logits"].detach().cpu()[fin] - o["global_logits"].detach()[fin]).abs().max().item() < 2e-4
+    mine = grads_of(net.vln_bert)
+    for k, v in Pg.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        err = (mine[k] - g).abs().max().item()
+        assert err < 2e-4 + 2e-3 * g.abs().max().item(), f"{k}: {err}"
+    # eval(): every dropout (drop_env included) is identity
+    net.eval()
+    with torch.no_grad():
+        e_txt, e_pano, e_outs, e_loss = _policy_step(net, b, G)
+    ref, _ = po.step_with_grads(P, cfg, batch)
+    assert abs(e_loss.item() - ref["loss"].item()) < 2e-4
+    with pytest.raises(NotImplementedError):
+        net(mode="waypoint")
+
+
+def test_bf16_weight_shadow_follows_torch_optimizer_after_device_move():
+    """a planner built on the CPU and moved with .cuda() keeps per-parameter version counters (`p.data = ...`),
+    so an in-place torch.optim step no longer bumps the arena's counter; the bf16 GEMM-weight shadow must still be re-cast
+    before the next forward."""
+    cfg = po.PlannerConfig.r2r(vocab_size=2048, num_l_layers=2, num_pano_layers=1, num_x_layers=1)
+    P = po.init_params(cfg, seed=1)
+    batch = po.make_batch(cfg, B=2, L=9, V=8, G=5, seed=2)
+    m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.bfloat16, device="cpu")
+    m.load_state_dict(P, strict=True)
+    m = m.cuda().eval()
+    ids, masks = batch["txt_ids"].cuda(), batch["txt_masks"].cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+    out0 = m.forward_txt(ids, masks)
+    out0.square().mean().backward()
+    opt.step()
+    torch.cuda.synchronize()
+    out1 = m.forward_txt(ids, masks).detach().clone()         # must see the updated weights
+    m._engine.refresh_weights(force=True)
+    out2 = m.forward_txt(ids, masks).detach()
+    assert (out1 - out0.detach()).abs().max().item() > 1e-3       # the step changed the output ...
+    assert torch.equal(out1, out2)                                # ... and no forced refresh was needed to see it

@@ -5,7 +5,7 @@ import pytest
 from oracle import planner_oracle as po
 from tests.golden_util import load_case, compare_outputs, compare_grads
 
-CASES = ["c1_single_episode", "ragged_small", "c2_shape_b2", "c5_g64_b2", "c4_rxr_b1"]
+CASES = ["c1_single_episode", "ragged_small", "c2_shape_b2", "c5_g64_b2", "c4_rxr_b1", "c5_g64_l80_b2", "c4_rxr_l512_b2"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -31,3 +31,13 @@ def test_oracle_trajectory_aggregation_matches_the_real_pretraining_method():
             "traj_cand_vpids": cands, "gmap_vpids": gvps}
     got = po.aggregate_gmap_features(torch.cat(embeds, 0), traj)
     assert got.shape == want.shape and np.abs(got.numpy() - want).max() < 1e-6
+
+
+def test_oracle_rollout_matches_reference_golden():
+    """T-step rollout (one forward_txt, T forward_navigation on the same txt_embeds, summed loss, one backward) against
+    the REAL reference's outputs (tests/golden/rollout_t3.npz, generator oracle/make_golden_rollout.py)."""
+    from tests.golden_util import load_rollout, compare_rollout
+    z, cfg, P, ids, masks, steps = load_rollout()
+    outs, grads = po.rollout_with_grads(P, cfg, ids, masks, steps)
+    compare_rollout(z, outs, atol=2e-5)
+    compare_grads(z, grads, atol=2e-5, rel=1e-4)
