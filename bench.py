@@ -105,14 +105,15 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph (one side stream) instead of eager three-stream issue; measured "
-                         "slower on MI355X: the step is not launch-bound (DESIGN.md)")
+                    help="force hipGraph replay of the three-stream step (explicitly recorded graph, PlannerStep.record)")
+    ap.add_argument("--eager", action="store_true", help="force eager three-stream issue (no graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-AdamW leg")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train (default): dropout active at every site, as under the reference's policy.train() "
                          "(ss_trainer_ETP.py:483); eval: dropout off (the parity-fixture configuration)")
-    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--comm-dtype", default="fp32", choices=["bf16", "fp32"],
+                    help="gradient transport: fp32 (default, DDP's numerics) or bf16 (half the xGMI bytes, bf16 sums)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
     ap.add_argument("--same-device", action="store_true",
@@ -150,8 +151,8 @@ def main():
     else:
         batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
                            seed=1234 + rank)                      # each rank owns its episodes
-    use_graph = args.graph
-    step = PlannerStep(model, batch, overlap="s2" if use_graph else True,
+    use_graph = args.graph and not args.eager
+    step = PlannerStep(model, batch, overlap=True,
                        dropout="config" if args.mode == "train" else None, drop_seed=rank)
     reducer = None
     if world > 1:
@@ -160,7 +161,13 @@ def main():
                                  comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
                                  sparse_rows=sparse)
     if use_graph:
-        step.capture(split_text_bwd=world > 1)
+        try:
+            step.record(split_text_bwd=world > 1)
+        except _lib.EtpError as e:                               # keep the bench alive if the runtime refuses the graph
+            if args.graph:
+                raise
+            print(f"[bench] graph recording failed ({e}); falling back to eager issue", file=sys.stderr)
+            use_graph = False
 
     def one_step():
         if world == 1:

@@ -464,7 +464,7 @@ template <typename T, int BQ, int BKV> static int launch_fwd(const AttnKArgs& k,
     ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, st, k);
+  ETP_LAUNCH(kern, dim3(blocks), dim3(256), smem, st, k);
   ETP_CHECK_LAUNCH("attn_fwd");
   return ETP_OK;
 }
@@ -476,7 +476,7 @@ template <typename T, int BQ, int BKV> static int launch_bwd(const AttnKArgs& k,
     ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, st, k);
+  ETP_LAUNCH(kern, dim3(blocks), dim3(256), smem, st, k);
   ETP_CHECK_LAUNCH("attn_bwd");
   return ETP_OK;
 }

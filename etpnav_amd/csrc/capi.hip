@@ -28,11 +28,10 @@ extern "C" {
 const char* etp_version(void) { return "etpnav_hip 0.1.0 (gfx950)"; }
 const char* etp_last_error(void) { return g_last_error.c_str(); }
 
-int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream) {
+static int desc_to_args(const etp_gemm_desc* d, GemmArgs& g) {
   ETP_REQUIRE(d && d->A && d->B && d->C, "null descriptor/operand");
   ETP_REQUIRE(d->act >= ETP_ACT_NONE && d->act <= ETP_ACT_RELU_BWD, "bad activation");
   ETP_REQUIRE((d->act != ETP_ACT_GELU && d->act != ETP_ACT_GELU_BWD && d->act != ETP_ACT_RELU_BWD) || d->Z, "activation needs Z");
-  GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = d->A; g.B = d->B; g.C = d->C; g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
@@ -41,7 +40,23 @@ int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream) {
   g.ksplit = d->ksplit > 0 ? d->ksplit : 1;
   g.alpha = d->alpha; g.bias = d->bias; g.R = d->R; g.ldr = d->ldr; g.Z = d->Z; g.ldz = d->ldz; g.act = d->act;
   g.out_mode = d->out_mode;
+  return ETP_OK;
+}
+int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream) {
+  GemmArgs g;
+  ETP_TRY(desc_to_args(d, g));
   return launch_gemm(d->dtype, d->c_dtype, d->trans_a, d->trans_b, g, d->batch > 0 ? d->batch : 1, (hipStream_t)stream);
+}
+int etp_gemm_group(const etp_gemm_desc* d, int n, etp_stream_t stream) {
+  ETP_REQUIRE(d && n >= 1 && n <= ETP_GEMM_GROUP_MAX, "1..8 descriptors");
+  GemmArgs gs[ETP_GEMM_GROUP_MAX];
+  for (int i = 0; i < n; ++i) {
+    ETP_TRY(desc_to_args(d + i, gs[i]));
+    ETP_REQUIRE(d[i].dtype == d[0].dtype && d[i].c_dtype == d[0].c_dtype && d[i].trans_a == d[0].trans_a &&
+                    d[i].trans_b == d[0].trans_b && d[i].batch <= 1 && d[i].ksplit <= 1,
+                "grouped products share dtype / storage class and are unbatched, unsplit");
+  }
+  return launch_gemm_group(d[0].dtype, d[0].c_dtype, d[0].trans_a, d[0].trans_b, gs, n, (hipStream_t)stream);
 }
 
 int etp_colsum(int dtype, const void* dy, int64_t ld, float* db, int M, int N, etp_stream_t s) {
@@ -67,6 +82,15 @@ int etp_ln_stream_bwd(int dtype, const float* dy, const float* x, const float* s
                       float* dx, void* dx_lp, float* dgamma, float* dbeta, int M, int H, etp_stream_t s) {
   ETP_REQUIRE(dy && x && stats && gamma && (dx || dx_lp) && ((dgamma == nullptr) == (dbeta == nullptr)), "null pointer");
   return ln_bwd_s(dtype, dy, x, stats, gamma, add, dx, dx_lp, dgamma, dbeta, M, H, (hipStream_t)s);
+}
+int64_t etp_ln_bwd_part_bytes(int M, int H) { return (M > 0 && H > 0) ? (int64_t)ln_bwd_part_bytes(M, H) : 0; }
+int etp_ln_stream_bwd_stage1(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
+                             float* dx, void* dx_lp, float* dgamma, float* dbeta, float* part, int M, int H, etp_stream_t s) {
+  ETP_REQUIRE(dy && x && stats && gamma && (dx || dx_lp) && dgamma && dbeta && part, "null pointer");
+  return ln_bwd_s(dtype, dy, x, stats, gamma, add, dx, dx_lp, dgamma, dbeta, M, H, (hipStream_t)s, drop_none(), part);
+}
+int etp_ln_part_reduce(const float* part, int M, int H, float* dgamma, float* dbeta, etp_stream_t s) {
+  return ln_part_reduce(part, M, H, dgamma, dbeta, (hipStream_t)s);
 }
 int etp_softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
                     int heads, int Lq, int Lk, int ldS, int mask_mode, etp_stream_t s) {
@@ -161,6 +185,13 @@ int etp_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
   return adamw_step(params, grads, exp_avg, exp_avg_sq, shadow, (long)n_shadow, decay_mask, (long)n, *cfg, sumsq, skip,
                     zero_grads, (hipStream_t)s);
 }
+int etp_adamw_step_counted(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow, int64_t n_shadow,
+                           const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
+                           int zero_grads, int32_t* step_counter, etp_stream_t s) {
+  ETP_REQUIRE(cfg && step_counter, "null config / step counter");
+  return adamw_step(params, grads, exp_avg, exp_avg_sq, shadow, (long)n_shadow, decay_mask, (long)n, *cfg, sumsq, skip,
+                    zero_grads, (hipStream_t)s, step_counter);
+}
 int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t s) {
   return grad_sqnorm(grads, (long)n, sumsq, nonfinite, (hipStream_t)s);
 }
@@ -203,8 +234,8 @@ int etp_stream_after(etp_stream_t from, etp_stream_t to) {
   }
   hipEvent_t e = pool[next];
   next = (next + 1) % pool.size();
-  ETP_CHECK_HIP(hipEventRecord(e, (hipStream_t)from));
-  ETP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)to, e, 0));
+  ETP_CHECK_HIP(event_record(e, (hipStream_t)from));
+  ETP_CHECK_HIP(stream_wait_event((hipStream_t)to, e));
   return ETP_OK;
 }
 int etp_graph_begin(etp_stream_t s) {
@@ -220,6 +251,23 @@ int etp_graph_end(etp_stream_t s, etp_graph** out) {
   *out = new etp_graph{g, e};
   return ETP_OK;
 }
+// Explicitly built graph (launch.h / graphrec.hip): between etp_rec_begin and etp_rec_end every call of this library that
+// takes a stream is RECORDED as graph nodes instead of being issued; stream handles only name the logical streams
+// (dependencies follow the same per-stream order + event edges the eager issue would have had).
+int etp_rec_begin(void) { return rec_begin(); }
+int etp_rec_end(etp_graph** out, int64_t* n_kernels, int64_t* n_edges) {
+  ETP_REQUIRE(out, "null pointer");
+  hipGraph_t g = nullptr;
+  hipGraphExec_t e = nullptr;
+  long nk = 0, ne = 0;
+  const int rc = rec_end(&g, &e, &nk, &ne);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (n_kernels) *n_kernels = nk;
+  if (n_edges) *n_edges = ne;
+  *out = new etp_graph{g, e};
+  return ETP_OK;
+}
+int etp_rec_abort(void) { rec_abort(); return ETP_OK; }
 int etp_graph_launch(etp_graph* g, etp_stream_t s) {
   ETP_REQUIRE(g, "null graph");
   ETP_CHECK_HIP(hipGraphLaunch(g->exec, (hipStream_t)s));
@@ -236,7 +284,7 @@ int etp_memset_async(void* p, int value, int64_t bytes, etp_stream_t s) {
   ETP_REQUIRE(p && bytes >= 0, "bad arguments");
   if (value == 0 && bytes % 4 == 0 && (uintptr_t)p % 16 == 0)      // zeroing (loss, gradient arena): our own kernel, no runtime blit
     return zero_f32(reinterpret_cast<float*>(p), bytes / 4, (hipStream_t)s);
-  ETP_CHECK_HIP(hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)s));
+  ETP_CHECK_HIP(memset_async(p, value, (size_t)bytes, (hipStream_t)s));
   return ETP_OK;
 }
 int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out) {
@@ -254,6 +302,9 @@ int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out) {
   return ETP_OK;
 }
 
+int etp_ktime_enable(int on) { ktime_enable(on != 0); return ETP_OK; }
+int etp_ktime_reset(void) { ktime_reset(); return ETP_OK; }
+int64_t etp_ktime_report(char* buf, int64_t cap) { return (buf && cap > 0) ? ktime_report(buf, (long)cap) : 0; }
 int etp_prof_enable(int on) { prof_enable(on != 0); return ETP_OK; }
 int etp_prof_reset(void) { prof_reset(); return ETP_OK; }
 int etp_prof_report(etp_prof_entry* out, int cap) {

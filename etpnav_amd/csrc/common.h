@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../include/etpnav_hip.h"
+#include "launch.h"
 
 namespace etp {
 
@@ -102,7 +103,7 @@ int check_hip(hipError_t e, const char* what);
     int _rc = ::etp::check_hip((expr), #expr);                \
     if (_rc) return _rc;                                      \
   } while (0)
-#define ETP_CHECK_LAUNCH(name) ETP_CHECK_HIP(hipGetLastError())
+#define ETP_CHECK_LAUNCH(name) ETP_CHECK_HIP(::etp::launch_status())
 #define ETP_REQUIRE(cond, msg)                                \
   do {                                                        \
     if (!(cond)) return ::etp::fail(ETP_ERR_INVALID, std::string(__func__) + ": " + (msg)); \
@@ -137,7 +138,19 @@ struct GemmArgs {
                                       // element index = row * N + col
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
+// Several independent, unbatched, unsplit products of ONE (dtype, c_dtype, transA, transB) class in a single grid (LDS-DMA
+// kernel only: every reduction length must pass gemm_uses_dma).  n <= ETP_GEMM_GROUP_MAX.
+constexpr int ETP_GEMM_GROUP_MAX = 8;
+struct GemmGroup { int n; int tile_start[ETP_GEMM_GROUP_MAX + 1]; GemmArgs g[ETP_GEMM_GROUP_MAX]; };
+int launch_gemm_group(int dtype, int c_dtype, int transA, int transB, const GemmArgs* gs, int n, hipStream_t st);
 bool gemm_uses_dma(int dtype, int K, int ksplit);   // true when launch_gemm will take the LDS-DMA kernel for this reduction
+// graphrec.hip: explicit hipGraph recording of everything issued through launch.h
+int rec_begin();
+int rec_end(hipGraph_t* graph, hipGraphExec_t* exec, long* n_kernels, long* n_edges);
+void rec_abort();
+void ktime_enable(bool on);
+void ktime_reset();
+long ktime_report(char* buf, long cap);
 void prof_enable(bool on);
 void prof_reset();
 int prof_report(etp_prof_entry* out, int cap);

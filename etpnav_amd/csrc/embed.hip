@@ -545,13 +545,17 @@ __global__ __launch_bounds__(256) void sap_tail_bwd_kernel(const float* __restri
 
 // --------------------------------------------------------------------------------------
 // Cross entropy (sum, ignore_index) + its gradient        F.cross_entropy ss_trainer_ETP.py:892
-//   loss += scale * sum_b [lse(logits_b) - logits_b[y_b]],  dlogits = scale * (softmax - onehot)
+//   loss = scale * sum_b [lse(logits_b) - logits_b[y_b]],  dlogits = scale * (softmax - onehot)
+// One workgroup (B is the episode batch: tens of rows): the loss is reduced in LDS and STORED, so the caller needs no
+// zeroing launch in front of it.
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sap_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                     float* __restrict__ loss, float* __restrict__ dlogits, int B, int G,
-                                                     float scale, long ignore_index) {
-  const int lane = threadIdx.x & 63;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += gridDim.x * 4) {
+__global__ __launch_bounds__(1024) void sap_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ loss, float* __restrict__ dlogits, int B, int G,
+                                                      float scale, long ignore_index) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves: two rows each at B = 32
+  float acc = 0.f;
+  for (int row = wave; row < B; row += 16) {
     const float* s = logits + (long)row * G;
     const long y = labels[row];
     const bool keep = (y != ignore_index);
@@ -568,7 +572,15 @@ __global__ __launch_bounds__(256) void sap_ce_kernel(const float* __restrict__ l
         if (keep) gk = scale * (expf(s[k] - lse) - (k == y ? 1.f : 0.f));
         dlogits[(long)row * G + k] = gk;
       }
-    if (lane == 0 && keep) atomicAdd(loss, scale * (lse - s[y]));
+    if (keep) acc += scale * (lse - s[y]);
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *loss = t;
   }
 }
 
@@ -740,8 +752,8 @@ int text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float
                    const float* beta, float* y, void* yt, float* stats, int B, int L, int H, float eps, hipStream_t st, Drop drop) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   const int M = B * L, grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (bf16_t*)yt, stats, M, L, eps, drop)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (float*)yt, stats, M, L, eps, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((text_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (bf16_t*)yt, stats, M, L, eps, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((text_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, gamma, beta, y, (float*)yt, stats, M, L, eps, drop)); }
   ETP_CHECK_LAUNCH("text_embed_fwd");
   return ETP_OK;
 }
@@ -752,7 +764,7 @@ int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* 
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   (void)dtype;
   const int M = B * L, grid = row_grid(M, 128);
-  ETP_DISPATCH_H(H, hipLaunchKernelGGL((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
+  ETP_DISPATCH_H(H, ETP_LAUNCH((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
   ETP_CHECK_LAUNCH("text_embed_bwd");
   return ETP_OK;
 }
@@ -761,8 +773,8 @@ int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, co
                    float* y, float* stats, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, y, stats, M, drop)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, y, stats, M, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)d, loc, nav, p, y, stats, M, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)d, loc, nav, p, y, stats, M, drop)); }
   ETP_CHECK_LAUNCH("pano_embed_fwd");
   return ETP_OK;
 }
@@ -773,8 +785,8 @@ int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, con
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M, drop)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M, drop)); }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }
@@ -784,8 +796,8 @@ int gmap_embed_fwd(int dtype, const float* img, const int64_t* step_ids, const f
                    int M, int H, int PK, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && PK == 7, "bad dims (pos feature width must be 7)");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (bf16_t*)xt, stats, M)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_fwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (float*)xt, stats, M)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((gmap_embed_fwd_kernel<bf16_t, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (bf16_t*)xt, stats, M)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((gmap_embed_fwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), 0, st, img, step_ids, pos, step_emb, w_pos, b_pos, gamma, beta, x, (float*)xt, stats, M)); }
   ETP_CHECK_LAUNCH("gmap_embed_fwd");
   return ETP_OK;
 }
@@ -797,7 +809,7 @@ int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const fl
   (void)dtype;
   const int grid = row_grid(M, 64);
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  ETP_DISPATCH_H(H, hipLaunchKernelGGL((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M));
+  ETP_DISPATCH_H(H, ETP_LAUNCH((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M));
   ETP_CHECK_LAUNCH("gmap_embed_bwd");
   return ETP_OK;
 }
@@ -806,8 +818,8 @@ int sap_tail_fwd(int dtype, const void* r, const float* gamma, const float* beta
                  const uint8_t* visited, const uint8_t* valid, float* logits, float* stats, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_fwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_fwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)r, gamma, beta, w2, b2, visited, valid, logits, stats, M, drop)); }
   ETP_CHECK_LAUNCH("sap_tail_fwd");
   return ETP_OK;
 }
@@ -817,8 +829,8 @@ int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* ga
                  float* dw2, float* db2, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 64);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
   ETP_CHECK_LAUNCH("sap_tail_bwd");
   return ETP_OK;
 }
@@ -826,7 +838,7 @@ int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* ga
 int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale, long ignore_index,
            hipStream_t st) {
   ETP_REQUIRE(B > 0 && G > 0, "bad dims");
-  hipLaunchKernelGGL(sap_ce_kernel, dim3(row_grid(B, 1024)), dim3(256), 0, st, logits, labels, loss, dlogits, B, G, scale, ignore_index);
+  ETP_LAUNCH(sap_ce_kernel, dim3(1), dim3(1024), 0, st, logits, labels, loss, dlogits, B, G, scale, ignore_index);
   ETP_CHECK_LAUNCH("sap_ce");
   return ETP_OK;
 }
@@ -834,16 +846,16 @@ int sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogi
 int vocab_ce(int dtype, const float* logits, const int64_t* labels, float* loss, void* dl, int Nm, int V, int ldv, float scale,
              hipStream_t st) {
   ETP_REQUIRE(logits && labels && loss && dl && Nm > 0 && V > 0 && ldv >= V, "bad arguments");
-  if (dtype == ETP_BF16) hipLaunchKernelGGL((vocab_ce_kernel<bf16_t>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (bf16_t*)dl, V, ldv, scale);
-  else hipLaunchKernelGGL((vocab_ce_kernel<float>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (float*)dl, V, ldv, scale);
+  if (dtype == ETP_BF16) ETP_LAUNCH((vocab_ce_kernel<bf16_t>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (bf16_t*)dl, V, ldv, scale);
+  else ETP_LAUNCH((vocab_ce_kernel<float>), dim3(Nm), dim3(256), 0, st, logits, labels, loss, (float*)dl, V, ldv, scale);
   ETP_CHECK_LAUNCH("vocab_ce");
   return ETP_OK;
 }
 int gelu_bwd_inplace(int dtype, void* d, const void* z, long n, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n + 255) / 256, 2048);
-  if (dtype == ETP_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)d, (const bf16_t*)z, n);
-  else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)d, (const float*)z, n);
+  if (dtype == ETP_BF16) ETP_LAUNCH((gelu_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)d, (const bf16_t*)z, n);
+  else ETP_LAUNCH((gelu_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)d, (const float*)z, n);
   ETP_CHECK_LAUNCH("gelu_bwd");
   return ETP_OK;
 }
@@ -852,8 +864,8 @@ int gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* id
                int accumulate, hipStream_t st) {
   ETP_REQUIRE(N > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(N, 4096);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gather_sum_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, ptr, idx, w, (bf16_t*)out, N, accumulate)); }
-  else { ETP_DISPATCH_H(H, hipLaunchKernelGGL((gather_sum_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)src, ptr, idx, w, (float*)out, N, accumulate)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((gather_sum_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, ptr, idx, w, (bf16_t*)out, N, accumulate)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH((gather_sum_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, (const float*)src, ptr, idx, w, (float*)out, N, accumulate)); }
   ETP_CHECK_LAUNCH("gather_sum");
   return ETP_OK;
 }
@@ -862,8 +874,8 @@ int colsum(int dtype, const void* dy, long ld, float* db, int M, int N, hipStrea
   ETP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "bad dims");
   const int rpb = 64;
   dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
-  if (dtype == ETP_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ld, db, M, N, rpb);
-  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ld, db, M, N, rpb);
+  if (dtype == ETP_BF16) ETP_LAUNCH((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ld, db, M, N, rpb);
+  else ETP_LAUNCH((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ld, db, M, N, rpb);
   ETP_CHECK_LAUNCH("colsum");
   return ETP_OK;
 }
@@ -871,7 +883,7 @@ int colsum(int dtype, const void* dy, long ld, float* db, int M, int N, hipStrea
 int cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n / 8 + 255) / 256 + 1, 4096);
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  ETP_LAUNCH(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
   ETP_CHECK_LAUNCH("cast_f32_bf16");
   return ETP_OK;
 }
@@ -879,15 +891,15 @@ int cast_drop(int dtype, const float* src, void* dst, long n, Drop drop, hipStre
   if (n <= 0) return ETP_OK;
   ETP_REQUIRE(n % 4 == 0, "cast_drop: element count must be a multiple of 4");
   const int grid = (int)std::min<long>((n / 4 + 255) / 256, 4096);
-  if (dtype == ETP_BF16) hipLaunchKernelGGL((cast_drop_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n, drop);
-  else hipLaunchKernelGGL((cast_drop_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, drop);
+  if (dtype == ETP_BF16) ETP_LAUNCH((cast_drop_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n, drop);
+  else ETP_LAUNCH((cast_drop_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n, drop);
   ETP_CHECK_LAUNCH("cast_drop");
   return ETP_OK;
 }
 int cast_bf16_to_f32(const void* src, float* dst, long n, float scale, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, scale);
+  ETP_LAUNCH(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n, scale);
   ETP_CHECK_LAUNCH("cast_bf16_f32");
   return ETP_OK;
 }
@@ -900,7 +912,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ dst, 
 int zero_f32(float* dst, long n, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n / 4 + 255) / 256 + 1, 4096);
-  hipLaunchKernelGGL(zero_f32_kernel, dim3(grid), dim3(256), 0, st, dst, n);
+  ETP_LAUNCH(zero_f32_kernel, dim3(grid), dim3(256), 0, st, dst, n);
   ETP_CHECK_LAUNCH("zero_f32");
   return ETP_OK;
 }
@@ -910,14 +922,14 @@ int copy_f32(const float* src, float* dst, long n, hipStream_t st) {
   if (n <= 0 || src == dst) return ETP_OK;
   ETP_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "copy_f32: 16-byte aligned buffers required");
   const int grid = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
-  hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(256), 0, st, src, dst, n);
+  ETP_LAUNCH(copy_f32_kernel, dim3(grid), dim3(256), 0, st, src, dst, n);
   ETP_CHECK_LAUNCH("copy_f32");
   return ETP_OK;
 }
 int scale_f32(float* p, long n, float scale, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid), dim3(256), 0, st, p, n, scale);
+  ETP_LAUNCH(scale_f32_kernel, dim3(grid), dim3(256), 0, st, p, n, scale);
   ETP_CHECK_LAUNCH("scale_f32");
   return ETP_OK;
 }

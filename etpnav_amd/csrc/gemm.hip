@@ -537,8 +537,9 @@ __device__ __forceinline__ void dma_issue(DmaPlan<T, TR, ROWS>& p, unsigned lds_
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// One BM x BN output tile of problem `g` through the LDS-DMA main loop (shared by the single-problem and the grouped kernel).
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
+__device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem) {
   using GA = TileGeom<T, TA, BM, 0>;
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int BK = MmaTraits<T>::BK;
@@ -546,19 +547,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
   constexpr int MT = BM / 32, NT = BN / 32;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
   constexpr int PER_SLAB = DmaPlan<T, TA, BM>::PER_WAVE + DmaPlan<T, TB, BN>::PER_WAVE;   // DMA instrs per wave per slab
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
-  const int zo = z / g.nb_inner, zi = z % g.nb_inner;
-  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
-  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
-  TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
 
   int kbeg = 0, kend = g.K;
   if (g.ksplit > 1) {
@@ -635,6 +627,44 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
   gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
 }
 
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
+  const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
+  const int zo = z / g.nb_inner, zi = z % g.nb_inner;
+  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem);
+}
+
+// Grouped launch: up to ETP_GEMM_GROUP_MAX independent products of one storage/dtype/tile class in ONE grid (the four
+// weight gradients of a transformer layer, the text K/V projections of all x-layers).  The concatenated tile list is cut
+// into 8 contiguous chunks, one per XCD (workgroup i runs on XCD i % 8), so every private L2 sees a compact slab of one or
+// two problems; inside a problem tiles run along the longer tile axis first (same order as tile_of_block).
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ETP_GEMM_GROUP_MAX; ++i)
+    if (i < grp.n && id >= grp.tile_start[i]) p = i;
+  const GemmArgs& g = grp.g[p];
+  const int local = id - grp.tile_start[p];
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  int tm, tn;
+  if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
+  else { tn = local / tiles_m; tm = local % tiles_m; }
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
+                                          reinterpret_cast<TC*>(g.C), tm, tn, 0, smem);
+}
+
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static bool g_prof_on = false;
@@ -691,7 +721,7 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   dim3 grid(tiles, nbatch * g.ksplit, 1);
   ProfRec rec;
-  const bool prof = g_prof_on;
+  const bool prof = g_prof_on && !rec_active();
   if (prof) {
     char nm[96];
     snprintf(nm, sizeof(nm), "gemm%s<%s,%s,%s%s,%dx%d>", STAGES ? "_dma" : "", sizeof(T) == 2 ? "bf16" : "f32",
@@ -704,7 +734,7 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
     ETP_CHECK_HIP(hipEventCreate(&rec.b));
     ETP_CHECK_HIP(hipEventRecord(rec.a, st));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
+  ETP_LAUNCH(kern, grid, dim3(256), smem, st, g);
   ETP_CHECK_LAUNCH("gemm");
   if (prof) {
     ETP_CHECK_HIP(hipEventRecord(rec.b, st));
@@ -771,8 +801,8 @@ static int launch_trans(int ta, int tb, const GemmArgs& g, int nbatch, hipStream
   return fail(ETP_ERR_INVALID, "gemm: (A trans, B row) storage pairing is not used on this path");
 }
 
-int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, int nbatch, hipStream_t st) {
-  const GemmArgs& g0 = g_in;
+// argument checks + derived fields (xcd_map, vec_epilogue) shared by the single and the grouped launcher
+static int prepare_args(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g0, int nbatch, GemmArgs& g) {
   ETP_REQUIRE(g0.M > 0 && g0.N > 0 && g0.K >= 0 && nbatch > 0 && g0.ksplit >= 1 && g0.nb_inner >= 1, "bad dims");
   const int epc = dtype == ETP_BF16 ? 8 : 4;
   ETP_REQUIRE(g0.lda % epc == 0 && g0.ldb % epc == 0, "lda/ldb must be multiples of a 16-byte chunk");
@@ -784,28 +814,128 @@ int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, in
   ETP_REQUIRE(g0.drop.p == 0.f || (g0.ksplit == 1 && nbatch == 1), "epilogue dropout needs an unsplit, unbatched product");
   ETP_REQUIRE(g0.a_colsum == nullptr || (ta && tb && gemm_uses_dma(dtype, g0.K, g0.ksplit)),
               "a_colsum needs the TN LDS-DMA kernel (check gemm_uses_dma first)");
-  GemmArgs g = g_in;
+  ETP_REQUIRE(dtype != ETP_F32 || c_dtype == ETP_F32, "fp32 operands need an fp32 C");
+  g = g0;
   {
     static const int xcd_on = [] { const char* e = getenv("ETP_GEMM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
     g.xcd_map = xcd_on;
   }
   {  // the vectorised epilogue needs 8-column chunks to stay in-bounds and 16-byte aligned
-    const size_t cs = dtype_size(c_dtype), ts = dtype_size(dtype);
+    const size_t cs = dtype_size(c_dtype);
     bool ok = (g.ldc % 8 == 0) && (g.ldc >= round_up(g.N, 8)) && ((uintptr_t)g.C % 16 == 0) && ((g.sCo * cs) % 16 == 0) &&
               ((g.sCi * cs) % 16 == 0);
     if (g.bias) ok = ok && ((uintptr_t)g.bias % 16 == 0) && (g.N % 8 == 0);
     if (g.R) ok = ok && (g.ldr % 8 == 0) && ((uintptr_t)g.R % 16 == 0) && (g.ldr >= round_up(g.N, 8));
     if (g.Z) ok = ok && (g.ldz % 8 == 0) && ((uintptr_t)g.Z % 16 == 0) && (g.ldz >= round_up(g.N, 8));
-    (void)ts;
     if (g.out_mode == 2) ok = false;   // atomics: lane-consecutive fp32 columns (row-major scalar path) coalesce best
     g.vec_epilogue = ok ? 1 : 0;
   }
-  if (dtype == ETP_F32) {
-    ETP_REQUIRE(c_dtype == ETP_F32, "fp32 operands need an fp32 C");
-    return launch_trans<float, float>(ta, tb, g, nbatch, st);
-  }
+  return ETP_OK;
+}
+
+int launch_gemm(int dtype, int c_dtype, int ta, int tb, const GemmArgs& g_in, int nbatch, hipStream_t st) {
+  GemmArgs g;
+  ETP_TRY(prepare_args(dtype, c_dtype, ta, tb, g_in, nbatch, g));
+  if (dtype == ETP_F32) return launch_trans<float, float>(ta, tb, g, nbatch, st);
   if (c_dtype == ETP_F32) return launch_trans<bf16_t, float>(ta, tb, g, nbatch, st);
   return launch_trans<bf16_t, bf16_t>(ta, tb, g, nbatch, st);
+}
+
+// ---- grouped launch ---------------------------------------------------------------------------------------------------
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+static int launch_group_one(GemmGroup& grp, hipStream_t st) {
+  using GA = TileGeom<T, TA, BM, 0>;
+  using GB = TileGeom<T, TB, BN, 0>;
+  constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
+  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
+  static bool attr_set = false;
+  void (*kern)(const GemmGroup) = gemm_group_kernel<T, TC, TA, TB, BM, BN, STAGES>;
+  if (!attr_set) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  int tiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    const GemmArgs& g = grp.g[i];
+    grp.tile_start[i] = tiles;
+    tiles += ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    flops += 2.0 * g.M * g.N * g.K;
+    bytes += ((double)g.M * g.K + (double)g.N * g.K) * sizeof(T) + (double)g.M * g.N * sizeof(TC);
+  }
+  for (int i = grp.n; i <= ETP_GEMM_GROUP_MAX; ++i) grp.tile_start[i] = tiles;
+  ProfRec rec;
+  const bool prof = g_prof_on && !rec_active();
+  if (prof) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "gemm_group<%s,%s,%s%s,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
+             TA ? "T" : "N", TB ? "N" : "T", BM, BN);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    rec.id = prof_id(nm);
+    rec.flops = flops; rec.bytes = bytes;
+    ETP_CHECK_HIP(hipEventCreate(&rec.a));
+    ETP_CHECK_HIP(hipEventCreate(&rec.b));
+    ETP_CHECK_HIP(hipEventRecord(rec.a, st));
+  }
+  ETP_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, grp);
+  ETP_CHECK_LAUNCH("gemm_group");
+  if (prof) {
+    ETP_CHECK_HIP(hipEventRecord(rec.b, st));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(rec);
+  }
+  return ETP_OK;
+}
+
+template <typename T, typename TC, bool TA, bool TB>
+static int launch_group_tiles(GemmGroup& grp, hipStream_t st) {
+  long t128 = 0;
+  bool all_big = true;
+  for (int i = 0; i < grp.n; ++i) {
+    t128 += (long)((grp.g[i].M + 127) / 128) * ((grp.g[i].N + 127) / 128);
+    all_big = all_big && grp.g[i].M >= 128 && grp.g[i].N >= 128;
+  }
+  // 128x128 tiles halve the L2->LDS bytes per FLOP; they pay once the group still gives most CUs a tile
+  bool big = all_big && t128 >= 160;
+  int stages = big ? 2 : 3;
+  const char* force = getenv("ETP_GROUP_TILE");          // tuning aid: "128s2", "128s3", "64s3", "64s4"
+  if (force && force[0]) {
+    big = force[0] == '1' && all_big;
+    stages = big ? 2 : 3;
+    if (strstr(force, "s2")) stages = 2;
+    if (strstr(force, "s3")) stages = 3;
+    if (strstr(force, "s4")) stages = 4;
+  }
+  if (big) {
+    if (stages == 3) return launch_group_one<T, TC, TA, TB, 128, 128, 3>(grp, st);
+    return launch_group_one<T, TC, TA, TB, 128, 128, 2>(grp, st);
+  }
+  if (stages == 4) return launch_group_one<T, TC, TA, TB, 64, 64, 4>(grp, st);
+  if (stages == 2) return launch_group_one<T, TC, TA, TB, 64, 64, 2>(grp, st);
+  return launch_group_one<T, TC, TA, TB, 64, 64, 3>(grp, st);
+}
+
+template <typename T, typename TC>
+static int launch_group_trans(int ta, int tb, GemmGroup& grp, hipStream_t st) {
+  if (!ta && !tb) return launch_group_tiles<T, TC, false, false>(grp, st);
+  if (!ta && tb) return launch_group_tiles<T, TC, false, true>(grp, st);
+  if (ta && tb) return launch_group_tiles<T, TC, true, true>(grp, st);
+  return fail(ETP_ERR_INVALID, "gemm group: (A trans, B row) storage pairing is not used on this path");
+}
+
+int launch_gemm_group(int dtype, int c_dtype, int ta, int tb, const GemmArgs* gs, int n, hipStream_t st) {
+  ETP_REQUIRE(gs && n >= 1 && n <= ETP_GEMM_GROUP_MAX, "1..ETP_GEMM_GROUP_MAX problems per group");
+  if (n == 1) return launch_gemm(dtype, c_dtype, ta, tb, gs[0], 1, st);
+  GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.n = n;
+  for (int i = 0; i < n; ++i) {
+    ETP_REQUIRE(gs[i].ksplit == 1 && gemm_uses_dma(dtype, gs[i].K, 1), "grouped products need unsplit LDS-DMA-able reductions");
+    ETP_TRY(prepare_args(dtype, c_dtype, ta, tb, gs[i], 1, grp.g[i]));
+  }
+  if (dtype == ETP_F32) return launch_group_trans<float, float>(ta, tb, grp, st);
+  if (c_dtype == ETP_F32) return launch_group_trans<bf16_t, float>(ta, tb, grp, st);
+  return launch_group_trans<bf16_t, bf16_t>(ta, tb, grp, st);
 }
 
 }  // namespace etp

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void vp_gather_kernel(const float* __restrict_
 int gmap_assemble(const GmapArgs& a, int B, hipStream_t st) {
   ETP_REQUIRE(B > 0 && a.Nmax >= 1 && a.Nmax <= GN && a.Mmax >= 0 && a.Mmax <= GM && a.G >= 1 && a.Fmax >= 0,
               "graph limits: <= 64 visited nodes and <= 192 ghosts per episode");
-  hipLaunchKernelGGL(gmap_assemble_kernel, dim3(B), dim3(256), 0, st, a);
+  ETP_LAUNCH(gmap_assemble_kernel, dim3(B), dim3(256), 0, st, a);
   ETP_CHECK_LAUNCH("gmap_assemble");
   return ETP_OK;
 }
@@ -195,7 +195,7 @@ extern "C" int etp_vp_gather(const float* cand_fts, const int32_t* cand_ptr, con
                              int64_t* view_lens, etp_stream_t stream) {
   using namespace etp;
   ETP_REQUIRE(cand_ptr && pano_fts && cand_mask && out_fts && B > 0 && P > 0 && F > 0 && V > 0, "bad arguments");
-  hipLaunchKernelGGL(vp_gather_kernel, dim3(B * V), dim3(256), 0, (hipStream_t)stream, cand_fts, cand_ptr, pano_fts,
+  ETP_LAUNCH(vp_gather_kernel, dim3(B * V), dim3(256), 0, (hipStream_t)stream, cand_fts, cand_ptr, pano_fts,
                      (long)pano_batch_stride, cand_mask, P, F, V, out_fts, nav_types, view_lens);
   ETP_CHECK_LAUNCH("vp_gather");
   return ETP_OK;

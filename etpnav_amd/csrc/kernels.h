@@ -17,8 +17,14 @@ int ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const f
            float* dgamma, float* dbeta, int M, int H, hipStream_t st);
 int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,
              float eps, hipStream_t st);
+// part != NULL: two-stage dgamma/dbeta reduction -- the kernel writes per-block column sums to `part`
+// (ln_bwd_part_bytes(M, H) bytes) and the caller issues ln_part_reduce(part, M, H, dgamma, dbeta) anywhere later (it is a
+// leaf of the backward graph); part == NULL: per-block atomics straight into dgamma / dbeta.
+constexpr int LN_BWD_MAX_BLOCKS = 512;
+size_t ln_bwd_part_bytes(int M, int H);
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
-             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop = drop_none());
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop = drop_none(), float* part = nullptr);
+int ln_part_reduce(const float* part, int M, int H, float* dgamma, float* dbeta, hipStream_t st);
 int softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, int B,
                 int nh, int Lq, int Lk, int ldS, int mask_mode, hipStream_t st);
 int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_sp_w, float* d_sp_b, int B, int nh, int Lq,
@@ -64,7 +70,8 @@ int zero_f32(float* dst, long n, hipStream_t st);
 
 // optim.hip: fused AdamW (+ bf16 shadow refresh + gradient zeroing) and the gradient norm / non-finite scan
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,
-               const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st);
+               const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st,
+               int32_t* step_dev = nullptr);
 int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st);
 
 // attention = batched MFMA GEMMs + masked softmax (planner.hip); head dim 64, heads interleaved in the row

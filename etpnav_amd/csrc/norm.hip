@@ -127,10 +127,10 @@ static int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* 
                     hipStream_t st) {
   const int grid = (int)std::min<long>((M + 3) / 4, 4096);
   switch (H / 256) {
-    case 1: hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
-    case 2: hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
-    case 3: hipLaunchKernelGGL((ln_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
-    case 4: hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
+    case 1: ETP_LAUNCH((ln_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
+    case 2: ETP_LAUNCH((ln_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
+    case 3: ETP_LAUNCH((ln_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
+    case 4: ETP_LAUNCH((ln_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, eps); break;
     default: return fail(ETP_ERR_INVALID, "layer norm: hidden size must be 256, 512, 768 or 1024");
   }
   ETP_CHECK_LAUNCH("ln_fwd");
@@ -142,10 +142,10 @@ static int ln_bwd_t(const void* dy, const void* x, const float* stats, const flo
                     float* dgamma, float* dbeta, int M, int H, hipStream_t st) {
   const int grid = (int)std::min<long>((M + 7) / 8, 128);   // 2 rows per wave minimum; each block flushes 2*H atomics
   switch (H / 256) {
-    case 1: hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
-    case 2: hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
-    case 3: hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
-    case 4: hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
+    case 1: ETP_LAUNCH((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
+    case 2: ETP_LAUNCH((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
+    case 3: ETP_LAUNCH((ln_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
+    case 4: ETP_LAUNCH((ln_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, M); break;
     default: return fail(ETP_ERR_INVALID, "layer norm: hidden size must be 256, 512, 768 or 1024");
   }
   ETP_CHECK_LAUNCH("ln_bwd");
@@ -193,7 +193,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ add, float* __restrict__ dx, T* __restrict__ dxt,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M, Drop drop) {
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ part, int M, Drop drop) {
   constexpr int H = NCH * 256;
   __shared__ float red[4][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -257,18 +258,49 @@ __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__
       red[wave][1][c * 256 + lane * 4 + e] = ab[c][e];
     }
   __syncthreads();
+  if (part != nullptr) {
+    // two-stage parameter-gradient reduction: this block's column sums go to its own slab [2][H]; ln_part_reduce_kernel
+    // (a leaf of the backward graph, issued off the dependent chain) adds the slabs into dgamma / dbeta
+    float* slab = part + (long)blockIdx.x * 2 * H;
+    for (int col = threadIdx.x; col < 2 * H; col += 256) {
+      const int which = col / H, c = col % H;
+      slab[col] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+    return;
+  }
   for (int col = threadIdx.x; col < H; col += 256) {
     atomicAdd(dgamma + col, red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col]);
     atomicAdd(dbeta + col, red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col]);
   }
 }
 
+// dgamma[c] += sum_b part[b][0][c], dbeta[c] += sum_b part[b][1][c].  Grid (2H/256, slab chunks): one thread per column and
+// chunk of LN_PART_CHUNK slabs (coalesced rows, independent loads in flight), one atomic per thread -- 2H x ~10 atomics in
+// total instead of 2H per workgroup of the backward kernel.
+constexpr int LN_PART_CHUNK = 32;
+__global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __restrict__ part, int nblk, int H,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= 2 * H) return;
+  const int b0 = blockIdx.y * LN_PART_CHUNK, b1 = min(nblk, b0 + LN_PART_CHUNK);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    a0 += part[(long)(b + 0) * 2 * H + col]; a1 += part[(long)(b + 1) * 2 * H + col];
+    a2 += part[(long)(b + 2) * 2 * H + col]; a3 += part[(long)(b + 3) * 2 * H + col];
+  }
+  for (; b < b1; ++b) a0 += part[(long)b * 2 * H + col];
+  const float v = (a0 + a1) + (a2 + a3);
+  if (col < H) atomicAdd(dgamma + col, v);
+  else atomicAdd(dbeta + col - H, v);
+}
+
 #define ETP_LN_DISPATCH(KERN, T, GRID, ...)                                                                         \
   switch (H / 256) {                                                                                                 \
-    case 1: hipLaunchKernelGGL((KERN<T, 1>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 2: hipLaunchKernelGGL((KERN<T, 2>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 3: hipLaunchKernelGGL((KERN<T, 3>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 4: hipLaunchKernelGGL((KERN<T, 4>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 1: ETP_LAUNCH((KERN<T, 1>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 2: ETP_LAUNCH((KERN<T, 2>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 3: ETP_LAUNCH((KERN<T, 3>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 4: ETP_LAUNCH((KERN<T, 4>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
     default: return fail(ETP_ERR_INVALID, "layer norm: hidden size must be 256, 512, 768 or 1024");                 \
   }
 
@@ -282,16 +314,34 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
   ETP_CHECK_LAUNCH("ln_fwd_s");
   return ETP_OK;
 }
+// number of workgroups ln_bwd_s launches for M rows (= slabs of the two-stage reduction): every wave gets the same number
+// of rows, at most LN_BWD_MAX_BLOCKS blocks (>= 2 per CU at M = 2560)
+static int ln_bwd_blocks(int M) {
+  const int groups = (M + 3) / 4;
+  static const int cap = [] { const char* e = getenv("ETP_LNBWD_GRID"); return e ? std::max(1, atoi(e)) : LN_BWD_MAX_BLOCKS; }();
+  const int rounds = (groups + cap - 1) / cap;
+  return (groups + rounds - 1) / rounds;
+}
+size_t ln_bwd_part_bytes(int M, int H) { return (size_t)std::min(ln_bwd_blocks(M), LN_BWD_MAX_BLOCKS) * 2 * H * sizeof(float); }
+
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
-             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop) {
+             void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop, float* part) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (dx || dxt), "bad arguments");
   ETP_REQUIRE(drop.p == 0.f || (dxt != nullptr && dxt != (void*)dx), "dropout needs a separate operand copy");
-  const char* eg = getenv("ETP_LNBWD_GRID");
-  const int cap = eg ? atoi(eg) : 128;
-  const int grid = (int)std::min<long>((M + 3) / 4, cap);
-  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, M, drop) }
-  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, M, drop) }
+  // without a slab buffer the blocks flush 2*H atomics each: keep their number low (128, the round-1 setting)
+  const int grid = part ? ln_bwd_blocks(M) : (int)std::min<long>((M + 3) / 4, 128);
+  if (dgamma == nullptr) part = nullptr;
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, part, M, drop) }
+  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, part, M, drop) }
   ETP_CHECK_LAUNCH("ln_bwd_s");
+  return ETP_OK;
+}
+int ln_part_reduce(const float* part, int M, int H, float* dgamma, float* dbeta, hipStream_t st) {
+  ETP_REQUIRE(part && dgamma && dbeta && M > 0 && H % 256 == 0, "bad arguments");
+  const int nblk = ln_bwd_blocks(M);
+  ETP_LAUNCH(ln_part_reduce_kernel, dim3((2 * H + 255) / 256, (nblk + LN_PART_CHUNK - 1) / LN_PART_CHUNK), dim3(256), 0, st, part, nblk, H,
+             dgamma, dbeta);
+  ETP_CHECK_LAUNCH("ln_part_reduce");
   return ETP_OK;
 }
 
@@ -400,9 +450,9 @@ int softmax_fwd(int dtype, void* S, const uint8_t* keymask, const float* dist, c
   const long rows = (long)B * nh * Lq;
   const int grid = (int)std::min<long>((rows + 3) / 4, 8192);
   if (dtype == ETP_BF16)
-    hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)S, keymask, dist, sp_w, sp_b, (int)rows, nh, Lq, Lk, ldS, mask_mode);
+    ETP_LAUNCH((softmax_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)S, keymask, dist, sp_w, sp_b, (int)rows, nh, Lq, Lk, ldS, mask_mode);
   else
-    hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)S, keymask, dist, sp_w, sp_b, (int)rows, nh, Lq, Lk, ldS, mask_mode);
+    ETP_LAUNCH((softmax_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)S, keymask, dist, sp_w, sp_b, (int)rows, nh, Lq, Lk, ldS, mask_mode);
   ETP_CHECK_LAUNCH("softmax_fwd");
   return ETP_OK;
 }
@@ -413,9 +463,9 @@ int softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float* d_
   const long rows = (long)B * nh * Lq;
   const int grid = (int)std::min<long>((rows + 3) / 4, 1024);
   if (dtype == ETP_BF16)
-    hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)P, (bf16_t*)dP, dist, d_sp_w, d_sp_b, (int)rows, nh, Lq, Lk, ldS);
+    ETP_LAUNCH((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)P, (bf16_t*)dP, dist, d_sp_w, d_sp_b, (int)rows, nh, Lq, Lk, ldS);
   else
-    hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)P, (float*)dP, dist, d_sp_w, d_sp_b, (int)rows, nh, Lq, Lk, ldS);
+    ETP_LAUNCH((softmax_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)P, (float*)dP, dist, d_sp_w, d_sp_b, (int)rows, nh, Lq, Lk, ldS);
   ETP_CHECK_LAUNCH("softmax_bwd");
   return ETP_OK;
 }
@@ -441,9 +491,9 @@ int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS,
   ETP_REQUIRE(src && dst && rows > 0 && Lk > 0 && ldS >= Lk, "bad arguments");
   const int grid = (int)std::min<long>((rows + 3) / 4, 2048);
   if (dtype == ETP_BF16)
-    hipLaunchKernelGGL((drop_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Lk, ldS, drop);
+    ETP_LAUNCH((drop_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Lk, ldS, drop);
   else
-    hipLaunchKernelGGL((drop_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Lk, ldS, drop);
+    ETP_LAUNCH((drop_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Lk, ldS, drop);
   ETP_CHECK_LAUNCH("drop_rows");
   return ETP_OK;
 }

@@ -36,8 +36,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n_shadow,
                                                     const uint8_t* __restrict__ decay_mask, long n, AdamwK k,
                                                     const float* __restrict__ sumsq, const int32_t* __restrict__ skip,
-                                                    int zero_grads) {
+                                                    int zero_grads, const int32_t* __restrict__ step_dev) {
   const bool skipped = skip != nullptr && skip[0] != 0;      // GradScaler: non-finite gradients -> no update this step
+  if (step_dev != nullptr && k.bc1 < 0.f) {
+    // device-side step counter (GradScaler semantics: a skipped step does not advance optimizer.state['step']): the bias
+    // corrections follow the number of APPLIED updates, already bumped by adamw_bump_kernel for this call
+    const float t = (float)step_dev[0];
+    k.bc1 = 1.0f - powf(k.beta1, t);
+    k.bc2_sqrt = sqrtf(1.0f - powf(k.beta2, t));
+  }
   float gs = k.grad_scale;
   if (k.max_norm > 0.f && sumsq != nullptr) {
     const float norm = sqrtf(sumsq[0]) * fabsf(k.grad_scale);
@@ -77,6 +84,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
+__global__ void adamw_bump_kernel(int32_t* __restrict__ step_dev, const int32_t* __restrict__ skip) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip != nullptr && skip[0] != 0)) step_dev[0] += 1;
+}
+
 // sum of squares (+ count of non-finite values) of a gradient arena; both outputs ACCUMULATE (zero them first)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ sumsq,
                                                      int32_t* __restrict__ nonfinite) {
@@ -103,23 +114,28 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 }
 
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,
-               const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st) {
+               const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st,
+               int32_t* step_dev) {
   ETP_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "arena pointers / length (multiple of 4) required");
   ETP_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "arenas must be 16-byte aligned");
-  ETP_REQUIRE(c.step >= 1 && c.beta1 >= 0.f && c.beta1 < 1.f && c.beta2 >= 0.f && c.beta2 < 1.f && c.eps >= 0.f, "bad hyper-parameters");
+  ETP_REQUIRE((c.step >= 1 || step_dev != nullptr) && c.beta1 >= 0.f && c.beta1 < 1.f && c.beta2 >= 0.f && c.beta2 < 1.f && c.eps >= 0.f, "bad hyper-parameters");
   ETP_REQUIRE(shadow == nullptr || (n_shadow >= 0 && n_shadow <= n && n_shadow % 4 == 0 && (uintptr_t)shadow % 8 == 0), "bad shadow region");
   AdamwK k;
   k.lr = c.lr; k.beta1 = c.beta1; k.beta2 = c.beta2; k.eps = c.eps; k.wd = c.weight_decay;
   k.hf_style = c.hf_style; k.grad_scale = c.grad_scale; k.max_norm = c.max_norm;
-  if (c.correct_bias) {
+  if (c.correct_bias && step_dev != nullptr) {
+    k.bc1 = -1.f; k.bc2_sqrt = 1.f;           // computed in the kernel from the device counter
+    ETP_LAUNCH(adamw_bump_kernel, dim3(1), dim3(64), 0, st, step_dev, skip);
+  } else if (c.correct_bias) {
     k.bc1 = (float)(1.0 - pow((double)c.beta1, (double)c.step));
     k.bc2_sqrt = (float)sqrt(1.0 - pow((double)c.beta2, (double)c.step));
   } else {
     k.bc1 = 1.f; k.bc2_sqrt = 1.f;
   }
   const int grid = (int)std::min<long>((n / 4 + 255) / 256, 256L * 16);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow, n_shadow, decay_mask, n, k, sumsq,
-                     skip, zero_grads);
+  if (!c.correct_bias && step_dev != nullptr) ETP_LAUNCH(adamw_bump_kernel, dim3(1), dim3(64), 0, st, step_dev, skip);
+  ETP_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow, n_shadow, decay_mask, n, k, sumsq,
+                     skip, zero_grads, (const int32_t*)step_dev);
   ETP_CHECK_LAUNCH("adamw");
   return ETP_OK;
 }
@@ -127,7 +143,7 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shad
 int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st) {
   ETP_REQUIRE(g && sumsq && n > 0 && n % 4 == 0 && (uintptr_t)g % 16 == 0, "bad arguments");
   const int grid = (int)std::min<long>((n / 4 + 255) / 256, 256L * 8);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, sumsq, nonfinite);
+  ETP_LAUNCH(sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, sumsq, nonfinite);
   ETP_CHECK_LAUNCH("grad_sqnorm");
   return ETP_OK;
 }

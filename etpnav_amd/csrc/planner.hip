@@ -14,6 +14,7 @@
 //   ws      per backward call: gradient scratch reused across layers
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -53,6 +54,10 @@ struct etp_planner {
   // 1: etp_nav_bwd / etp_pano_bwd leave their weight-gradient GEMMs running on the aux stream instead of joining them
   // before returning; the caller joins later (etp_txt_bwd* always joins, or etp_planner_join_aux)
   bool lazy_join = false;
+  // 1: weight-gradient GEMMs STORE into the matrix region of the gradient arena instead of accumulating (no fp32 read of
+  // C, and the caller zeroes only the vector/table tail [n_matrix, total) per step).  Valid when every matrix is touched by
+  // exactly one weight-gradient product between two optimizer steps (one planner step per optimizer step).
+  bool grad_overwrite = false;
   uint64_t drop_seed = 0;
   // optional second stream: weight-gradient GEMMs (leaves of the backward graph) run beside the dgrad chain
   hipStream_t aux = nullptr;
@@ -254,6 +259,9 @@ struct Ctx {
   // and of the host calls.  (Under rocprofv3 the kernel behind each marker started ~13 us late, tools/timeline.py;
   // unprofiled the step time is unchanged within noise, 5.21 -> 5.20 ms.)
   std::vector<std::function<int()>>* pend;
+  // Weight-gradient products collected since the last flush: launched as ONE grouped grid per flush (gemm_group_kernel) --
+  // a layer's four to seven small TN products fill the chip together, which none of them does alone.
+  std::vector<GemmArgs>* wq;
 };
 // dropout sites: (entry point, layer, slot) -> independent mask streams
 enum { SITE_EMBED = 0, SITE_ATT_P = 1, SITE_ATT_O = 2, SITE_FFN_O = 3, SITE_FFN_I = 4, SITE_X_P = 5, SITE_X_O = 6, SITE_HEAD = 7,
@@ -271,6 +279,7 @@ static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
   c.sw = (pl->aux != nullptr && pl->aux != c.st) ? pl->aux : c.st;
   c.H = pl->cfg.hidden; c.I = pl->cfg.inter; c.nh = pl->cfg.heads;
   c.pend = nullptr;
+  c.wq = nullptr;
   return c;
 }
 
@@ -278,15 +287,25 @@ static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
 static int stream_after(etp_planner* pl, hipStream_t from, hipStream_t to) {
   if (from == to) return ETP_OK;
   hipEvent_t e = pl->next_event();
-  ETP_CHECK_HIP(hipEventRecord(e, from));
-  ETP_CHECK_HIP(hipStreamWaitEvent(to, e, 0));
+  ETP_CHECK_HIP(event_record(e, from));
+  ETP_CHECK_HIP(stream_wait_event(to, e));
   return ETP_OK;
 }
 static int flush_side(const Ctx& c) {
-  if (!c.pend || c.pend->empty()) return ETP_OK;
+  const bool have_w = c.wq && !c.wq->empty(), have_p = c.pend && !c.pend->empty();
+  if (!have_w && !have_p) return ETP_OK;
   ETP_TRY(stream_after(c.pl, c.st, c.sw));            // one fork for everything collected since the last flush
-  for (auto& f : *c.pend) ETP_TRY(f());
-  c.pend->clear();
+  if (have_w) {
+    for (size_t i = 0; i < c.wq->size(); i += ETP_GEMM_GROUP_MAX) {
+      const int n = (int)std::min<size_t>(ETP_GEMM_GROUP_MAX, c.wq->size() - i);
+      ETP_TRY(launch_gemm_group(c.dt, ETP_F32, 1, 1, c.wq->data() + i, n, c.sw));
+    }
+    c.wq->clear();
+  }
+  if (have_p) {
+    for (auto& f : *c.pend) ETP_TRY(f());
+    c.pend->clear();
+  }
   return ETP_OK;
 }
 // run `f` on the side stream after everything enqueued on the main stream so far (now, or at the next flush_side)
@@ -359,14 +378,27 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
   GemmArgs g = base_args();
   g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = c.pl->gf(wi); g.ldc = K;
   g.M = N; g.N = K; g.K = M;
+  // matrix-region gradients may be first-touch stores (etp_planner_set_grad_overwrite); tables (the tied MLM decoder adds
+  // into the word-embedding gradient) always accumulate
+  const bool store = c.pl->grad_overwrite && c.pl->params[wi].region == 0;
+  static const bool group_on = [] { const char* e = getenv("ETP_WGRAD_GROUP"); return !(e && e[0] == '0'); }();
+  if (c.wq && group_on && gemm_uses_dma(c.dt, M, 1)) {
+    // grouped path: whole token reduction in one tile pass (no split-K: the group as a whole fills the chip), bias
+    // gradient fused as column sums of the dY tile
+    g.out_mode = store ? 0 : 1;
+    if (bi >= 0) g.a_colsum = c.pl->gf(bi);
+    c.wq->push_back(g);
+    return ETP_OK;
+  }
   // split the token reduction (atomic fp32 accumulate) only when the weight alone badly under-fills 256 CUs and the
   // reduction is long; measured on MI355X (tools/gemm_bench.py): dW[768,768] over 2560 tokens 21 -> 17 us with 4 splits,
   // every other planner shape is fastest with a single read-modify-write pass.
   const int bk = c.dt == ETP_BF16 ? 64 : 32;
   const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
   int ks = (tiles <= 144 && M >= 2048 && M % (4 * bk) == 0) ? 4 : 1;
+  if (store) ks = 1;
   g.ksplit = ks;
-  g.out_mode = ks > 1 ? 2 : 1;
+  g.out_mode = ks > 1 ? 2 : (store ? 0 : 1);
   const bool fuse_bias = bi >= 0 && gemm_uses_dma(c.dt, M, ks);     // bias gradient rides in the wgrad kernel
   if (fuse_bias) g.a_colsum = c.pl->gf(bi);
   // weight gradients are leaves of the backward graph: issue them on the side stream, after dY's producer
@@ -505,7 +537,7 @@ static FfnStash plan_ffn(Bump& b, int dt, long M, int H, int I) {
 
 // Scratch of ONE backward sub-block.  Every sub-block gets a fresh set (HBM is plentiful) so that weight-gradient
 // GEMMs still running on the side stream never see their dY operand overwritten by a later layer.
-struct BwdWs { Act t1; void *t2, *dI, *dqkv, *dP; };
+struct BwdWs { Act t1; void *t2, *dI, *dqkv, *dP; float* lnp; };   // lnp: slabs of the two-stage LayerNorm dgamma/dbeta reduction
 static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, int H, int I) {
   const size_t es = dtype_size(dt);
   BwdWs w;
@@ -514,7 +546,23 @@ static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, i
   w.dI = b.take(M * I * es);
   w.dqkv = b.take(M * 3 * H * es);
   w.dP = b.take((size_t)Bn * nh * Lq * ldS * es);
+  w.lnp = (float*)b.take(ln_bwd_part_bytes((int)M, H));
   return w;
+}
+
+// LayerNorm backward on the dependent chain; the dgamma/dbeta reduction over the per-block slabs is a leaf and goes to the
+// side stream with the layer's weight gradients
+static int ln_bwd_chain(const Ctx& c, const float* dy, const float* x, const float* stats, int gi, int bi, const float* add,
+                        float* dx, void* dxt, int M, const Drop& d, float* part) {
+  etp_planner* pl = c.pl;
+  static const bool two_stage = [] { const char* e = getenv("ETP_LNBWD_TWO_STAGE"); return !(e && e[0] == '0'); }();
+  if (!two_stage) part = nullptr;
+  ETP_TRY(ln_bwd_s(c.dt, dy, x, stats, pl->pf(gi), add, dx, dxt, pl->gf(gi), pl->gf(bi), M, c.H, c.st, d, part));
+  if (!part) return ETP_OK;
+  float* dg = pl->gf(gi); float* db = pl->gf(bi);
+  const int H = c.H;
+  hipStream_t sw = c.sw;
+  return on_side(c, [=]() -> int { return ln_part_reduce(part, M, H, dg, db, sw); });
 }
 
 // y = LN(dropout(dense(attn(x))) + x)
@@ -536,8 +584,7 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
   const int H = c.H, M = Bn * L;
   etp_planner* pl = c.pl;
   const Drop dh = hid(c, mode, layer, SITE_ATT_O);
-  ETP_TRY(ln_bwd_s(c.dt, g, s.s, s.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
-                   c.st, dh));                                                          // t1.f = ds, operand copy = ds * mask
+  ETP_TRY(ln_bwd_chain(c, g, s.s, s.st, p.ln_g, p.ln_b, nullptr, w.t1.f, lp2(c, w.t1, dh), M, dh, w.lnp));   // t1.f = ds, operand copy = ds * mask
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
   ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t2 = dctx
@@ -561,8 +608,7 @@ static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f,
   const int H = c.H, I = c.I;
   etp_planner* pl = c.pl;
   const Drop dh = hid(c, mode, layer, SITE_FFN_O);
-  ETP_TRY(ln_bwd_s(c.dt, g_in ? g_in : g, f.s, f.st, pl->pf(p.ln_g), nullptr, w.t1.f, lp2(c, w.t1, dh), pl->gf(p.ln_g), pl->gf(p.ln_b), M, H,
-                   c.st, dh));
+  ETP_TRY(ln_bwd_chain(c, g_in ? g_in : g, f.s, f.st, p.ln_g, p.ln_b, nullptr, w.t1.f, lp2(c, w.t1, dh), M, dh, w.lnp));
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, f.h, I, p.o_w, p.o_b, M, H, I));
   ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));            // dI = dz
@@ -638,6 +684,11 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux) {
 int etp_planner_set_lazy_join(etp_planner* p, int lazy) {
   ETP_REQUIRE(p, "null planner");
   p->lazy_join = lazy != 0;
+  return ETP_OK;
+}
+int etp_planner_set_grad_overwrite(etp_planner* p, int on) {
+  ETP_REQUIRE(p, "null planner");
+  p->grad_overwrite = on != 0;
   return ETP_OK;
 }
 int etp_planner_join_aux(etp_planner* p, etp_stream_t stream) {
@@ -722,7 +773,9 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
   ETP_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= p->cfg.n_l, "bad layer range");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
+  std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
+  c.wq = &wq;
   Bump b(stash);
   TxtStash t = plan_txt(p, b, B, L);
   Bump wb(ws);
@@ -821,7 +874,7 @@ PanoEmbedGrads pano_grads(const etp_planner* p) {
   return q;
 }
 // per-layer backward scratch of the pre-LN panorama layer
-struct PanoWs { Act g; float* t1f; Act t2; void *dI, *t1, *dqkv, *dP; };
+struct PanoWs { Act g; float* t1f; Act t2; void *dI, *t1, *dqkv, *dP; float *lnp, *lnp2; };
 PanoWs plan_pano_ws(Bump& b, int dt, long M, int Bn, int nh, int V, int ldS, int H, int I) {
   const size_t es = dtype_size(dt);
   PanoWs w;
@@ -832,6 +885,8 @@ PanoWs plan_pano_ws(Bump& b, int dt, long M, int Bn, int nh, int V, int ldS, int
   w.t1 = b.take(M * H * es);
   w.dqkv = b.take(M * 3 * H * es);
   w.dP = b.take((size_t)Bn * nh * V * ldS * es);
+  w.lnp = (float*)b.take(ln_bwd_part_bytes((int)M, H));
+  w.lnp2 = (float*)b.take(ln_bwd_part_bytes((int)M, H));
   return w;
 }
 }  // namespace
@@ -859,7 +914,7 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
   PanoStash s = plan_pano(p, b, B, V);
   const etp_config& cf = p->cfg;
   const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
-  hipLaunchKernelGGL(seq_mask_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, view_lens, s.mask, out_mask, B, V);
+  ETP_LAUNCH(seq_mask_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, view_lens, s.mask, out_mask, B, V);
   ETP_CHECK_LAUNCH("seq_mask");
   const void* rgbT = rgb; const void* depT = dep;
   const Drop denv = site(c, p->p_env, MODE_PANO, 0, SITE_ENV);     // Policy_ViewSelection_ETP.py:102,345 (drop_env on the RGB features)
@@ -900,7 +955,9 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   ETP_REQUIRE(p && p->P && p->G && dout && rgb && loc && nav && stash && ws && B > 0 && V > 0, "bad arguments");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
+  std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
+  c.wq = &wq;
   Bump b(stash);
   PanoStash s = plan_pano(p, b, B, V);
   const etp_config& cf = p->cfg;
@@ -912,8 +969,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   if (cf.n_p > 0) {
     const float* xin = s.layers[cf.n_p - 1].x2;
     gd = hid(c, MODE_PANO, cf.n_p - 1, SITE_FFN_O);      // g's operand copy carries the mask of the layer that consumes it
-    ETP_TRY(ln_bwd_s(c.dt, dout, xin, s.stn, p->pf(p->pn_g), nullptr, g.f, lp2(c, g, gd), p->gf(p->pn_g), p->gf(p->pn_b), M, H,
-                     c.st, gd));
+    ETP_TRY(ln_bwd_chain(c, dout, xin, s.stn, p->pn_g, p->pn_b, nullptr, g.f, lp2(c, g, gd), M, gd, w0.lnp));
   } else {
     ETP_TRY(copy_f32(dout, g.f, (long)M * H, c.st));
   }
@@ -930,8 +986,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
     ETP_TRY(linear_dgrad_s(c, w.dI, I, q.l1_w, w.t1f, M, I, H, nullptr));                                         // t1f = df
     const Drop d1 = hid(c, MODE_PANO, l, SITE_ATT_O);
-    ETP_TRY(ln_bwd_s(c.dt, w.t1f, t.x1, t.st2, p->pf(q.n2_g), g.f, w.t2.f, lp2(c, w.t2, d1), p->gf(q.n2_g), p->gf(q.n2_b), M, H,
-                     c.st, d1));                                                                                    // t2 = dx1
+    ETP_TRY(ln_bwd_chain(c, w.t1f, t.x1, t.st2, q.n2_g, q.n2_b, g.f, w.t2.f, lp2(c, w.t2, d1), M, d1, w.lnp));     // t2 = dx1
     // attention: x1 = x + dropout1(Wo attn(LN1(x)))
     const void* t2op = op2(c, w.t2, d1);
     ETP_TRY(linear_wgrad(c, t2op, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
@@ -944,8 +999,8 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
     ETP_TRY(linear_dgrad_s(c, w.dqkv, 3 * H, q.in_w, w.t1f, M, 3 * H, H, nullptr));                               // t1f = da
     gd = l > 0 ? hid(c, MODE_PANO, l - 1, SITE_FFN_O) : drop_none();
-    ETP_TRY(ln_bwd_s(c.dt, w.t1f, x, t.st1, p->pf(q.n1_g), w.t2.f, w.g.f, l > 0 ? lp2(c, w.g, gd) : nullptr, p->gf(q.n1_g),
-                     p->gf(q.n1_b), M, H, c.st, gd));                                                               // dx
+    ETP_TRY(ln_bwd_chain(c, w.t1f, x, t.st1, q.n1_g, q.n1_b, w.t2.f, w.g.f, l > 0 ? lp2(c, w.g, gd) : nullptr, M, gd,
+                         w.lnp2));                                                                                  // dx
     ETP_TRY(flush_side(c));
     g = w.g;
   }
@@ -1095,11 +1150,13 @@ int etp_nav_kv_bwd(etp_planner* p, const float* txt, const void* d_kv, int B, in
   ETP_REQUIRE(p && p->P && p->G && txt && d_kv && kvbuf && d_txt && B > 0 && L > 0, "bad arguments");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
+  std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
+  c.wq = &wq;
   KvCache kc = plan_kv(p, const_cast<void*>(kvbuf), B, L);
   const int H = c.H, Mt = B * L;
   const void* txtT = c.dt == ETP_BF16 ? kc.txtT : (const void*)txt;
-  if (p->cfg.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
+  if (p->cfg.n_x == 0) ETP_CHECK_HIP(memset_async(d_txt, 0, (size_t)Mt * H * 4, c.st));
   for (int l = 0; l < p->cfg.n_x; ++l) {
     const void* d = offs(d_kv, (long)l * Mt * 2 * H, c.es);
     ETP_TRY(linear_wgrad(c, d, 2 * H, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, Mt, 2 * H, H));
@@ -1145,7 +1202,7 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
       ETP_TRY(linear_fwd(cs, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, s.layers[l].cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE,
                          nullptr, nullptr, 0));
       kv_ready[l] = p->next_event();
-      ETP_CHECK_HIP(hipEventRecord(kv_ready[l], c.sw));
+      ETP_CHECK_HIP(event_record(kv_ready[l], c.sw));
     }
   }
   for (int l = 0; l < cf.n_x; ++l) {   // GraphLXRTXLayer.forward vilmodel_cmt.py:383-398
@@ -1153,7 +1210,7 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
     XStash& t = s.layers[l];
     // cross attention nodes -> text (BertXAttention :360-363)
     ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
-    if (kv_side) ETP_CHECK_HIP(hipStreamWaitEvent(c.st, kv_ready[l], 0));
+    if (kv_side) ETP_CHECK_HIP(stream_wait_event(c.st, kv_ready[l]));
     else if (!cached)
       ETP_TRY(linear_fwd(c, txtT, H, q.kv_w, q.kv_b, t.cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     void* kv = cached ? kc.kv[l] : t.cross.kv;
@@ -1207,7 +1264,9 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
               "bad arguments");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
+  std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
+  c.wq = &wq;
   Bump b(stash);
   NavStash s = plan_nav(p, b, B, L, G);
   Bump wb(ws);
@@ -1232,7 +1291,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
   } else {
     ETP_TRY(copy_f32(d_embeds, g, (long)Mg * H, c.st));
   }
-  if (cf.n_x == 0 && !cached) ETP_CHECK_HIP(hipMemsetAsync(d_txt, 0, (size_t)Mt * H * 4, c.st));
+  if (cf.n_x == 0 && !cached) ETP_CHECK_HIP(memset_async(d_txt, 0, (size_t)Mt * H * 4, c.st));
   for (int l = cf.n_x - 1; l >= 0; --l) {
     const XLayerP& q = p->xl[l];
     const XStash& t = s.layers[l];
@@ -1244,8 +1303,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
                          n.self[l], MODE_NAV, l));
     // cross attention backward
     const Drop dx = hid(c, MODE_NAV, l, SITE_X_O);
-    ETP_TRY(ln_bwd_s(c.dt, g, t.cross.s, t.cross.st, p->pf(q.xln_g), nullptr, w.t1.f, lp2(c, w.t1, dx), p->gf(q.xln_g),
-                     p->gf(q.xln_b), Mg, H, c.st, dx));
+    ETP_TRY(ln_bwd_chain(c, g, t.cross.s, t.cross.st, q.xln_g, q.xln_b, nullptr, w.t1.f, lp2(c, w.t1, dx), Mg, dx, w.lnp));
     const void* dso = op2(c, w.t1, dx);
     ETP_TRY(linear_wgrad(c, dso, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
     ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
@@ -1439,7 +1497,9 @@ int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
               "bad arguments");
   Ctx c = make_ctx(p, stream);
   std::vector<std::function<int()>> pend;
+  std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
+  c.wq = &wq;
   Bump b(stash);
   MlmStash s = plan_mlm(p, b, B, L, G, Nm);
   Bump wb(ws);
@@ -1481,8 +1541,7 @@ int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     ETP_TRY(self_att_bwd(c, q.lself, t.y, t.self, B, L, txt_mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, w.self[l],
                          MODE_MLM, l));
     const Drop dx = hid(c, MODE_MLM, l, SITE_X_O);
-    ETP_TRY(ln_bwd_s(c.dt, g, t.s, t.st, p->pf(q.xln_g), nullptr, wc.t1.f, lp2(c, wc.t1, dx), p->gf(q.xln_g), p->gf(q.xln_b), Mt, H,
-                     c.st, dx));
+    ETP_TRY(ln_bwd_chain(c, g, t.s, t.st, q.xln_g, q.xln_b, nullptr, wc.t1.f, lp2(c, wc.t1, dx), Mt, dx, wc.lnp));
     const void* dso = op2(c, wc.t1, dx);
     ETP_TRY(linear_wgrad(c, dso, H, t.ctx, H, q.xo_w, q.xo_b, Mt, H, H));
     ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, wc.t2, H, Mt, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
@@ -1498,7 +1557,7 @@ int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     ETP_TRY(flush_side(c));
   }
   ETP_TRY(copy_f32(g, d_txt, (long)Mt * H, c.st));
-  if (cf.n_x == 0) ETP_CHECK_HIP(hipMemsetAsync(w.d_nodes, 0, (size_t)Mg * H * 4, c.st));
+  if (cf.n_x == 0) ETP_CHECK_HIP(memset_async(w.d_nodes, 0, (size_t)Mg * H * 4, c.st));
   ETP_TRY(copy_f32(w.d_nodes, d_img, (long)Mg * H, c.st));
   ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,

@@ -1,4 +1,4 @@
-"""Data-parallel gradient averaging over RCCL/xGMI (one process per GPU, torch.distributed backend "nccl" = RCCL).
+"""Data-parallel gradient averaging over RCCL/xGMI (one process per GPU).
 
 Replaces ``DistributedDataParallel(self.policy.net, ...)`` of ss_trainer_ETP.py:208-212 (and pretrain
 utils/misc.py:52-65) for the planner: episodes shard across ranks with no activation exchange; the only collective
@@ -7,34 +7,94 @@ is the mean of the parameter gradients, once per step.
 MI355X-first choices:
   * all gradients already live in ONE flat fp32 arena, so the reduction runs over a few large contiguous buckets
     (no per-parameter bucketing / flattening copies);
-  * gradients travel as bf16 (half the xGMI bytes; accumulation stays fp32 locally) unless ``comm_dtype=float32``;
+  * on GPUs the dense buckets go through the library's own communicator (C ABI ``etp_allreduce_*``, csrc/comm.hip):
+    in-place reduce-scatter -> 1/world scaling of the rank's slice -> all-gather on a private stream, RCCL bound at run
+    time; without it (CPU / gloo tests, or ``native=False``) the same buckets go through ``torch.distributed``;
+  * fp32 transport by default (DDP's numerics); ``comm_dtype=torch.bfloat16`` is opt-in (half the xGMI bytes, bf16 sums);
   * the word-embedding gradient is row-sparse (<= B*L of 30 522 / 250 002 rows are non-zero): instead of all-reducing
-    the dense 94 MB / 768 MB table, ranks all-gather their (row ids, rows) and scatter-add locally — same result as the
-    dense mean up to summation order;
-  * buckets are issued on RCCL's stream right after the backward segment that completes them, so the text-encoder
-    backward overlaps the reduction of everything computed before it (see ``PlannerStep``/bench.py).
+    the dense 94 MB / 768 MB table, ranks all-gather a FIXED-capacity (B*L ids, B*L rows) block and scatter-add locally —
+    same result as the dense mean up to summation order, and no host synchronisation (duplicates are masked on the
+    device, nothing depends on the number of distinct rows);
+  * buckets are issued right after the backward segment that completes them, so the text-encoder backward overlaps the
+    reduction of everything computed before it (see ``PlannerStep``/bench.py).
 Works unchanged on CPU with the ``gloo`` backend (tests/test_dp_gloo.py, world_size 2).
 """
 from __future__ import annotations
 
+import ctypes
+import os
+import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
+class NativeComm:
+    """The library's RCCL communicator (include/etpnav_hip.h ``etp_allreduce_*``).  The 128-byte unique id is created on
+    rank 0 and distributed through the existing torch.distributed group (any backend)."""
+
+    def __init__(self, device: torch.device, comm_dtype=torch.float32, max_bucket_elems: int = 0, group=None):
+        from . import _lib
+        self._lib, self.L = _lib, _lib.lib()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(self.L.etp_allreduce_unique_id(ident), "allreduce_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        cdt = _lib.ETP_BF16 if comm_dtype == torch.bfloat16 else _lib.ETP_F32
+        with torch.cuda.device(device):
+            _lib.check(self.L.etp_allreduce_init(ctypes.byref(h), ident, self.rank, self.world, cdt, int(max_bucket_elems)),
+                       "allreduce_init")
+        self.handle = h
+
+    def bucket_ready(self, grads: torch.Tensor, start: int, end: int):
+        self._lib.check(self.L.etp_allreduce_bucket_ready(self.handle, grads.data_ptr() + 4 * start, end - start,
+                                                          torch.cuda.current_stream().cuda_stream), "allreduce_bucket_ready")
+
+    def wait(self):
+        self._lib.check(self.L.etp_allreduce_wait(self.handle, torch.cuda.current_stream().cuda_stream), "allreduce_wait")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.etp_allreduce_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GradReducer:
-    def __init__(self, flat_grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], comm_dtype=torch.bfloat16,
-                 sparse_rows: Optional[Tuple[int, int, int]] = None, group=None):
+    def __init__(self, flat_grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], comm_dtype=torch.float32,
+                 sparse_rows: Optional[Tuple[int, int, int]] = None, group=None, native: Optional[bool] = None):
         """ranges: element ranges [start, end) of the dense buckets, in the order they become ready.
-        sparse_rows: (offset, n_rows, row_len) of a row-sparse table excluded from the dense ranges."""
+        sparse_rows: (offset, n_rows, row_len) of a row-sparse table excluded from the dense ranges.
+        native: use the library's communicator for the dense buckets (default: when the gradients are on a GPU, the group's
+        backend is nccl/RCCL and ETP_DP_NATIVE != 0); False = torch.distributed collectives."""
         self.g = flat_grads
         self.ranges = list(ranges)
         self.comm_dtype = comm_dtype
         self.sparse = sparse_rows
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._bufs = [torch.empty(e - s, dtype=comm_dtype, device=flat_grads.device) if comm_dtype != torch.float32 else None
+        self.native = None
+        if native is None:
+            native = (flat_grads.is_cuda and dist.is_initialized() and dist.get_backend(group) == "nccl"
+                      and os.environ.get("ETP_DP_NATIVE", "1") != "0")
+        if native and self.world > 1:
+            try:
+                self.native = NativeComm(flat_grads.device, comm_dtype, max((e - s) for s, e in self.ranges), group)
+            except Exception as e:                       # keep training alive: the torch.distributed path is equivalent
+                warnings.warn(f"etp_allreduce_* unavailable ({e}); using torch.distributed collectives")
+                self.native = None
+        need_buf = comm_dtype != torch.float32 and self.native is None
+        self._bufs = [torch.empty(e - s, dtype=comm_dtype, device=flat_grads.device) if need_buf else None
                       for s, e in self.ranges]
         self._pending: List = []
 
@@ -43,6 +103,9 @@ class GradReducer:
         if self.world == 1:
             return
         s, e = self.ranges[i]
+        if self.native is not None:
+            self.native.bucket_ready(self.g, s, e)
+            return
         view = self.g[s:e]
         if self.comm_dtype == torch.float32:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
@@ -55,32 +118,29 @@ class GradReducer:
 
     def reduce_sparse_rows(self, row_ids: torch.Tensor):
         """Row-sparse exchange for the word-embedding gradient: row_ids = this rank's touched rows (any order, may
-        repeat).  Result: table gradient = mean over ranks, as the dense all-reduce would give."""
+        repeat); its length (B*L) must be the same on every rank.  Result: table gradient = mean over ranks, as the
+        dense all-reduce would give.  No host synchronisation: every shape is fixed by len(row_ids)."""
         if self.world == 1 or self.sparse is None:
             return
         off, n_rows, row_len = self.sparse
         table = self.g[off:off + n_rows * row_len].view(n_rows, row_len)
-        ids = torch.unique(row_ids.reshape(-1))
-        # fixed-size exchange: pad to the max count over ranks (B*L is equal across ranks for synthetic batches)
-        cnt = torch.tensor([ids.numel()], device=ids.device, dtype=torch.long)
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        dist.all_gather(cnts, cnt, group=self.group)
-        m = int(max(c.item() for c in cnts))
-        pad_ids = torch.zeros(m, dtype=torch.long, device=ids.device); pad_ids[:ids.numel()] = ids
-        rows = torch.zeros(m, row_len, dtype=self.comm_dtype, device=ids.device)
-        rows[:ids.numel()] = table[ids].to(self.comm_dtype)
-        all_ids = [torch.empty_like(pad_ids) for _ in range(self.world)]
+        ids, _ = torch.sort(row_ids.reshape(-1).to(torch.long))
+        first = torch.ones_like(ids, dtype=torch.bool)
+        first[1:] = ids[1:] != ids[:-1]                                   # a repeated id contributes its row once
+        rows = (table.index_select(0, ids) * first[:, None]).to(self.comm_dtype)
+        all_ids = [torch.empty_like(ids) for _ in range(self.world)]
         all_rows = [torch.empty_like(rows) for _ in range(self.world)]
-        dist.all_gather(all_ids, pad_ids, group=self.group)
+        dist.all_gather(all_ids, ids, group=self.group)
         dist.all_gather(all_rows, rows, group=self.group)
-        table[ids] = 0
-        for r in range(self.world):
-            k = int(cnts[r].item())
-            table.index_add_(0, all_ids[r][:k], all_rows[r][:k].float())
-        table.mul_(1.0 / self.world)
+        table.index_fill_(0, ids, 0.0)                                    # own rows come back inside the gathered block
+        inv = 1.0 / self.world
+        table.index_add_(0, torch.cat(all_ids), torch.cat(all_rows).float() * inv)
 
     def finish(self):
-        """Wait for the outstanding buckets and write the means back into the fp32 arena."""
+        """Wait for the outstanding buckets (the consumer = torch's current stream) and, on the torch.distributed path,
+        write the means back into the fp32 arena."""
+        if self.native is not None:
+            self.native.wait()
         for h, buf, view in self._pending:
             if h is not None:
                 h.wait()
@@ -94,6 +154,11 @@ class GradReducer:
             else:
                 torch.mul(buf, 1.0 / self.world, out=view)
         self._pending.clear()
+
+    def close(self):
+        if self.native is not None:
+            self.native.close()
+            self.native = None
 
 
 def planner_buckets_layered(model, text_groups: int = 3):

@@ -36,26 +36,53 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.hf_style, self.correct_bias = bool(hf_style), bool(correct_bias)
         self.max_grad_norm, self.check_finite = float(max_grad_norm), bool(check_finite)
-        self.step_count = 0
+        self._step_host = 0
         dev = eng.device
+        # with the non-finite check the number of APPLIED steps is only known on the device (a skipped step must not advance
+        # it: GradScaler.step() does not call optimizer.step() on overflow)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if self.check_finite else None
         self.exp_avg = torch.zeros_like(eng.params)
         self.exp_avg_sq = torch.zeros_like(eng.params)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.decay_mask = None
+        self.no_decay_names = []        # parameters excluded from weight decay (checkpoint validation)
         if any(not p.requires_grad for p in model.parameters()):
             raise NotImplementedError("FusedAdamW updates the whole arena; frozen parameters (fix_lang_embedding / "
                                       "fix_pano_embedding) need torch.optim.AdamW over model.parameters()")
         if no_decay is not None:
-            # one byte per 64 elements; every parameter starts on a 64-element boundary of the arena
-            mask = torch.ones((eng.total + 63) // 64, dtype=torch.uint8)
-            for name, shape, off in eng.table:
+            self.set_no_decay_names([name for name, _, _ in eng.table if no_decay(name)])
+
+    def set_no_decay_names(self, names):
+        """Exclude exactly these parameters from weight decay (one mask byte per 64 elements; every parameter starts on a
+        64-element boundary of the arena).  An empty list = every parameter decays (no mask)."""
+        eng = self.eng
+        names = set(names)
+        self.no_decay_names = [name for name, _, _ in eng.table if name in names]
+        if not self.no_decay_names:
+            self.decay_mask = None
+            return
+        mask = torch.ones((eng.total + 63) // 64, dtype=torch.uint8)
+        for name, shape, off in eng.table:
+            if name in names:
                 n = 1
                 for s in shape:
                     n *= s
-                if no_decay(name):
-                    mask[off // 64:(off + n + 63) // 64] = 0
-            self.decay_mask = mask.to(dev)
+                mask[off // 64:(off + n + 63) // 64] = 0
+        self.decay_mask = mask.to(eng.device)
+
+    @property
+    def step_count(self) -> int:
+        """Number of applied updates (reads the device counter -- one host sync -- when check_finite is on)."""
+        if self.step_dev is not None:
+            return int(self.step_dev.item())
+        return self._step_host
+
+    @step_count.setter
+    def step_count(self, v: int):
+        self._step_host = int(v)
+        if self.step_dev is not None:
+            self.step_dev.fill_(int(v))
 
     @staticmethod
     def reference_no_decay(name: str) -> bool:
@@ -84,14 +111,18 @@ class FusedAdamW:
         if need_scan:
             self.sumsq.zero_(); self.nonfinite.zero_()
             check(eng.L.etp_grad_sqnorm(ptr(eng.grads), eng.total, ptr(self.sumsq), ptr(self.nonfinite), s), "grad_sqnorm")
-        self.step_count += 1
+        self._step_host += 1
         c = _lib.AdamwCfg(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
-                          step=self.step_count, hf_style=int(self.hf_style), correct_bias=int(self.correct_bias),
+                          step=self._step_host, hf_style=int(self.hf_style), correct_bias=int(self.correct_bias),
                           grad_scale=float(grad_scale), max_norm=self.max_grad_norm)
-        check(eng.L.etp_adamw_step(ptr(eng.params), ptr(eng.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(eng.shadow),
-                                   eng.n_matrix if eng.shadow is not None else 0, ptr(self.decay_mask), eng.total,
-                                   ctypes.byref(c), ptr(self.sumsq) if self.max_grad_norm > 0.0 else None,
-                                   ptr(self.nonfinite) if self.check_finite else None, int(zero_grads), s), "adamw_step")
+        args = (ptr(eng.params), ptr(eng.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(eng.shadow),
+                eng.n_matrix if eng.shadow is not None else 0, ptr(self.decay_mask), eng.total, ctypes.byref(c),
+                ptr(self.sumsq) if self.max_grad_norm > 0.0 else None, ptr(self.nonfinite) if self.check_finite else None,
+                int(zero_grads))
+        if self.step_dev is not None:
+            check(eng.L.etp_adamw_step_counted(*args, ptr(self.step_dev), s), "adamw_step_counted")
+        else:
+            check(eng.L.etp_adamw_step(*args, s), "adamw_step")
         eng.mark_shadow_current()      # the kernel rewrote the masters AND their bf16 shadow
         return self.nonfinite if self.check_finite else None
 
@@ -99,10 +130,14 @@ class FusedAdamW:
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "hyper": dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
-                              hf_style=self.hf_style, correct_bias=self.correct_bias, max_grad_norm=self.max_grad_norm)}
+                              hf_style=self.hf_style, correct_bias=self.correct_bias, max_grad_norm=self.max_grad_norm,
+                              check_finite=self.check_finite),
+                "no_decay": list(self.no_decay_names)}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for k, v in sd.get("hyper", {}).items():
             setattr(self, k, tuple(v) if k == "betas" else v)
+        if "no_decay" in sd:
+            self.set_no_decay_names(sd["no_decay"])

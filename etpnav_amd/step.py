@@ -52,12 +52,21 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
 
 class PlannerStep:
     def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True,
-                 dropout=None, drop_seed: int = 0, refresh_weights: bool = True, zero_grads: bool = True):
+                 dropout=None, drop_seed: int = 0, refresh_weights: bool = True, zero_grads: bool = True,
+                 grad_overwrite: Optional[bool] = None):
         """dropout: None (eval-mode step), "config" (the model config's rates, the reference's policy.train()), or a
         tuple (p_hidden, p_attn, p_head, p_env).  refresh_weights / zero_grads = False when etpnav_amd.optim.FusedAdamW
-        closes the step: its kernel already wrote the bf16 weight shadow and zeroed the gradient arena."""
+        closes the step: its kernel already wrote the bf16 weight shadow and zeroed the gradient arena.
+        grad_overwrite: weight-gradient GEMMs store instead of accumulating (etp_planner_set_grad_overwrite) and only the
+        vector/table tail of the gradient arena is zeroed per step.  Default: on when this step owns the zeroing (fresh
+        gradients every step) and every weight matrix is touched exactly once per step (not the pre-training variant, whose
+        language-side x-layer weights this step does not touch)."""
         self.model = model
         self.refresh_weights, self.zero_grads = refresh_weights, zero_grads
+        if grad_overwrite is None:
+            grad_overwrite = bool(zero_grads) and not model._engine.cconf.use_lang2visn and \
+                os.environ.get("ETP_GRAD_OVERWRITE", "1") != "0"
+        self.grad_overwrite = bool(grad_overwrite)
         if dropout == "config":
             c = model.config
             dropout = (float(getattr(c, "hidden_dropout_prob", 0.1)), float(getattr(c, "attention_probs_dropout_prob", 0.1)),
@@ -143,18 +152,20 @@ class PlannerStep:
         dt = _lib.ETP_F32          # node assembly works on the fp32 API tensors
         self.step_no += 1
         eng.set_dropout(self._drop_state())
+        check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
         # weight-shadow refresh and gradient zeroing ride on the stream that first needs them: the text cast on the main
         # stream, the panorama/navigation casts and the (bandwidth-bound) gradient memset on the panorama stream, whose
         # join below precedes forward_navigation and every backward kernel
         if self.refresh_weights:
             check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
-        check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
         check(L.etp_stream_after(s, s2), "fork")
         if self.refresh_weights:
             check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
             check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
         if backward and self.zero_grads:
-            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
+            # overwrite mode: the matrix region [0, n_matrix) is fully rewritten by this step's weight-gradient stores
+            lo = eng.n_matrix if self.grad_overwrite else 0
+            check(L.etp_memset_async(eng.grads.data_ptr() + lo * 4, 0, (eng.grads.numel() - lo) * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), self.Bp, V,
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
@@ -167,6 +178,7 @@ class PlannerStep:
         check(L.etp_sap_ce(ptr(self.logits), ptr(i["labels"]), ptr(self.loss), ptr(self.dlogits) if backward else None, B, G,
                            1.0 / B, -100, s), "sap_ce")
         if not backward:
+            check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
             return
         check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
@@ -182,6 +194,7 @@ class PlannerStep:
             check(L.etp_planner_join_aux(h, s), "join aux")      # callers of this mode read the non-text gradients next
         else:
             self._pano_pending = True
+        check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")     # the mode never leaks to other users of the planner
 
     def enqueue_txt_bwd(self, s: int, layer_lo: int = 0, layer_hi: Optional[int] = None):
         """Text-encoder backward (optionally only layers [layer_lo, layer_hi), descending calls share the running gradient)."""
@@ -189,8 +202,10 @@ class PlannerStep:
         if layer_hi is None:
             layer_hi = eng.cconf.n_l
         eng.set_dropout(self._drop_state())
+        check(L.etp_planner_set_grad_overwrite(eng.handle, int(self.grad_overwrite)), "set_grad_overwrite")
         check(L.etp_txt_bwd_range(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
                                   ptr(self.st_txt), ptr(self.ws_txt), layer_lo, layer_hi, s), "txt_bwd")
+        check(L.etp_planner_set_grad_overwrite(eng.handle, 0), "set_grad_overwrite")
         if layer_lo > 0:
             return
         if self._pano_pending:
@@ -241,6 +256,39 @@ class PlannerStep:
             self.graphs.append(self._capture_one(self.enqueue_txt_bwd))
         else:
             self.graphs.append(self._capture_one(lambda st: self.run_eager(stream=st, backward=backward)))
+        self.graph = self.graphs[0]
+        return self
+
+    def record(self, backward: bool = True, split_text_bwd: bool = False):
+        """Build the step's hipGraph EXPLICITLY (etp_rec_begin / etp_rec_end: one kernel node per launch, dependencies from
+        the per-stream order and the fork/join events) instead of by stream capture -- this keeps the full three-stream
+        schedule (capture() cannot: hipStreamEndCapture crashes with two side streams on ROCm 7.2) while the host issues a
+        single hipGraphLaunch per step.  Like capture(), a recorded graph replays the dropout masks it was built with."""
+        torch.cuda.synchronize()
+        self.run_eager(backward=backward)          # warm-up: kernel attributes, lazy allocations
+        torch.cuda.synchronize()
+        s = ctypes.c_void_p()
+        check(self.L.etp_stream_create(ctypes.byref(s)), "stream_create")
+        self.stream = s.value
+        self.graphs, self.graph_stats = [], []
+
+        def rec(fn):
+            check(self.L.etp_rec_begin(), "rec_begin")
+            try:
+                fn(self.stream)
+            except Exception:
+                self.L.etp_rec_abort()
+                raise
+            g, nk, ne = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+            check(self.L.etp_rec_end(ctypes.byref(g), ctypes.byref(nk), ctypes.byref(ne)), "rec_end")
+            self.graph_stats.append((int(nk.value), int(ne.value)))
+            return g.value
+
+        if backward and split_text_bwd:
+            self.graphs.append(rec(lambda st: self.enqueue_main(st, True)))
+            self.graphs.append(rec(self.enqueue_txt_bwd))
+        else:
+            self.graphs.append(rec(lambda st: self.run_eager(stream=st, backward=backward)))
         self.graph = self.graphs[0]
         return self
 

@@ -63,6 +63,10 @@ typedef struct etp_gemm_desc {
   int32_t out_mode;         /* 0 store, 1 C += v, 2 atomicAdd (fp32 C) */
 } etp_gemm_desc;
 int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream);
+/* n (<= 8) independent, unbatched, unsplit products of ONE (dtype, c_dtype, trans_a, trans_b) class in a single grid: the
+ * four to seven weight gradients of one transformer layer (autograd of vilmodel_cmt.py:108-110,151,178,190,326-328), none
+ * of which fills 256 CUs alone.  Every K must be a multiple of the 128-byte slab (64 bf16 / 32 fp32) and >= 2 slabs. */
+int etp_gemm_group(const etp_gemm_desc* d, int n, etp_stream_t stream);
 
 /* db[n] += sum_m dY[m,n]  (bias gradient of every nn.Linear). */
 int etp_colsum(int dtype, const void* dy, int64_t ld, float* db, int M, int N, etp_stream_t stream);
@@ -117,6 +121,13 @@ int etp_ln_stream_fwd(int dtype, const float* x, const float* gamma, const float
                       int H, float eps, etp_stream_t stream);
 int etp_ln_stream_bwd(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
                       float* dx, void* dx_lp, float* dgamma, float* dbeta, int M, int H, etp_stream_t stream);
+/* The same with the two-stage parameter-gradient reduction the planner uses: stage 1 (on `stream`) writes per-workgroup
+ * column sums to `part` (etp_ln_bwd_part_bytes(M, H) bytes), stage 2 (on `reduce_stream`, ordered after stage 1 by the
+ * caller when the streams differ) adds them into dgamma / dbeta. */
+int64_t etp_ln_bwd_part_bytes(int M, int H);
+int etp_ln_stream_bwd_stage1(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
+                             float* dx, void* dx_lp, float* dgamma, float* dbeta, float* part, int M, int H, etp_stream_t stream);
+int etp_ln_part_reduce(const float* part, int M, int H, float* dgamma, float* dbeta, etp_stream_t reduce_stream);
 
 /* BertEmbeddings.forward vilmodel_cmt.py:62-77 (eval): y = LN(word[id] + pos[l] + type[0]). */
 int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
@@ -154,7 +165,8 @@ int etp_sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float
                      float* dw2, float* db2, int M, int H, etp_stream_t stream);
 
 /* F.cross_entropy(reduction='sum', ignore_index) ss_trainer_ETP.py:892 scaled by `scale` (:1055):
- * *loss += scale*sum_b nll_b ; dlogits = scale*(softmax - onehot) (0 on ignored rows); dlogits may be NULL. */
+ * *loss = scale*sum_b nll_b (stored, not accumulated) ; dlogits = scale*(softmax - onehot) (0 on ignored rows); dlogits may
+ * be NULL. */
 int etp_sap_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B, int G, float scale,
                int64_t ignore_index, etp_stream_t stream);
 
@@ -192,6 +204,12 @@ typedef struct {
 int etp_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow, int64_t n_shadow,
                    const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
                    int zero_grads, etp_stream_t stream);
+/* The same with the optimizer's step count kept ON THE DEVICE: *step_counter is incremented only when the update is applied
+ * (skip == NULL or *skip == 0) and the bias corrections use it -- GradScaler.step() does not call optimizer.step() on
+ * overflow, so state['step'] must not advance on a skipped step (ss_trainer_ETP.py:504-506).  cfg->step is ignored. */
+int etp_adamw_step_counted(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow, int64_t n_shadow,
+                           const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
+                           int zero_grads, int32_t* step_counter, etp_stream_t stream);
 int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -236,6 +254,11 @@ int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
  * gradients; the gradients are complete in `stream` order only after a later joining call: etp_txt_bwd / etp_txt_bwd_range
  * / etp_nav_kv_bwd (always join) or etp_planner_join_aux.  Default 0: every backward entry point joins before it returns. */
 int etp_planner_set_lazy_join(etp_planner* p, int lazy);
+/* on = 1: weight-gradient products STORE into the matrix region [0, etp_planner_matrix_elems) of the gradient arena instead of
+ * accumulating (torch's `.grad +=`, the default): no fp32 read of the old gradient and no per-step zeroing of that region.
+ * Valid when every weight matrix receives exactly one weight-gradient product between two optimizer steps (one rollout step
+ * per optimizer step, as bench.py's unit of work); the vector / embedding-table tail still accumulates and must be zeroed. */
+int etp_planner_set_grad_overwrite(etp_planner* p, int on);
 int etp_planner_join_aux(etp_planner* p, etp_stream_t stream);
 /* Training-mode dropout (all rates 0 = eval, the default).  Masks are a counter-based hash of (seed, site, element index):
  * nothing is stored, the backward entry points recompute the masks, so a backward call must see the same rates and seed as
@@ -379,6 +402,33 @@ int etp_stream_sync(etp_stream_t s);
 int etp_stream_after(etp_stream_t from, etp_stream_t to);
 int etp_graph_begin(etp_stream_t s);
 int etp_graph_end(etp_stream_t s, etp_graph** out);
+/* ----------------------------------------------------------------------------------------------------
+ * Data-parallel gradient mean: replaces DistributedDataParallel(self.policy.net) of
+ * ss_trainer_ETP.py:208-212 / pretrain utils/misc.py:52-65 for the planner's flat gradient arena.  One communicator per
+ * process (one process per GPU); RCCL over xGMI, bound at run time.  A bucket is reduced IN PLACE as reduce-scatter (sum) ->
+ * 1/world scaling of the rank's own slice -> all-gather on a private communication stream ordered after `producer`.
+ * comm_dtype ETP_F32 (default, DDP's numerics) or ETP_BF16 (opt-in: half the xGMI bytes, bf16 sums; needs
+ * max_bucket_elems for the packed staging buffer).  Rank 0 creates the 128-byte id, the caller distributes it (any
+ * out-of-band channel, e.g. torch.distributed's store) and every rank calls etp_allreduce_init with it.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct etp_comm etp_comm;
+int etp_allreduce_unique_id(void* id_out_128_bytes);
+int etp_allreduce_init(etp_comm** out, const void* unique_id, int rank, int world, int comm_dtype, int64_t max_bucket_elems);
+int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_t producer);
+int etp_allreduce_wait(etp_comm* c, etp_stream_t consumer);
+int etp_allreduce_destroy(etp_comm* c);
+int etp_allreduce_rank(const etp_comm* c);
+int etp_allreduce_world(const etp_comm* c);
+etp_stream_t etp_allreduce_stream(const etp_comm* c);
+
+/* Explicit graph construction (replaces stream capture for the three-stream step: hipStreamEndCapture crashes on ROCm 7.2
+ * once two side streams joined a capture).  Between etp_rec_begin() and etp_rec_end() every entry point of this library
+ * that takes a stream is RECORDED as hipGraph kernel / memset nodes instead of being issued: per-stream order and the event
+ * edges of etp_stream_after / the planner's internal forks and joins become graph dependencies.  The result is launched,
+ * timed and destroyed like a captured graph.  One recording at a time; record from one host thread. */
+int etp_rec_begin(void);
+int etp_rec_end(etp_graph** out, int64_t* n_kernels, int64_t* n_edges);
+int etp_rec_abort(void);
 int etp_graph_launch(etp_graph* g, etp_stream_t s);
 int etp_graph_destroy(etp_graph* g);
 int etp_memset_async(void* p, int value, int64_t bytes, etp_stream_t s);
@@ -393,6 +443,12 @@ typedef struct etp_prof_entry {
   int64_t launches;
   double ms, flops, bytes;
 } etp_prof_entry;
+/* Per-launch HIP-event timing of EVERY kernel the library issues (measurement aid, tools/chain_budget.py): one text line per
+ * launch in launch order, "<us>\t<grid>\t<block>\t<stream>\t<kernel name>".  Events sit on the launch stream: issue the step on a
+ * single stream when each pair should bracket its kernel alone. */
+int etp_ktime_enable(int on);
+int etp_ktime_reset(void);
+int64_t etp_ktime_report(char* buf, int64_t cap);
 int etp_prof_enable(int on);
 int etp_prof_reset(void);
 int etp_prof_report(etp_prof_entry* out, int cap);

@@ -252,3 +252,36 @@ def test_bf16_weight_shadow_follows_torch_optimizer_after_device_move():
     out2 = m.forward_txt(ids, masks).detach()
     assert (out1 - out0.detach()).abs().max().item() > 1e-3       # the step changed the output ...
     assert torch.equal(out1, out2)                                # ... and no forced refresh was needed to see it
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_explicitly_recorded_three_stream_graph_replays_the_step(dtype):
+    """PlannerStep.record(): the whole three-stream step as ONE explicitly built hipGraph (kernel nodes + dependency edges
+    from the fork/join events) reproduces the eager step; replaying twice gives the same result (buffers are rewritten, not
+    accumulated); also the split form (text backward as its own graph, the data-parallel overlap schedule)."""
+    cfg = po.PlannerConfig.r2r(vocab_size=4096)
+    P = po.init_params(cfg, seed=11)
+    batch = po.make_batch(cfg, B=4, L=33, V=19, G=10, seed=99, ragged=True)
+    model = build_model(cfg, P, dtype)
+    rates = (0.1, 0.1, 0.1, 0.4)
+    step = PlannerStep(model, batch, dropout=rates, drop_seed=7)
+    step.run_eager(); torch.cuda.synchronize()
+    eager_loss, eager_grad = step.loss.item(), model.flat_grads.clone()
+    step.step_no = -1                                  # warm-up run = step 0, the recorded step = step 1 (same masks as above)
+    step.record()
+    assert step.graph_stats[0][0] > 100 and step.graph_stats[0][1] >= step.graph_stats[0][0] - 3
+    model.flat_grads.fill_(7.0)                        # poison: the graph must rewrite / re-zero everything it owns
+    step.replay(); step.replay()
+    step.sync()
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert abs(step.loss.item() - eager_loss) < 1e-5
+    assert (model.flat_grads - eager_grad).abs().max().item() < tol * max(1.0, eager_grad.abs().max().item())
+    step.close()
+    step = PlannerStep(model, batch, dropout=rates, drop_seed=7)
+    step.step_no = -1
+    step.record(split_text_bwd=True)
+    model.flat_grads.fill_(-3.0)
+    step.replay(part=0); step.replay(part=1)
+    step.sync()
+    assert (model.flat_grads - eager_grad).abs().max().item() < tol * max(1.0, eager_grad.abs().max().item())
+    step.close()

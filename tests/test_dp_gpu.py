@@ -1,0 +1,122 @@
+"""Data-parallel path on the GPU box (one MI355X):
+
+  * the library's own communicator (etp_allreduce_*, csrc/comm.hip) with world_size 1: RCCL is bound at run time, a bucket
+    goes through reduce-scatter -> scale -> all-gather in place (fp32) or pack -> collectives -> unpack (bf16 opt-in);
+  * two processes on the SAME device over gloo running the REAL planner step with the overlap schedule of bench.py
+    (non-text bucket reduced while the text backward runs in layer groups, row-sparse word-embedding exchange) — the
+    averaged gradient must equal the gradient of one process holding both half-batches (DDP's defining property,
+    ss_trainer_ETP.py:208-212,1055);
+  * the single-GPU pieces of the torch.distributed fallback: etp_cast_bf16_to_f32 with the 1/world scale.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from etpnav_amd import _lib, dp  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_cast_bf16_to_f32_with_scale():
+    torch.manual_seed(0)
+    src = torch.randn(100003, device="cuda").to(torch.bfloat16)
+    dst = torch.full((100003,), float("nan"), device="cuda")
+    _lib.check(_lib.lib().etp_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), 0.125,
+                                               torch.cuda.current_stream().cuda_stream), "cast")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src.float() * 0.125)
+
+
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_native_communicator_world1_in_place_mean(comm_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1)
+        n = 64 * 1000 + 37                                    # not a multiple of the slice granule: exercises the tail
+        g = torch.randn(n, device="cuda")
+        ref = g.clone()
+        comm = dp.NativeComm(g.device, comm_dtype, max_bucket_elems=n)
+        comm.bucket_ready(g, 128, n)                          # a sub-range, as the arena buckets are
+        comm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(g[:128], ref[:128])
+        if comm_dtype == torch.float32:
+            assert torch.equal(g[128:], ref[128:])            # mean over one rank, fp32 transport: bit-identical
+        else:
+            assert torch.equal(g[128:], ref[128:].to(torch.bfloat16).float())
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import planner_oracle as po      # input/weight generator only (checker side)
+        from etpnav_amd.planner import GlocalTextPathNavCMT
+        from etpnav_amd.step import PlannerStep
+        torch.cuda.set_device(0)
+        cfg = po.PlannerConfig.r2r(vocab_size=4096)
+        P = po.init_params(cfg, seed=3)
+        B = 6
+        full = po.make_batch(cfg, B=B, L=26, V=15, G=9, seed=50, ragged=False)
+        full["txt_ids"][0, 3] = full["txt_ids"][B - 1, 5]         # the same word on both ranks and twice on one rank
+        full["txt_ids"][0, 4] = full["txt_ids"][0, 3]
+        half = {k: v[rank * (B // 2):(rank + 1) * (B // 2)].clone() for k, v in full.items()}
+        model = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.float32, device="cuda:0")
+        model.load_state_dict(P, strict=True)
+        model.eval()
+        step = PlannerStep(model, half)
+        ranges, sparse, groups = dp.planner_buckets_layered(model, text_groups=3)
+        red = dp.GradReducer(model.flat_grads, ranges, comm_dtype=torch.float32, sparse_rows=sparse, native=False)
+        s = model._engine.stream()
+        step.enqueue_main(s, True, join_pano=True)
+        red.reduce_bucket(0)
+        for k, (lo, hi) in enumerate(groups):
+            step.enqueue_txt_bwd(s, lo, hi)
+            red.reduce_bucket(1 + k)
+        for i in range(1 + len(groups), len(red.ranges)):
+            red.reduce_bucket(i)
+        red.reduce_sparse_rows(step.inp["txt_ids"])
+        red.finish()
+        torch.cuda.synchronize()
+        mine = model.flat_grads.clone()
+        step.close()
+        ok, err = True, 0.0
+        if rank == 0:
+            model2 = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.float32, device="cuda:0")
+            model2.load_state_dict(P, strict=True)
+            model2.eval()
+            st2 = PlannerStep(model2, full)
+            st2.run_eager(); torch.cuda.synchronize()
+            ref = model2.flat_grads
+            err = (mine - ref).abs().max().item()
+            ok = err < 2e-5 + 1e-4 * ref.abs().max().item()
+            st2.close()
+        q.put((rank, ok, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_planner_step_mean_equals_full_batch_gradient():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, ok, err in res:
+        assert ok, f"rank {rank}: max err {err}"

@@ -267,7 +267,7 @@ def test_cross_entropy_and_gather():
     lr = logits.clone().requires_grad_(True)
     ref = torch.nn.functional.cross_entropy(lr, labels, reduction="sum", ignore_index=-100) / B
     ref.backward()
-    loss = torch.zeros(1, device=DEV); dl = torch.empty(B, G, device=DEV)
+    loss = torch.full((1,), 123.0, device=DEV); dl = torch.empty(B, G, device=DEV)     # the kernel STORES the loss
     check(L().etp_sap_ce(ptr(logits), ptr(labels), ptr(loss), ptr(dl), B, G, 1.0 / B, -100, stream()), "sap_ce")
     assert abs(loss.item() - ref.item()) < 1e-5
     assert (dl - lr.grad).abs().max().item() < 1e-6
@@ -297,3 +297,94 @@ def test_colsum_and_cast():
     y = torch.empty(100003, device=DEV, dtype=torch.bfloat16)
     check(L().etp_cast_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream()), "cast")
     assert torch.equal(y, x.to(torch.bfloat16))
+
+
+# ---- grouped GEMM (one grid for the weight gradients of a layer) and two-stage LayerNorm backward -------------------------
+def _desc(A, B, C, M, N, K, ta, tb, dtype, c_dtype, out_mode=0):
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(-2), B.stride(-2), C.stride(-2)
+    d.trans_a, d.trans_b, d.dtype, d.c_dtype = ta, tb, dtype, c_dtype
+    d.batch, d.batch_inner, d.ksplit, d.alpha, d.out_mode = 1, 1, 1, 1.0, out_mode
+    return d
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("tile", ["", "128s2", "128s3", "64s3", "64s4"])
+def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
+    """Seven TN products of different shapes / reduction lengths (an x-layer's weight gradients: token counts 512 and 2560,
+    ragged 200-wide output) in ONE grid == the same products one by one; store and accumulate modes; every tile class."""
+    monkeypatch.setenv("ETP_GROUP_TILE", tile)
+    torch.manual_seed(3)
+    t = tdt(dtype)
+    shapes = [(768, 768, 512), (1536, 768, 2560), (768, 768, 512), (2304, 768, 512), (200, 136, 512), (3072, 768, 512),
+              (768, 3072, 512)]            # (N_out, K_in, tokens)
+    descs, refs, outs = (GemmDesc * len(shapes))(), [], []
+    keep = []
+    for i, (n, k, m) in enumerate(shapes):
+        dY = (torch.randn(m, n, device=DEV) * 0.5).to(t)
+        X = (torch.randn(m, k, device=DEV) * 0.5 + 0.05).to(t)
+        W0 = torch.randn(n, k, device=DEV)
+        mode = i % 2                                   # alternate first-touch store / accumulate
+        ref = dY.float().t() @ X.float() + (W0 if mode == 1 else 0)
+        W = W0.clone()
+        descs[i] = _desc(dY, X, W, n, k, m, 1, 1, dtype, _lib.ETP_F32, out_mode=mode)
+        keep += [dY, X]
+        refs.append(ref); outs.append(W)
+    check(L().etp_gemm_group(descs, len(shapes), stream()), "etp_gemm_group")
+    torch.cuda.synchronize()
+    for (n, k, m), W, ref in zip(shapes, outs, refs):
+        err = (W - ref).abs().max().item()
+        assert err <= tol(dtype, math.sqrt(m) / 4), f"{(n, k, m)}: {err}"
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+def test_gemm_group_forward_products(dtype):
+    """NT class with bias epilogue (the text K/V projections of all x-layers in one launch)."""
+    torch.manual_seed(4)
+    t = tdt(dtype)
+    M, N, K = 640, 1536, 768
+    X = torch.randn(M, K, device=DEV).to(t)
+    descs = (GemmDesc * 4)()
+    Ws, Cs, bs = [], [], []
+    for i in range(4):
+        W = (torch.randn(N, K, device=DEV) * 0.05).to(t); b = torch.randn(N, device=DEV)
+        C = torch.empty(M, N, device=DEV, dtype=t)
+        d = _desc(X, W, C, M, N, K, 0, 0, dtype, dtype)
+        d.bias = b.data_ptr()
+        descs[i] = d
+        Ws.append(W); Cs.append(C); bs.append(b)
+    check(L().etp_gemm_group(descs, 4, stream()), "etp_gemm_group")
+    torch.cuda.synchronize()
+    for W, C, b in zip(Ws, Cs, bs):
+        ref = X.float() @ W.float().t() + b
+        assert (C.float() - ref).abs().max().item() <= tol(dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
+@pytest.mark.parametrize("M", [7, 512, 2560, 5000])
+def test_layer_norm_backward_two_stage(dtype, M):
+    """ln_bwd_s with per-workgroup slabs + ln_part_reduce == autograd of F.layer_norm (dx, dgamma, dbeta accumulate)."""
+    torch.manual_seed(M)
+    H = 768
+    x = torch.randn(M, H, device=DEV) * 2 + 0.3
+    gmm = torch.randn(H, device=DEV); bta = torch.randn(H, device=DEV)
+    dy = torch.randn(M, H, device=DEV)
+    add = torch.randn(M, H, device=DEV)
+    xr = x.clone().requires_grad_(True); gr = gmm.clone().requires_grad_(True); br = bta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-12)
+    y.backward(dy)
+    stats = torch.stack([x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-12)], 1).contiguous()
+    dx = torch.empty(M, H, device=DEV); dxt = torch.empty(M, H, device=DEV, dtype=tdt(dtype))
+    dg0 = torch.randn(H, device=DEV); db0 = torch.randn(H, device=DEV)
+    dg, db = dg0.clone(), db0.clone()
+    part = torch.empty(int(L().etp_ln_bwd_part_bytes(M, H)), dtype=torch.uint8, device=DEV)
+    check(L().etp_ln_stream_bwd_stage1(dtype, ptr(dy), ptr(x), ptr(stats), ptr(gmm), ptr(add), ptr(dx), ptr(dxt), ptr(dg), ptr(db),
+                                       ptr(part), M, H, stream()), "ln stage1")
+    check(L().etp_ln_part_reduce(ptr(part), M, H, ptr(dg), ptr(db), stream()), "ln stage2")
+    torch.cuda.synchronize()
+    assert (dx - (xr.grad + add)).abs().max().item() < 2e-4
+    assert (dxt.float() - (xr.grad + add)).abs().max().item() <= tol(dtype, 4)
+    assert (dg - dg0 - gr.grad).abs().max().item() < 2e-4 * math.sqrt(M)
+    assert (db - db0 - br.grad).abs().max().item() < 2e-4 * math.sqrt(M)

@@ -105,4 +105,19 @@ def test_fused_adamw_closes_the_planner_step():
         step.run_eager(); torch.cuda.synchronize()
         losses.append(step.loss.item())
     assert losses[2] < losses[0]                                              # it trains
+    # a skipped step (non-finite gradient) must not advance the step count that drives the bias correction --
+    # GradScaler.step() does not call optimizer.step() on overflow (ss_trainer_ETP.py:504-506)
+    assert opt.step_count == 2
+    good = eng.grads.detach().clone()
+    eng.grads[5] = float("inf")
+    before = eng.params.detach().clone()
+    bad = opt.step()
+    torch.cuda.synchronize()
+    assert bad.item() >= 1 and opt.step_count == 2 and torch.equal(eng.params, before)
+    eng.grads.copy_(good)
+    bad = opt.step()
+    torch.cuda.synchronize()
+    assert bad.item() == 0 and opt.step_count == 3
+    oo.adamw_step(p_ref, good.cpu(), m_ref, v_ref, 3, 1e-3, 0.9, 0.98, 1e-6, wd, True, True, 1.0, 5.0)    # t = 3, not 4
+    assert close(eng.params, p_ref)
     step.close()

@@ -49,7 +49,7 @@ def run(kind, M, N, K, dtype=_lib.ETP_BF16, iters=30, ksplit=1, batch=1):
     fl = 2.0 * M * N * K
     return us, fl / us / 1e6
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("GEMM_GROUP_ONLY"):
     shapes = [("fwd_s", 2560, 768, 768), ("fwd_s", 2560, 768, 3072), ("dgrad_s", 2560, 2304, 768), ("dgrad_s", 2560, 3072, 768),
               ("dgrad_s", 512, 3072, 768), ("fwd", 2560, 2304, 768), ("fwd", 2560, 768, 768), ("fwd", 2560, 3072, 768), ("fwd", 2560, 768, 3072),
               ("fwd", 1152, 2304, 768), ("fwd", 512, 768, 768), ("fwd", 512, 3072, 768),
@@ -74,3 +74,58 @@ if __name__ == "__main__":
                 row += f"{us:10.1f} {tf:7.1f} "
         print(row, flush=True)
 
+
+
+def run_group(tokens, shapes, tile, iters=20, nsets=4, store=True):
+    """One grouped TN launch (etp_gemm_group) over `shapes` = [(N_out, K_in)] with `tokens` rows; nsets rotating operand sets
+    keep the operands L2-cold (MALL-warm), like a real backward pass where every dY was just written by another kernel."""
+    os.environ["ETP_GROUP_TILE"] = tile
+    t = torch.bfloat16
+    sets = []
+    for _ in range(nsets):
+        descs = (GemmDesc * len(shapes))()
+        keep = []
+        for i, (n, k) in enumerate(shapes):
+            dY = torch.randn(tokens, n, device=dev).to(t); X = torch.randn(tokens, k, device=dev).to(t)
+            W = torch.zeros(n, k, device=dev)
+            d = GemmDesc()
+            d.A, d.B, d.C = dY.data_ptr(), X.data_ptr(), W.data_ptr()
+            d.M, d.N, d.K = n, k, tokens
+            d.lda, d.ldb, d.ldc = n, k, k
+            d.trans_a, d.trans_b, d.dtype, d.c_dtype = 1, 1, _lib.ETP_BF16, _lib.ETP_F32
+            d.batch, d.batch_inner, d.ksplit, d.alpha, d.out_mode = 1, 1, 1, 1.0, 0 if store else 1
+            descs[i] = d
+            keep += [dY, X, W]
+        sets.append((descs, keep))
+    s = torch.cuda.current_stream().cuda_stream
+    for descs, _ in sets: check(L.etp_gemm_group(descs, len(shapes), s))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        descs, _ = sets[i % nsets]
+        check(L.etp_gemm_group(descs, len(shapes), s))
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    fl = sum(2.0 * tokens * n * k for n, k in shapes)
+    return us, fl / us / 1e6
+
+
+def group_table():
+    layers = {"text layer (2560 tok)": (2560, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+              "pano layer (1152 tok)": (1152, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+              "x-layer node side (512 tok)": (512, [(768, 768), (768, 768), (2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+              "x-layer text K/V (2560 tok)": (2560, [(1536, 768)]),
+              "RxR text layer (8192 tok)": (8192, [(2304, 768), (768, 768), (3072, 768), (768, 3072)])}
+    tiles = ["128s2", "128s3", "64s3", "64s4"]
+    print(f"{'grouped weight gradients':34} " + " ".join(f"{t + ':us':>10} {'TF':>7}" for t in tiles))
+    for name, (tok, shapes) in layers.items():
+        row = f"{name:34} "
+        for tl in tiles:
+            us, tf = run_group(tok, shapes, tl)
+            row += f"{us:10.1f} {tf:7.1f} "
+        print(row, flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("GEMM_GROUP_TABLE"):
+    group_table()
