@@ -92,6 +92,8 @@ def cpu_baseline(w, cfg_kwargs, budget_s=20.0, train=True):
     dt = (time.time() - t0) / n
     scale = sb / w["B"]
     return {"value": scale / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "reference_module_timing": "profiles/r02_cpu_reference.json (the real vilmodel_cmt.py timed in the build container; "
+                                       "/root/reference does not exist on the GPU box, so this leg times the oracle port)",
             "sample": f"{n} timed fwd+bwd steps of {sb} of the {w['B']} episodes per step (same L/V/G), rate scaled by "
                       f"{sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py, {'train mode: dropout on' if train else 'eval mode'}), "
                       f"{cores} threads of {avail} available"}
@@ -100,8 +102,8 @@ def cpu_baseline(w, cfg_kwargs, budget_s=20.0, train=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", action="store_true",
@@ -251,13 +253,14 @@ def main():
                                 "same step after the timed region, so the pairs bracket the kernel alone)"}
             # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
             # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on the weight-shadow cast: tools/pmc_traffic.py)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
             if args.workload == "c2" and args.dtype == "bf16" and os.path.exists(pmc):
                 try:
                     ent = json.load(open(pmc))["kernels"].get(d["kernel"])
                     if ent and ent.get("hbm_bytes_per_launch"):
                         roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
-                        roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                        roofline["traffic_source"] = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                      "this command, committed -- NOT re-measured in this run")
                 except (ValueError, KeyError):
                     pass
 
@@ -285,6 +288,17 @@ def main():
                      "note": "not part of `value`; replaces torch AdamW + the next step's weight cast and gradient memset"}
     if rank == 0:
         fl = flops_per_step(w, cfg)
+        # whole-step roofline: t_roof = sum over the step's kernels of max(flops/peak_mfma, bytes/peak_hbm),
+        # algorithmic work from the tensor shapes (etpnav_amd/roofline.py); achieved = t_roof / measured step time
+        from etpnav_amd.roofline import step_roofline
+        sr = step_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
+                           peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
+        step_roof = {"t_roof_ms": round(sr["t_roof_ms"], 4), "measured_ms": round(ms_per_step, 4),
+                     "frac": round(sr["t_roof_ms"] / ms_per_step, 4), "alg_flops": sr["flops"], "alg_hbm_bytes": sr["hbm_bytes"],
+                     "mfma_bound_ms": round(sr["t_mfma_bound_ms"], 4), "hbm_bound_ms": round(sr["t_hbm_bound_ms"], 4),
+                     "peaks": {"bf16_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
+                     "note": "t_roof = sum_k max(flops_k/peak_mfma, bytes_k/peak_hbm) over the step's fused kernels, one read of "
+                             "every input and one write of every output per kernel (etpnav_amd/roofline.py)"}
         out = {
             "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
             "value": round(args.steps / elapsed * world, 3),
@@ -305,6 +319,7 @@ def main():
             "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
             "model_flops_per_step": fl,
             "roofline": roofline,
+            "roofline_step": step_roof,
             "optimizer": optimizer,
             "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
         }

@@ -61,6 +61,9 @@ struct etp_planner {
   uint64_t drop_seed = 0;
   // optional second stream: weight-gradient GEMMs (leaves of the backward graph) run beside the dgrad chain
   hipStream_t aux = nullptr;
+  // optional third stream: the d(txt_embeds) contributions of the x-layers' text K/V projections (M = B*L rows, the largest
+  // GEMMs of the navigation backward) form a serial accumulate chain of their own that nothing on the node chain reads
+  hipStream_t aux2 = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   hipEvent_t next_event() {
@@ -254,6 +257,7 @@ struct Ctx {
   etp_planner* pl; hipStream_t st; int dt; size_t es;  // element size of T
   int H, I, nh;
   hipStream_t sw;                                      // stream of the weight-gradient launches (== st when no aux stream)
+  hipStream_t s3;                                      // stream of the d_txt accumulate chain (== st when no aux2 stream)
   // Deferred side-stream launches: leaves (weight gradients, the d_txt contribution) are collected and forked once per
   // layer by flush_side() instead of once per GEMM -- a quarter of the event-record marker packets in the main queue
   // and of the host calls.  (Under rocprofv3 the kernel behind each marker started ~13 us late, tools/timeline.py;
@@ -277,6 +281,7 @@ static Ctx make_ctx(etp_planner* pl, etp_stream_t s) {
   Ctx c;
   c.pl = pl; c.st = reinterpret_cast<hipStream_t>(s); c.dt = pl->cfg.dtype; c.es = dtype_size(c.dt);
   c.sw = (pl->aux != nullptr && pl->aux != c.st) ? pl->aux : c.st;
+  c.s3 = (pl->aux2 != nullptr && pl->aux2 != c.st) ? pl->aux2 : c.st;
   c.H = pl->cfg.hidden; c.I = pl->cfg.inter; c.nh = pl->cfg.heads;
   c.pend = nullptr;
   c.wq = nullptr;
@@ -679,6 +684,11 @@ int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads) 
 int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux) {
   ETP_REQUIRE(p, "null planner");
   p->aux = reinterpret_cast<hipStream_t>(aux);
+  return ETP_OK;
+}
+int etp_planner_set_aux2_stream(etp_planner* p, etp_stream_t aux2) {
+  ETP_REQUIRE(p, "null planner");
+  p->aux2 = reinterpret_cast<hipStream_t>(aux2);
   return ETP_OK;
 }
 int etp_planner_set_lazy_join(etp_planner* p, int lazy) {
@@ -1320,12 +1330,18 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, l == 0 ? d_img : g, Mg, H, H, w.t1.f));
     if (cached) { ETP_TRY(flush_side(c)); continue; }
     ETP_TRY(linear_wgrad(c, xc.dkv, 2 * H, txtT, H, q.kv_w, q.kv_b, Mt, 2 * H, H));
-    // d_txt (consumed by the text backward right after this entry point) stays on the main stream: on the side stream it
-    // would queue behind this entry point's weight gradients and the text backward would wait for all of them
-    ETP_TRY(linear_dgrad_s(c, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
+    // d_txt (consumed by the text backward right after this entry point) must not queue behind this entry point's weight
+    // gradients on the weight-gradient stream; with a dedicated stream its serial accumulate chain leaves the node chain
+    // (joined back at the end of this entry point), without one it stays on the main stream
+    {
+      Ctx c3 = c;
+      if (c.s3 != c.st) { ETP_TRY(stream_after(p, c.st, c.s3)); c3.st = c.s3; }
+      ETP_TRY(linear_dgrad_s(c3, xc.dkv, 2 * H, q.kv_w, d_txt, Mt, 2 * H, H, nullptr, l == cf.n_x - 1 ? 0 : 1));
+    }
     ETP_TRY(flush_side(c));          // this layer's weight gradients: one fork
   }
   if (cf.n_x == 0) ETP_TRY(copy_f32(g, d_img, (long)Mg * H, c.st));
+  if (!cached && c.s3 != c.st) ETP_TRY(stream_after(p, c.s3, c.st));      // d_txt complete in `stream` order
   ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));

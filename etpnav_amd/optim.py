@@ -141,3 +141,31 @@ class FusedAdamW:
             setattr(self, k, tuple(v) if k == "betas" else v)
         if "no_decay" in sd:
             self.set_no_decay_names(sd["no_decay"])
+
+
+# ---- learning-rate schedule of the pre-training loop (pretrain_src/pretrain_src/optim/sched.py:17-30) -------------------
+def warmup_linear(step: int, warmup_step: int, tot_step: int) -> float:
+    """BERT schedule (sched.py:17-21): linear warm-up to 1 over `warmup_step`, then linear decay to 0 at `tot_step`."""
+    if step < warmup_step:
+        return step / warmup_step
+    return max(0, (tot_step - step) / (tot_step - warmup_step))
+
+
+def get_lr_sched(global_step: int, learning_rate: float, warmup_steps: int, num_train_steps: int) -> float:
+    """sched.py:24-30 with the option fields spelled out: never returns a non-positive rate (floor 1e-8)."""
+    lr = learning_rate * warmup_linear(global_step, warmup_steps, num_train_steps)
+    return 1e-8 if lr <= 0 else lr
+
+
+class WarmupLinearLR:
+    """Drives ``FusedAdamW.lr`` the way train_r2r.py sets ``param_group['lr']`` before every optimizer step
+    (pretrain_src/pretrain_src/train_r2r.py: lr_this_step = get_lr_sched(global_step, opts)).  The rate is a kernel argument
+    of the fused step (no device state), so changing it costs nothing."""
+
+    def __init__(self, optimizer, learning_rate: float, warmup_steps: int, num_train_steps: int):
+        self.opt, self.base, self.warmup, self.total = optimizer, float(learning_rate), int(warmup_steps), int(num_train_steps)
+
+    def step(self, global_step: int) -> float:
+        lr = get_lr_sched(global_step, self.base, self.warmup, self.total)
+        self.opt.lr = lr
+        return lr

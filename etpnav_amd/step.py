@@ -132,7 +132,13 @@ class PlannerStep:
             b2 = ctypes.c_void_p()
             check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
             self.s2 = b2.value
+        self.aux2 = None
+        if self.aux is not None and os.environ.get("ETP_DTXT_STREAM", "1") != "0":
+            a2 = ctypes.c_void_p()
+            check(self.L.etp_stream_create(ctypes.byref(a2)), "stream_create")
+            self.aux2 = a2.value
         check(self.L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
+        check(self.L.etp_planner_set_aux2_stream(h, self.aux2), "set_aux2_stream")
         # navigation / panorama weight gradients keep running on the aux stream while the text backward starts; the text
         # backward's own join (or the explicit one in enqueue_main) completes them
         check(self.L.etp_planner_set_lazy_join(h, 1 if self.aux is not None else 0), "set_lazy_join")
@@ -319,7 +325,8 @@ class PlannerStep:
             self.L.etp_stream_destroy(self.stream); self.stream = None
         self.L.etp_planner_set_lazy_join(self.eng.handle, 0)
         self.L.etp_planner_set_aux_stream(self.eng.handle, None)
-        for st in (self.aux, self.s2):
+        self.L.etp_planner_set_aux2_stream(self.eng.handle, None)
+        for st in (self.aux, self.s2, getattr(self, "aux2", None)):
             if st is not None:
                 self.L.etp_stream_destroy(st)
-        self.aux = self.s2 = None
+        self.aux = self.s2 = self.aux2 = None

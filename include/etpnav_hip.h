@@ -249,6 +249,9 @@ int etp_planner_bind(etp_planner* p, float* params, void* shadow, float* grads);
  * on `aux` after their dY producer and joined back before the call returns to `stream`, so they overlap the dgrad
  * chain (works eagerly and under hipGraph capture: the fork/join become graph edges).  NULL = single stream. */
 int etp_planner_set_aux_stream(etp_planner* p, etp_stream_t aux);
+/* Optional third stream for etp_nav_bwd: the d(txt_embeds) contributions of the text K/V projections (vilmodel_cmt.py:326-328,
+ * M = B*L rows) accumulate on `aux2` beside the node chain and are joined back before the call returns.  NULL = main stream. */
+int etp_planner_set_aux2_stream(etp_planner* p, etp_stream_t aux2);
 /* With an aux stream: lazy = 1 lets etp_nav_bwd* / etp_pano_bwd return WITHOUT joining their weight-gradient GEMMs back
  * (nothing downstream of them reads weight gradients), so the text backward does not wait for the navigation weight
  * gradients; the gradients are complete in `stream` order only after a later joining call: etp_txt_bwd / etp_txt_bwd_range

@@ -1,0 +1,79 @@
+"""SURVEY.md §8f N4 remainders on the CPU: the view-feature store (dataset.py:375-388) and the warm-up-linear learning-rate
+schedule (optim/sched.py:17-30)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from etpnav_amd import features as ft
+from etpnav_amd.optim import warmup_linear, get_lr_sched, WarmupLinearLR
+
+REF_SCHED = "/root/reference/pretrain_src/pretrain_src/optim/sched.py"
+
+
+def _store(tmp_path, n=7, V=36, Fi=16, Fd=8, suffix=".etpf"):
+    rng = np.random.default_rng(0)
+    keys = [f"scan{i % 3}_vp{i:03d}" for i in range(n)]
+    img = {k: rng.standard_normal((V, Fi)).astype(np.float32) for k in keys}
+    dep = {k: rng.standard_normal((V, Fd)).astype(np.float32) for k in reversed(keys)}      # different key order on purpose
+    pi, pd = str(tmp_path / ("img" + suffix)), str(tmp_path / ("dep" + suffix))
+    ft.write_flat_pack(pi, img.items()); ft.write_flat_pack(pd, dep.items())
+    return keys, img, dep, pi, pd
+
+
+def test_flat_pack_feature_store_reads_caches_and_gathers(tmp_path):
+    keys, img, dep, pi, pd = _store(tmp_path)
+    fs = ft.FeatureStore(pi, pd, in_memory=True)
+    scan, vp = keys[4].split("_")
+    a, d = fs.get_scanvp_feature(scan, vp)
+    assert a.dtype == np.float32 and a.shape == (36, 16) and d.shape == (36, 8)
+    assert np.array_equal(a, img[keys[4]]) and np.array_equal(d, dep[keys[4]])
+    assert fs.get_scanvp_feature(scan, vp)[0] is a                       # in-memory cache hit (dataset.py:377-379)
+    nc = ft.FeatureStore(pi, pd, in_memory=False)
+    assert nc.get_scanvp_feature(scan, vp)[0] is not nc.get_scanvp_feature(scan, vp)[0]
+    fs.to_device("cpu")
+    want = [tuple(k.split("_")) for k in (keys[5], keys[0], keys[5])]
+    r, dd = fs.gather(want)
+    assert torch.equal(r[0], torch.from_numpy(img[keys[5]])) and torch.equal(r[1], torch.from_numpy(img[keys[0]]))
+    assert torch.equal(dd[2], torch.from_numpy(dep[keys[5]]))           # depth rows follow the RGB key order
+    with pytest.raises(KeyError):
+        fs.get_scanvp_feature("nope", "x")
+    with pytest.raises(ValueError):
+        ft.write_flat_pack(str(tmp_path / "bad.etpf"), [("a", np.zeros((3, 4))), ("b", np.zeros((3, 5)))])
+
+
+def test_hdf5_backend_is_gated_on_h5py(tmp_path):
+    p = tmp_path / "img.hdf5"
+    p.write_bytes(b"\x89HDF\r\n\x1a\n")
+    if importlib.util.find_spec("h5py") is None:
+        with pytest.raises(ImportError, match="h5py"):
+            ft.FeatureStore(str(p))
+    else:                                                    # where h5py exists: round trip through a real file
+        import h5py
+        with h5py.File(str(p), "w") as f:
+            f["s_v"] = np.arange(36 * 4, dtype=np.float32).reshape(36, 4)
+        fs = ft.FeatureStore(str(p), None)
+        assert fs.get_scanvp_feature("s", "v")[0][1, 2] == 6.0
+
+
+def test_warmup_linear_schedule_matches_the_reference_function():
+    cases = [(0, 100, 1000), (50, 100, 1000), (100, 100, 1000), (550, 100, 1000), (1000, 100, 1000), (1200, 100, 1000)]
+    want = [0.0, 0.5, 1.0, 0.5, 0.0, 0.0]
+    for (s, w, t), v in zip(cases, want):
+        assert warmup_linear(s, w, t) == pytest.approx(v)
+    assert get_lr_sched(0, 5e-5, 100, 1000) == 1e-8 and get_lr_sched(1000, 5e-5, 100, 1000) == 1e-8      # floor (sched.py:28-29)
+    assert get_lr_sched(50, 5e-5, 100, 1000) == pytest.approx(2.5e-5)
+    if os.path.exists(REF_SCHED):
+        spec = importlib.util.spec_from_file_location("ref_sched", REF_SCHED)
+        ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+        class O: learning_rate = 5e-5; warmup_steps = 100; num_train_steps = 1000
+        for s in range(0, 1300, 37):
+            assert get_lr_sched(s, 5e-5, 100, 1000) == ref.get_lr_sched(s, O)
+            assert warmup_linear(s, 100, 1000) == ref.warmup_linear(s, 100, 1000)
+
+    class Opt: lr = 0.0
+    o = Opt()
+    sch = WarmupLinearLR(o, 5e-5, 100, 1000)
+    assert sch.step(50) == pytest.approx(2.5e-5) and o.lr == pytest.approx(2.5e-5)
