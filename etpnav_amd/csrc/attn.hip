@@ -441,6 +441,336 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
   }
 }
 
+// =========================================================================================================
+// Streaming ("flash") attention for long key axes (RxR: 512-token instructions, BASELINE.json configs[3];
+// vilmodel_cmt.py:117-137 at L = 512, :335-348 with 512 text keys).  bf16, head dim 64, additive / -inf key masks.
+//   forward   one workgroup per (batch, head, 64 queries): K/V tiles of 128 keys stream through LDS, online softmax
+//             (running row max m and sum l in registers, O rescaled when m grows), dropout by the same counter hash; the
+//             probabilities are never written: only lse = m + log l per row (fp32, in the front of the P buffer).
+//   backward  P is RECOMPUTED from Q, K and lse (MFMA work is cheap here, HBM traffic is not):
+//             flash_bwd_dq   per (batch, head, 64 queries), loops over key tiles:  D = rowsum(dO*O),  dS = P*(dP*mask - D),
+//                            dQ = alpha dS K;  publishes D next to lse
+//             flash_bwd_dkv  per (batch, head, 128 keys), loops over query tiles:  dV = (P*mask)^T dO,  dK = alpha dS^T Q
+// Replaces, for Lq or Lk > 128, the batched-GEMM path (scores, probabilities and their gradients through HBM: ~0.9 GB per
+// layer backward at B = 16, L = 512) with three kernels whose HBM traffic is Q, K, V, O, dO in and ctx / dQ, dK, dV out.
+// =========================================================================================================
+constexpr int FBQ = 64, FBKV = 128;
+struct FlashLds {
+  static constexpr int PQ = Nat<bf16_t, 64>::PITCH, PP = Nat<bf16_t, FBKV>::PITCH;
+  static constexpr int Q_OFF = 0, DO_OFF = FBQ * PQ, K_OFF = 2 * FBQ * PQ, V_OFF = K_OFF + FBKV * PQ, T_OFF = V_OFF + FBKV * PQ;
+  static constexpr int RS_OFF = T_OFF + FBQ * PP;              // row max / row sum exchange [2][2][FBQ] fp32 (also D)
+  static constexpr int TOTAL = RS_OFF + 4 * FBQ * 4;
+  static_assert(FBKV * 68 * 4 <= V_OFF, "dK/dV fp32 staging [128][68] sits over the Q, dO and K tiles");
+  static_assert(FBQ * 68 * 4 <= T_OFF - K_OFF, "ctx/dQ fp32 staging [64][68] sits over the K and V tiles");
+};
+
+// additive key term of this lane's NT columns of the key tile starting at k0 (columns >= Lk: excluded)
+template <int NT>
+__device__ __forceinline__ void key_terms(float (&kadd)[NT], const uint8_t* km, int k0, int Lk, int mask_mode, int wc, int i) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = k0 + wc * (FBKV / 2) + n * 16 + i;
+    float v = 0.f;
+    if (col >= Lk) v = -INFINITY;
+    else if (km && !km[col]) v = mask_mode ? -INFINITY : -10000.0f;
+    kadd[n] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const AttnKArgs a) {
+  using T = bf16_t;
+  using L = FlashLds;
+  constexpr int PQ = L::PQ, PP = L::PP, MT = FBQ / 32, NT = FBKV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *qt = smem + L::Q_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *pt = smem + L::T_OFF;
+  float* rmax = reinterpret_cast<float*>(smem + L::RS_OFF);
+  float* rsum = rmax + 2 * FBQ;
+  float* ct = reinterpret_cast<float*>(smem + L::K_OFF);          // output staging over the K/V tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x / a.nq, q0 = (blockIdx.x % a.nq) * FBQ;
+  const int b = bh / a.nh, h = bh % a.nh;
+  const int Lq = min(FBQ, a.Lq - q0);
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + ((long)b * a.Lq + q0) * a.ldq + h * 64;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + (long)b * a.Lk * a.ldv + h * 64;
+  T* Cg = reinterpret_cast<T*>(a.ctx) + ((long)b * a.Lq + q0) * a.ldc + h * 64;
+  float* lse = reinterpret_cast<float*>(a.P) + (long)bh * a.Lq + q0;
+  const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
+
+  nat_load<T, FBQ, 64>(qt, Qg, a.ldq, Lq, 64, tid);
+  float m_run[MT][4], l_run[MT][4];
+  f32x4_t oc[MT][2];
+  acc_zero(oc);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[m][r] = -INFINITY; l_run[m][r] = 0.f; }
+
+  for (int k0 = 0; k0 < a.Lk; k0 += FBKV) {
+    const int nk = min(FBKV, a.Lk - k0);
+    __syncthreads();                                   // the previous tile's P.V is done with vt / pt
+    nat_load<T, FBKV, 64>(kt, Kg + (long)k0 * a.ldk, a.ldk, nk, 64, tid);
+    nat_load<T, FBKV, 64>(vt, Vg + (long)k0 * a.ldv, a.ldv, nk, 64, tid);
+    float kadd[NT];
+    key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+    __syncthreads();
+    f32x4_t sc[MT][NT];
+    acc_zero(sc);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (FBKV / 2), lane);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float v = sc[m][n][r] * a.alpha + kadd[n];
+          sc[m][n][r] = v;
+          mx = fmaxf(mx, v);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (i == 0) rmax[wc * FBQ + wr * (FBQ / 2) + m * 16 + g * 4 + r] = mx;
+      }
+    __syncthreads();
+    float scale_o[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+        const float m_new = fmaxf(m_run[m][r], fmaxf(rmax[row], rmax[FBQ + row]));
+        const float mref = (m_new == -INFINITY) ? 0.f : m_new;      // a fully excluded prefix: exp(-inf - 0) = 0, no NaN
+        scale_o[m][r] = __expf(m_run[m][r] - mref);
+        m_run[m][r] = m_new;
+        float sum = 0.f;
+        const uint32_t rbase = ((uint32_t)bh * a.Lq + q0 + row) * (uint32_t)a.Lk + (uint32_t)k0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = wc * (FBKV / 2) + n * 16 + i;
+          const float e = __expf(sc[m][n][r] - mref);
+          sum += e;
+          float pd = e;
+          if (a.drop.p > 0.f) pd *= drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep);
+          Elem<T>::st(reinterpret_cast<T*>(pt + row * PP) + col, pd);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        if (i == 0) rsum[wc * FBQ + row] = sum;
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oc[m][c][r] *= scale_o[m][r];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+        l_run[m][r] = l_run[m][r] * scale_o[m][r] + rsum[row] + rsum[FBQ + row];
+      }
+    tile_mma<T, MT, 2, FBKV / 32, false, true, PP, PQ>(oc, pt, wr * (FBQ / 2), vt, wc * 32, lane);
+  }
+  __syncthreads();                                     // K/V tiles dead -> fp32 output staging
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+      const float inv = l_run[m][r] > 0.f ? 1.0f / l_run[m][r] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) oc[m][c][r] *= inv;
+      if (wc == 0 && i == 0 && row < Lq) lse[row] = m_run[m][r] + __logf(l_run[m][r]);
+    }
+  acc_to_lds(oc, ct, 68, wr * (FBQ / 2), wc * 32, 1.0f, lane);
+  __syncthreads();
+  store_rows64<T, FBQ>(ct, Cg, a.ldc, Lq, tid);
+}
+
+// P = exp(alpha*S + key term - lse), the dropout multiplier and dS = P*(dP*mult - D) for one 64x128 tile of scores;
+// `pd_out` (P*mult) and `ds_out` may alias sc / dp register arrays of the caller
+template <int MT, int NT>
+__device__ __forceinline__ void flash_bwd_tile(f32x4_t (&sc)[MT][NT], f32x4_t (&dp)[MT][NT], const float (&kadd)[NT],
+                                               const float (&lse_r)[MT][4], const float (&d_r)[MT][4], const bool (&row_ok)[MT][4],
+                                               const AttnKArgs& a, uint32_t bh, int q0, int k0, int wr, int wc, int i, int g) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+      const uint32_t rbase = (bh * (uint32_t)a.Lq + (uint32_t)(q0 + row)) * (uint32_t)a.Lk + (uint32_t)k0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int col = wc * (FBKV / 2) + n * 16 + i;
+        float p = row_ok[m][r] ? __expf(sc[m][n][r] * a.alpha + kadd[n] - lse_r[m][r]) : 0.f;
+        float mult = 1.f;
+        if (a.drop.p > 0.f) mult = drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep);
+        const float ds = p * (dp[m][n][r] * mult - d_r[m][r]);
+        sc[m][n][r] = p * mult;        // dropped probabilities (dV operand)
+        dp[m][n][r] = ds;              // score gradient (dQ / dK operand)
+      }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_to_tile(const f32x4_t (&x)[MT][NT], char* tile, int PP, int wr, int wc, int i, int g) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(tile + row * PP) + wc * (FBKV / 2) + n * 16 + i, x[m][n][r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const AttnKArgs a, const void* O, long ldo) {
+  using T = bf16_t;
+  using L = FlashLds;
+  constexpr int PQ = L::PQ, PP = L::PP, MT = FBQ / 32, NT = FBKV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *qt = smem + L::Q_OFF, *dot = smem + L::DO_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *dst = smem + L::T_OFF;
+  float* dD = reinterpret_cast<float*>(smem + L::RS_OFF);          // D of this block's 64 query rows
+  float* ct = reinterpret_cast<float*>(smem + L::K_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x / a.nq, q0 = (blockIdx.x % a.nq) * FBQ;
+  const int b = bh / a.nh, h = bh % a.nh;
+  const int Lq = min(FBQ, a.Lq - q0);
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + ((long)b * a.Lq + q0) * a.ldq + h * 64;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (long)b * a.Lk * a.ldk + h * 64;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + (long)b * a.Lk * a.ldv + h * 64;
+  const T* Dg = reinterpret_cast<const T*>(a.dctx) + ((long)b * a.Lq + q0) * a.ldd + h * 64;
+  const T* Og = reinterpret_cast<const T*>(O) + ((long)b * a.Lq + q0) * ldo + h * 64;
+  const float* lse = reinterpret_cast<const float*>(a.P) + (long)bh * a.Lq + q0;
+  float* delta = reinterpret_cast<float*>(a.P) + (long)gridDim.x / a.nq * a.Lq + (long)bh * a.Lq + q0;     // D, behind all lse rows
+  const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
+
+  nat_load<T, FBQ, 64>(qt, Qg, a.ldq, Lq, 64, tid);
+  nat_load<T, FBQ, 64>(dot, Dg, a.ldd, Lq, 64, tid);
+  nat_load<T, FBQ, 64>(kt, Og, ldo, Lq, 64, tid);                  // O parked in the K tile for the row dots
+  __syncthreads();
+  {   // D[row] = sum_d dO[row,d] * O[row,d]: four threads per row, 16 columns each
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      s += Elem<T>::ld(reinterpret_cast<const T*>(dot + row * PQ) + c0 + c) * Elem<T>::ld(reinterpret_cast<const T*>(kt + row * PQ) + c0 + c);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((tid & 3) == 0) { dD[row] = s; if (row < Lq) delta[row] = s; }
+  }
+  __syncthreads();
+  float lse_r[MT][4], d_r[MT][4];
+  bool row_ok[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+      row_ok[m][r] = row < Lq;
+      lse_r[m][r] = row < Lq ? lse[row] : 0.f;
+      d_r[m][r] = dD[row];
+    }
+  f32x4_t dq[MT][2];
+  acc_zero(dq);
+  for (int k0 = 0; k0 < a.Lk; k0 += FBKV) {
+    const int nk = min(FBKV, a.Lk - k0);
+    __syncthreads();
+    nat_load<T, FBKV, 64>(kt, Kg + (long)k0 * a.ldk, a.ldk, nk, 64, tid);
+    nat_load<T, FBKV, 64>(vt, Vg + (long)k0 * a.ldv, a.ldv, nk, 64, tid);
+    float kadd[NT];
+    key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+    __syncthreads();
+    f32x4_t sc[MT][NT], dp[MT][NT];
+    acc_zero(sc); acc_zero(dp);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (FBKV / 2), lane);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(dp, dot, wr * (FBQ / 2), vt, wc * (FBKV / 2), lane);
+    flash_bwd_tile<MT, NT>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
+    acc_to_tile<MT, NT>(dp, dst, PP, wr, wc, i, g);
+    __syncthreads();
+    tile_mma<T, MT, 2, FBKV / 32, false, true, PP, PQ>(dq, dst, wr * (FBQ / 2), kt, wc * 32, lane);
+  }
+  __syncthreads();
+  T* dQg = reinterpret_cast<T*>(a.dQ) + ((long)b * a.Lq + q0) * a.lddq + h * 64;
+  acc_to_lds(dq, ct, 68, wr * (FBQ / 2), wc * 32, a.alpha, lane);
+  __syncthreads();
+  store_rows64<T, FBQ>(ct, dQg, a.lddq, Lq, tid);
+}
+
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const AttnKArgs a, int nkv) {
+  using T = bf16_t;
+  using L = FlashLds;
+  constexpr int PQ = L::PQ, PP = L::PP, MT = FBQ / 32, NT = FBKV / 32, MTk = FBKV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *qt = smem + L::Q_OFF, *dot = smem + L::DO_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *tt = smem + L::T_OFF;
+  float* ct = reinterpret_cast<float*>(smem);                       // staging [128][68] fp32 over Q/dO/K tiles (34.8 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x / nkv, k0 = (blockIdx.x % nkv) * FBKV;
+  const int b = bh / a.nh, h = bh % a.nh;
+  const int nk = min(FBKV, a.Lk - k0);
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + ((long)b * a.Lk + k0) * a.ldk + h * 64;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + ((long)b * a.Lk + k0) * a.ldv + h * 64;
+  const T* Dg = reinterpret_cast<const T*>(a.dctx) + (long)b * a.Lq * a.ldd + h * 64;
+  const float* lse = reinterpret_cast<const float*>(a.P) + (long)bh * a.Lq;
+  const float* delta = reinterpret_cast<const float*>(a.P) + (long)gridDim.x / nkv * a.Lq + (long)bh * a.Lq;
+  const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
+
+  nat_load<T, FBKV, 64>(kt, Kg, a.ldk, nk, 64, tid);
+  nat_load<T, FBKV, 64>(vt, Vg, a.ldv, nk, 64, tid);
+  float kadd[NT];
+  key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+  f32x4_t dk[MTk][2], dv[MTk][2];
+  acc_zero(dk); acc_zero(dv);
+  for (int q0 = 0; q0 < a.Lq; q0 += FBQ) {
+    const int nq = min(FBQ, a.Lq - q0);
+    __syncthreads();                                   // the previous query tile's products are done with qt / dot / tt
+    nat_load<T, FBQ, 64>(qt, Qg + (long)q0 * a.ldq, a.ldq, nq, 64, tid);
+    nat_load<T, FBQ, 64>(dot, Dg + (long)q0 * a.ldd, a.ldd, nq, 64, tid);
+    float lse_r[MT][4], d_r[MT][4];
+    bool row_ok[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
+        row_ok[m][r] = row < nq;
+        lse_r[m][r] = row < nq ? lse[q0 + row] : 0.f;
+        d_r[m][r] = row < nq ? delta[q0 + row] : 0.f;
+      }
+    __syncthreads();
+    f32x4_t sc[MT][NT], dp[MT][NT];
+    acc_zero(sc); acc_zero(dp);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (FBKV / 2), lane);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(dp, dot, wr * (FBQ / 2), vt, wc * (FBKV / 2), lane);
+    flash_bwd_tile<MT, NT>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
+    acc_to_tile<MT, NT>(sc, tt, PP, wr, wc, i, g);                 // dropped P
+    __syncthreads();
+    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dv, tt, wr * (FBKV / 2), dot, wc * 32, lane);     // dV += (P*mask)^T dO
+    __syncthreads();
+    acc_to_tile<MT, NT>(dp, tt, PP, wr, wc, i, g);                 // dS over the same tile
+    __syncthreads();
+    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dk, tt, wr * (FBKV / 2), qt, wc * 32, lane);      // dK += dS^T Q
+  }
+  __syncthreads();
+  T* dKg = reinterpret_cast<T*>(a.dK) + ((long)b * a.Lk + k0) * a.lddk + h * 64;
+  T* dVg = reinterpret_cast<T*>(a.dV) + ((long)b * a.Lk + k0) * a.lddv + h * 64;
+  acc_to_lds(dv, ct, 68, wr * (FBKV / 2), wc * 32, 1.0f, lane);
+  __syncthreads();
+  store_rows64<T, FBKV>(ct, dVg, a.lddv, nk, tid);
+  __syncthreads();
+  acc_to_lds(dk, ct, 68, wr * (FBKV / 2), wc * 32, a.alpha, lane);
+  __syncthreads();
+  store_rows64<T, FBKV>(ct, dKg, a.lddk, nk, tid);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 static bool fused_enabled() {
   const char* e = getenv("ETP_ATTN_FUSED");
@@ -488,6 +818,53 @@ static AttnKArgs make_args(int nh, const AttnBuf& a, float alpha) {
   k.ldS = a.ldS; k.nh = nh; k.Lq = a.Lq; k.Lk = a.Lk;
   k.keymask = a.keymask; k.mask_mode = a.mask_mode; k.dist = a.dist; k.sp_w = a.sp_w; k.sp_b = a.sp_b; k.alpha = alpha;
   return k;
+}
+
+// streaming kernels: bf16, a query or key axis beyond the resident-tile kernels, no pairwise-distance bias (that only exists
+// on the graph self-attention, G <= 128), room for lse + D (2 floats per row) in the probability buffer
+bool attn_flash_ok(int dt, const AttnBuf& a, long ldc) {
+  static const bool on = [] { const char* e = getenv("ETP_ATTN_FLASH"); return !(e && e[0] == '0'); }();
+  if (!on || !fused_enabled() || dt != ETP_BF16) return false;
+  if (a.Lq <= 128 && a.Lk <= 128) return false;
+  if (a.dist != nullptr || a.Lq < 1 || a.Lk < 1 || a.ldS < 4) return false;
+  if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || ldc % 8) return false;
+  if (((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V) % 16) return false;
+  return true;
+}
+static int flash_attr() {
+  static bool done = false;
+  if (done) return ETP_OK;
+  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
+  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
+  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
+  done = true;
+  return ETP_OK;
+}
+int attn_flash_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
+  ETP_TRY(flash_attr());
+  AttnKArgs k = make_args(nh, a, alpha);
+  k.drop = drop;
+  k.P = P; k.ctx = ctx; k.ldc = ldc;
+  k.nq = (a.Lq + FBQ - 1) / FBQ;
+  ETP_LAUNCH(flash_fwd_kernel, dim3(a.B * nh * k.nq), dim3(256), FlashLds::TOTAL, st, k);
+  ETP_CHECK_LAUNCH("flash_fwd");
+  return ETP_OK;
+}
+int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
+                   void* dV, long lddv, float alpha, hipStream_t st, Drop drop) {
+  ETP_REQUIRE(a.O != nullptr, "the streaming attention backward needs the forward output (AttnBuf::O)");
+  ETP_TRY(flash_attr());
+  AttnKArgs k = make_args(nh, a, alpha);
+  k.drop = drop;
+  k.P = const_cast<void*>(P); k.dctx = dctx; k.ldd = ldd;
+  k.dQ = dQ; k.dK = dK; k.dV = dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv;
+  k.nq = (a.Lq + FBQ - 1) / FBQ;
+  const int nkv = (a.Lk + FBKV - 1) / FBKV;
+  ETP_LAUNCH(flash_bwd_dq_kernel, dim3(a.B * nh * k.nq), dim3(256), FlashLds::TOTAL, st, k, a.O, a.ldo);
+  ETP_CHECK_LAUNCH("flash_bwd_dq");
+  ETP_LAUNCH(flash_bwd_dkv_kernel, dim3(a.B * nh * nkv), dim3(256), FlashLds::TOTAL, st, k, nkv);
+  ETP_CHECK_LAUNCH("flash_bwd_dkv");
+  return ETP_OK;
 }
 
 int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {

@@ -115,7 +115,9 @@ int etp_attn_fwd(const etp_attn_desc* d, etp_stream_t s) {
 int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t s) {
   ETP_REQUIRE(d && d->f.Q && d->f.K && d->f.V && d->f.P && d->dctx && d->dP && d->dQ && d->dK && d->dV, "null pointer");
   ETP_REQUIRE(d->f.ldS >= d->f.Lk && d->f.ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");
-  return attn_bwd_impl(d->f.dtype, d->f.heads, to_buf(d->f), d->f.P, d->dctx, d->ldd, d->dP, d->dQ, d->lddq, d->dK, d->lddk,
+  AttnBuf ab = to_buf(d->f);
+  ab.O = d->f.ctx; ab.ldo = d->f.ldc;          // the forward output (the streaming kernels need it)
+  return attn_bwd_impl(d->f.dtype, d->f.heads, ab, d->f.P, d->dctx, d->ldd, d->dP, d->dQ, d->lddq, d->dK, d->lddk,
                        d->dV, d->lddv, d->f.alpha, d->d_sp_w, d->d_sp_b, (hipStream_t)s);
 }
 

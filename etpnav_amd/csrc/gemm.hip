@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -206,10 +207,62 @@ __device__ __forceinline__ void frag_load(Frag<T>& f, const char* lds, int row16
   }
 }
 
+// Epilogue operands of a 64x64 tile (residual / activation operand / old C / bias: 2 chunks of 8 columns per thread) fetched
+// BEFORE the main loop of the LDS-DMA kernel: for the planner's K = 768 products the loop is ~3 us, and two dependent global
+// round trips behind it (operand reads, then the bias) were a fifth of the launch (K sweep: 7 us intercept,
+// profiles/r02_gemm_sweep.json).  Larger tiles keep the fetch in the epilogue (too many registers).
+// (No arrays in these structs on purpose: a runtime-indexed member array keeps the whole object in scratch memory.)
+struct EpiChunk { uint4 r0, r1, c0, c1, z0, z1; float4 b0, b1; };
+template <typename T, typename TC, int BM, int BN> struct EpiPre {
+  static constexpr int NCHUNK = BM * (BN / 8) / 256;
+  static constexpr bool ON = NCHUNK <= 2;
+  EpiChunk k0, k1;
+  bool valid;
+};
+template <typename T, typename TC, int BN>
+__device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmArgs& g, const TC* C, int m0, int n0, int ks, int tid) {
+  constexpr int CPRW = BN / 8;
+  constexpr int VPC = 8 * (int)sizeof(TC) / 16, VPT = 8 * (int)sizeof(T) / 16;
+  const int q = tid + j * 256;
+  const int lr = q / CPRW, lc = (q % CPRW) * 8;
+  const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, (g.N - 1) / 8 * 8);
+  if (g.R != nullptr) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const TC*>(g.R) + (long)rowc * g.ldr + colc);
+    k.r0 = p[0];
+    if constexpr (VPC == 2) k.r1 = p[1];
+  }
+  if (g.out_mode == 1) {
+    const uint4* p = reinterpret_cast<const uint4*>(C + (long)rowc * g.ldc + colc);
+    k.c0 = p[0];
+    if constexpr (VPC == 2) k.c1 = p[1];
+  }
+  if (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.Z) + (long)rowc * g.ldz + colc);
+    k.z0 = p[0];
+    if constexpr (VPT == 2) k.z1 = p[1];
+  }
+  if (g.bias != nullptr && ks == 0) {
+    k.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
+    k.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+  }
+}
+template <typename T, typename TC, int BM, int BN>
+__device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN>& pre, const GemmArgs& g, const TC* C, int m0, int n0, int ks,
+                                             int tid) {
+  using E = EpiPre<T, TC, BM, BN>;
+  pre.valid = false;
+  if constexpr (E::ON) {
+    if (!g.vec_epilogue) return;
+    pre.valid = true;
+    epi_fetch_chunk<T, TC, BN>(pre.k0, 0, g, C, m0, n0, ks, tid);
+    if constexpr (E::NCHUNK == 2) epi_fetch_chunk<T, TC, BN>(pre.k1, 1, g, C, m0, n0, ks, tid);
+  }
+}
+
 // Epilogue shared by both GEMM kernels (register-staged and LDS-DMA main loops).
 template <typename T, typename TC, int BM, int BN>
 __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], char* smem, const GemmArgs& g, TC* C, int m0,
-                                              int n0, int ks, int tid) {
+                                              int n0, int ks, int tid, const EpiPre<T, TC, BM, BN>& pre) {
   constexpr int MT = BM / 32, NT = BN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -245,8 +298,19 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
 #pragma unroll
     for (int h0 = 0; h0 < NCHUNK; h0 += HC) {
     uint4 rr[HC][VPC], cc[HC][VPC], zz[HC][VPT];
+    const bool use_pre = pre.valid;
+    EpiChunk pk;
+    if (use_pre) {
+      if constexpr (EpiPre<T, TC, BM, BN>::ON) {      // fetched before the main loop (HC == 1 for these tiles: chunk h0)
+        if (h0 == 0) pk = pre.k0; else pk = pre.k1;
+        rr[0][0] = pk.r0; cc[0][0] = pk.c0; zz[0][0] = pk.z0;
+        if constexpr (VPC == 2) { rr[0][1] = pk.r1; cc[0][1] = pk.c1; }
+        if constexpr (VPT == 2) zz[0][1] = pk.z1;
+      }
+    }
 #pragma unroll
     for (int jh = 0; jh < HC; ++jh) {
+      if (use_pre) break;
       const int jj = jh, q = tid + (h0 + jh) * 256;
       const int lr = q / CPRW, lc = (q % CPRW) * 8;
       const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, col_last);
@@ -281,7 +345,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
       }
       if (has_bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + colc), b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+        float4 b0, b1;
+        if (use_pre) {
+          if constexpr (EpiPre<T, TC, BM, BN>::ON) { b0 = pk.b0; b1 = pk.b1; }
+        } else {
+          b0 = *reinterpret_cast<const float4*>(g.bias + colc); b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+        }
         const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
@@ -463,7 +532,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   }
 
   __syncthreads();   // every wave is done reading the operand tiles before the C tile overwrites them
-  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
+  EpiPre<T, TC, BM, BN> pre;
+  pre.valid = false;
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
 }
 
 // =========================================================================================================
@@ -536,6 +607,15 @@ __device__ __forceinline__ void dma_issue(DmaPlan<T, TR, ROWS>& p, unsigned lds_
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `younger` whole slabs (PER_SLAB DMA instructions each) are still in flight; younger in [0, MAXS]
+template <int PER_SLAB, int MAXS> __device__ __forceinline__ void wait_slabs(int younger) {
+  if constexpr (MAXS <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (younger >= MAXS) wait_vmcnt<MAXS * PER_SLAB>();
+    else wait_slabs<PER_SLAB, MAXS - 1>(younger);
+  }
+}
 
 // One BM x BN output tile of problem `g` through the LDS-DMA main loop (shared by the single-problem and the grouped kernel).
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
@@ -566,6 +646,9 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  EpiPre<T, TC, BM, BN> pre;
+  epi_prefetch<T, TC, BM, BN>(pre, g, C, m0, n0, ks, tid);     // epilogue operands travel while the reduction runs
+
   const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
   float colsum_acc = 0.f;
   DmaPlan<T, TA, BM> pa;
@@ -582,9 +665,9 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     }
 
   for (int t = 0; t < nk; ++t) {
-    // slab t must have landed; up to STAGES-2 younger slabs stay in flight across the barrier
-    if (STAGES > 2 && t + 1 < nk) wait_vmcnt<(STAGES - 2) * PER_SLAB>();
-    else wait_vmcnt<0>();
+    // slab t must have landed; the younger slabs actually issued (at most STAGES-2, fewer at the tail of the reduction) stay
+    // in flight across the barrier.  (Round-2 fix: with STAGES >= 4 the count must shrink over the last STAGES-2 slabs.)
+    wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 1 - t));
     __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of slab t are in LDS, (b) buffer (t-1)%STAGES is free
     if (t + STAGES - 1 < nk) {
       const unsigned dst = lds0 + ((t + STAGES - 1) % STAGES) * STAGE;
@@ -624,7 +707,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     if (do_colsum && m0 + (tid % BM) < g.M) atomicAdd(g.a_colsum + m0 + (tid % BM), colsum_acc);
   }
   __syncthreads();
-  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid);
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
 }
 
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
@@ -649,8 +732,11 @@ template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x, nwg = gridDim.x;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int id = bid;
+  if (grp.xcd_chunks) {      // uniform reduction lengths: contiguous chunk of the tile list per XCD (L2 locality)
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }                          // mixed lengths: dispatch order = list order (longest reductions first, spread over all XCDs)
   int p = 0;
 #pragma unroll
   for (int i = 1; i < ETP_GEMM_GROUP_MAX; ++i)
@@ -763,6 +849,13 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
   bool dma = dma_ok(BK, g.K, g.ksplit);
   int stages = big ? 2 : 3;   // whole-step A/B on MI355X: 3-deep ring on 64x64 tiles 5.76 -> 5.37 ms/step
+  // cold-operand sweep (tools/gemm_sweep.py, profiles/r02_gemm_sweep.json): once a product has fewer 64x64 tiles than the
+  // chip has room for (one workgroup per CU or less: the M = 512 / 1152 products), a 4-deep ring wins 5-20 % -- the only
+  // way left to keep more bytes in flight per CU; at >= 2 workgroups per CU the 3-deep ring is as good or better
+  {
+    const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch * g.ksplit;
+    if (!big && t64 <= 320 && g.K >= 4 * BK) stages = 4;
+  }
   bool wide = false;          // 128x64 tiles
   const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r", "w", "64s6"
   if (force && force[0]) {
@@ -929,10 +1022,18 @@ int launch_gemm_group(int dtype, int c_dtype, int ta, int tb, const GemmArgs* gs
   GemmGroup grp;
   memset(&grp, 0, sizeof(grp));
   grp.n = n;
+  // longest reduction first: a tile's run time grows with K, and the last-dispatched tiles set the tail of the launch
+  int order[ETP_GEMM_GROUP_MAX];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order, order + n, [&](int a, int b) { return gs[a].K > gs[b].K; });
+  bool uniform = true;
   for (int i = 0; i < n; ++i) {
-    ETP_REQUIRE(gs[i].ksplit == 1 && gemm_uses_dma(dtype, gs[i].K, 1), "grouped products need unsplit LDS-DMA-able reductions");
-    ETP_TRY(prepare_args(dtype, c_dtype, ta, tb, gs[i], 1, grp.g[i]));
+    const GemmArgs& gi = gs[order[i]];
+    uniform = uniform && gi.K == gs[order[0]].K;
+    ETP_REQUIRE(gi.ksplit == 1 && gemm_uses_dma(dtype, gi.K, 1), "grouped products need unsplit LDS-DMA-able reductions");
+    ETP_TRY(prepare_args(dtype, c_dtype, ta, tb, gi, 1, grp.g[i]));
   }
+  grp.xcd_chunks = (uniform && grp.g[0].xcd_map) ? 1 : 0;
   if (dtype == ETP_F32) return launch_group_trans<float, float>(ta, tb, grp, st);
   if (c_dtype == ETP_F32) return launch_group_trans<bf16_t, float>(ta, tb, grp, st);
   return launch_group_trans<bf16_t, bf16_t>(ta, tb, grp, st);

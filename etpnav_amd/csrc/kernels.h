@@ -80,9 +80,18 @@ struct AttnBuf {
   int B, Lq, Lk, ldS;
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
   void* Pd = nullptr;      // unfused path only: second [B,heads,Lq,ldS] buffer for the DROPPED probabilities (training mode)
+  const void* O = nullptr; long ldo = 0;   // backward only: the forward output (streaming kernels: D = rowsum(dO * O))
 };
 // shapes the fused kernels do not take (the batched-GEMM path runs them and needs AttnBuf::Pd for dropout)
+// (bf16 with Lq or Lk > 128 normally runs the streaming kernels instead; the second buffer is still planned so that
+// ETP_ATTN_FLASH=0 / an unaligned operand can fall back)
 inline bool attn_needs_unfused(int dt, int Lq, int Lk) { return Lq > 128 || Lk > 128 || (dt == ETP_F32 && (Lq > 64 || Lk > 64)); }
+// streaming ("flash") kernels for long key / query axes, bf16 (attn.hip): P is not materialised, the front of the P buffer
+// holds lse and D (2 fp32 per query row)
+bool attn_flash_ok(int dt, const AttnBuf& a, long ldc);
+int attn_flash_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
+int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
+                   void* dV, long lddv, float alpha, hipStream_t st, Drop drop);
 int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS, Drop drop, hipStream_t st);
 // fused single-kernel variants (attn.hip) for Lq, Lk <= 128
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);

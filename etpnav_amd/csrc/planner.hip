@@ -424,6 +424,7 @@ static inline void* offs(void* p, long elems, size_t es) { return reinterpret_ca
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   const int dh = 64;
   if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st, drop);
+  if (attn_flash_ok(dt, a, ldc)) return attn_flash_fwd(nh, a, P, ctx, ldc, alpha, st, drop);
   ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
   GemmArgs g = base_args();
   // S = alpha * Q K^T
@@ -455,6 +456,8 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
     const int epc = dt == ETP_BF16 ? 8 : 4;
     if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
       return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
+    if (a.O != nullptr && attn_flash_ok(dt, a, ldd) && a.ldo % epc == 0 && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
+      return attn_flash_bwd(nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, st, drop);
   }
   ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
   const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;
@@ -596,6 +599,7 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   a.Pd = s.Pd;
+  a.O = s.ctx; a.ldo = H;
   ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, w.t2, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
                         offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
@@ -1004,6 +1008,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     a.Pd = t.Pd;
+    a.O = t.ctx; a.ldo = H;
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
                           offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
@@ -1323,6 +1328,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     void* dkv_out = cached ? offs(d_kv, (long)l * Mt * 2 * H, c.es) : xc.dkv;
     AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
     a.Pd = t.cross.Pd;
+    a.O = t.cross.ctx; a.ldo = H;
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
                           0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
@@ -1563,6 +1569,7 @@ int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, wc.t2, H, Mt, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     AttnBuf a{t.q, (long)H, t.kv, 2L * H, offs(t.kv, H, c.es), 2L * H, B, L, G, ldG, gmask, 0, nullptr, nullptr, nullptr};
     a.Pd = t.Pd;
+    a.O = t.ctx; a.ldo = H;
     void* dq = w.dq[l]; void* dkv = w.dkv[l];
     ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, wc.t2, H, w.dPx[l], dq, H, dkv, 2L * H, offs(dkv, H, c.es), 2L * H, 0.125f, nullptr,
                           nullptr, c.st, att(c, MODE_MLM, l, SITE_X_P)));

@@ -161,6 +161,55 @@ class GradReducer:
             self.native = None
 
 
+# ---- per-task static bucket sets (replaces DDP's find_unused_parameters=True, pretrain utils/misc.py:58) -------------------
+# Which parameters a pre-training task touches is a static property of the task (pretrain_cmt.py:141-163 'mlm' vs :223-283
+# 'sap'): the reference lets DDP discover the unused ones dynamically every step; here each task has a fixed list of arena
+# ranges, and only those are reduced (the rest of the gradient arena is exactly zero on every rank).
+_TASK_ONLY = {
+    "sap": (".visn_self_att.", ".visn_inter.", ".visn_output.", "sprel_linear.", "global_sap_head."),
+    "mlm": (".lang_self_att.", ".lang_inter.", ".lang_output.", "mlm_head."),
+}
+
+
+def task_uses_param(task: str, name: str) -> bool:
+    """True when parameter `name` receives a gradient in pre-training task `task` ('sap' | 'mlm')."""
+    if task not in _TASK_ONLY:
+        raise ValueError(f"unknown pre-training task {task!r}")
+    for t, pats in _TASK_ONLY.items():
+        if t != task and any(p in name for p in pats):
+            return False
+    return True
+
+
+def task_grad_ranges(model, task: str, max_gap: int = 0):
+    """Element ranges [start, end) of the flat gradient arena that task `task` writes, merged over adjacent parameters
+    (64-element alignment padding between two used parameters is bridged), in arena order, and the sparse word-table
+    descriptor: SAP touches <= B*L rows of the word table (row-sparse exchange), MLM's tied decoder makes it dense (it is
+    then part of the returned ranges and the descriptor is None)."""
+    eng = model._engine
+    spans = []
+    word = None
+    for name, shape, off in eng.table:
+        n = 1
+        for d in shape:
+            n *= d
+        if name == "embeddings.word_embeddings.weight":
+            word = (off, shape[0], shape[1])
+            if task != "mlm":
+                continue
+        if task_uses_param(task, name):
+            spans.append((off, off + (n + 63) // 64 * 64))
+    spans.sort()
+    merged = []
+    for s, e in spans:
+        if merged and s - merged[-1][1] <= max_gap:
+            merged[-1][1] = max(merged[-1][1], e)
+        else:
+            merged.append([s, e])
+    total = eng.total
+    return [(s, min(e, total)) for s, e in merged], (None if task == "mlm" else word)
+
+
 def planner_buckets_layered(model, text_groups: int = 3):
     """Finer buckets for overlap with the text-encoder backward: bucket 0 = non-text matrices (ready after the navigation
     and panorama backward), then one bucket per group of text layers in backward order (last layers first), then vectors

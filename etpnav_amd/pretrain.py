@@ -20,8 +20,11 @@ from .planner import GlocalTextPathNavCMT
 
 
 class MlmStep:
-    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], dropout=None, drop_seed: int = 0):
-        """batch: etpnav_amd.synthetic.make_sap_batch layout + ``txt_labels`` [B,L] (-1 = not masked, else the token id)."""
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], dropout=None, drop_seed: int = 0,
+                 overlap: bool = True):
+        """batch: etpnav_amd.synthetic.make_sap_batch layout + ``txt_labels`` [B,L] (-1 = not masked, else the token id).
+        overlap: the three-stream schedule of PlannerStep -- weight gradients on an `aux` stream, the panorama branch
+        (forward and backward) on `s2` beside the text branch; False = everything on the caller's stream."""
         eng = self.eng = model._engine
         eng.require_gpu()
         if not eng.cconf.use_lang2visn:
@@ -69,21 +72,44 @@ class MlmStep:
         self.st_txt = eng.buf(self.L.etp_txt_stash_bytes(h, B, Lt)); self.ws_txt = eng.buf(self.L.etp_txt_ws_bytes(h, B, Lt))
         self.st_pano = eng.buf(self.L.etp_pano_stash_bytes(h, Bp, V)); self.ws_pano = eng.buf(self.L.etp_pano_ws_bytes(h, Bp, V))
         self.st_mlm = eng.buf(self.L.etp_mlm_stash_bytes(h, B, Lt, G, Nm)); self.ws_mlm = eng.buf(self.L.etp_mlm_ws_bytes(h, B, Lt, G, Nm))
+        self.aux = self.s2 = None
+        if overlap:
+            import ctypes
+            a, b2 = ctypes.c_void_p(), ctypes.c_void_p()
+            check(self.L.etp_stream_create(ctypes.byref(a)), "stream_create")
+            check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
+            self.aux, self.s2 = a.value, b2.value
+
+    def close(self):
+        self.L.etp_planner_set_aux_stream(self.eng.handle, None)
+        for st in (self.aux, self.s2):
+            if st is not None:
+                self.L.etp_stream_destroy(st)
+        self.aux = self.s2 = None
 
     def run_eager(self, backward: bool = True):
         L, eng, i = self.L, self.eng, self.inp
         h, s = eng.handle, eng.stream()
+        s2 = self.s2 if self.s2 is not None else s
         B, Lt, Bp, V, G, H = self.dims
         self.step_no += 1
         eng.set_dropout(None if self.dropout is None else
                         tuple(self.dropout) + ((self.drop_seed << 32) | (self.step_no & 0xFFFFFFFF),))
-        check(L.etp_planner_refresh_weights(h, s), "refresh_weights")
+        check(L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
+        check(L.etp_planner_set_lazy_join(h, 0), "set_lazy_join")
+        # text weights first on the main stream; everything else (panorama / x-layer casts, the gradient memset) rides on the
+        # panorama stream, whose join precedes the MLM forward and every backward kernel
+        check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
         check(L.etp_memset_async(ptr(self.loss), 0, 4, s), "memset loss")
+        check(L.etp_stream_after(s, s2), "fork")
+        check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
+        check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
         if backward:
-            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s), "memset grads")
+            check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), Bp, V,
-                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s), "pano_fwd")
+                             ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
+        check(L.etp_stream_after(s2, s), "join")
         pf, xf, wf = self.csr_f
         check(L.etp_gather_sum(_lib.ETP_F32, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "aggregate")
         check(L.etp_mlm_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
@@ -97,7 +123,59 @@ class MlmStep:
         pb, xb, wb = self.csr_b
         check(L.etp_gather_sum(_lib.ETP_F32, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), Bp * V, H, 0, s),
               "aggregate bwd")
+        check(L.etp_stream_after(s, s2), "fork")                  # panorama backward beside the text backward
         check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), Bp, V, None,
-                             ptr(self.st_pano), ptr(self.ws_pano), s), "pano_bwd")
+                             ptr(self.st_pano), ptr(self.ws_pano), s2), "pano_bwd")
         check(L.etp_txt_bwd(h, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.st_txt), ptr(self.ws_txt),
                             s), "txt_bwd")
+        check(L.etp_stream_after(s2, s), "join")
+        check(L.etp_planner_set_aux_stream(h, None), "set_aux_stream")
+
+
+# ---- multi-task driver pieces (pretrain_src/pretrain_src/data/loader.py:18-75, train_r2r.py:229-300) ----------------------
+class MetaLoader:
+    """Wraps several task loaders and yields ``(task_name, batch)`` forever, as the reference's MetaLoader: every
+    ``accum_steps`` steps a task is drawn with probability proportional to its mixing ratio (``torch.multinomial``,
+    loader.py:54-58), in distributed runs rank 0's draw is broadcast so that all ranks train the same task (:57-58; the
+    per-task gradient bucket sets of etpnav_amd.dp.task_grad_ranges rely on exactly that), an exhausted loader is
+    re-created after calling its ``pre_epoch(epoch)`` hook (:63-71, DistributedSampler.set_epoch).
+
+    loaders: {name: iterable  |  (iterable, ratio, pre_epoch_fn)}; an "iterable" is anything ``iter()`` accepts that can
+    be iterated again for the next epoch (a DataLoader, a list of batches)."""
+
+    def __init__(self, loaders: Dict, accum_steps: int = 1, distributed: bool = False, device=None, generator=None):
+        assert isinstance(loaders, dict) and loaders
+        self.name2loader, self.name2iter, self.name2pre_epoch, self.names, ratios = {}, {}, {}, [], []
+        for n, l in loaders.items():
+            if isinstance(l, tuple):
+                l, r, p = l
+            else:
+                r, p = 1, (lambda e: None)
+            self.names.append(n)
+            self.name2loader[n], self.name2iter[n], self.name2pre_epoch[n] = l, iter(l), p
+            ratios.append(r)
+        self.accum_steps, self.device, self.distributed = accum_steps, device, distributed
+        self.sampling_ratios = torch.tensor(ratios).float()
+        self.generator = generator
+        self.step = 0
+
+    def __iter__(self):
+        import torch.distributed as dist
+        task_id, epoch_id = None, 0
+        while True:
+            if self.step % self.accum_steps == 0:
+                task_id = torch.multinomial(self.sampling_ratios, 1, generator=self.generator)
+                if self.distributed:
+                    t = task_id.to(self.device) if self.device is not None else task_id
+                    dist.broadcast(t, 0)                      # every rank trains the same task this step
+                    task_id = t.cpu()
+            self.step += 1
+            task = self.names[int(task_id.item())]
+            try:
+                batch = next(self.name2iter[task])
+            except StopIteration:
+                epoch_id += 1
+                self.name2pre_epoch[task](epoch_id)
+                self.name2iter[task] = iter(self.name2loader[task])
+                batch = next(self.name2iter[task])
+            yield task, batch

@@ -285,3 +285,53 @@ def test_explicitly_recorded_three_stream_graph_replays_the_step(dtype):
     step.sync()
     assert (model.flat_grads - eager_grad).abs().max().item() < tol * max(1.0, eager_grad.abs().max().item())
     step.close()
+
+
+def test_long_instruction_bf16_train_mode_step_close_to_oracle_with_same_masks():
+    """L = 200 > 128 in bf16 train mode: the streaming attention kernels (text self-attention and the cross-attention onto
+    200 text keys) draw their dropout masks from the same counter hash as the resident-tile kernels -- the oracle with the
+    same masks must agree to the bf16 bounds on outputs and every gradient."""
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=6)
+    batch = po.make_batch(cfg, B=2, L=200, V=14, G=9, seed=33, ragged=True)
+    rates = (0.1, 0.1, 0.1, 0.4)
+    outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*rates, seed=(11 << 32) | 1))
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch, dropout=rates, drop_seed=11)
+    step.run_eager()
+    got = step_outputs(step)
+    for k in ("txt_embeds", "gmap_embeds"):
+        assert (got[k].float().cpu() - outs[k]).abs().max().item() < 8e-2, k
+    assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
+    mine = grads_of(model)
+    for k, g in grads.items():
+        if k.startswith("__input__"):
+            continue
+        err = (mine[k] - g).abs().max().item()
+        assert err < 8e-2 + 0.1 * g.abs().max().item(), f"{k}: {err}"
+    step.close()
+
+
+def test_same_seed_steps_are_bit_identical_where_no_atomics_are_involved():
+    """SURVEY.md §5 determinism check: the same step (same weights, inputs and dropout seed) twice -> every forward output
+    and every weight-MATRIX gradient (first-touch stores of the grouped weight-gradient GEMM, fixed reduction order) is
+    bit-identical; only the atomically reduced vectors / embedding rows (LayerNorm and bias gradients, word rows) may differ,
+    and only in the last bits."""
+    cfg = po.PlannerConfig.r2r(vocab_size=4096)
+    P = po.init_params(cfg, seed=2)
+    batch = po.make_batch(cfg, B=4, L=80, V=36, G=16, seed=7)
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch, dropout=(0.1, 0.1, 0.1, 0.4), drop_seed=9)
+    runs = []
+    for _ in range(2):
+        step.step_no = 0
+        step.run_eager(); torch.cuda.synchronize()
+        runs.append(({k: v.clone() for k, v in step_outputs(step).items()}, model.flat_grads.clone()))
+    for k in runs[0][0]:
+        a, b = runs[0][0][k], runs[1][0][k]
+        assert torch.equal(torch.nan_to_num(a, neginf=-1e30), torch.nan_to_num(b, neginf=-1e30)), k
+    nm = model._engine.n_matrix
+    assert torch.equal(runs[0][1][:nm], runs[1][1][:nm])
+    tail = (runs[0][1][nm:] - runs[1][1][nm:]).abs().max().item()
+    assert tail <= 1e-5 * max(1.0, runs[0][1][nm:].abs().max().item())
+    step.close()

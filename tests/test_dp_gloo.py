@@ -124,3 +124,66 @@ def test_pretraining_variant_buckets_cover_language_side_weights_and_dense_word_
         seen_lang |= ".lang_self_att." in name
         seen_head |= name.startswith("mlm_head.")
     assert seen_lang and seen_head
+
+
+def test_per_task_bucket_sets_match_the_parameters_each_pretraining_task_touches():
+    """static per-task bucket sets instead of DDP's find_unused_parameters=True (utils/misc.py:58).  The
+    oracle (pinned to the real GlocalTextPathCMTPreTraining) says which parameters get a gradient in each task: exactly
+    those must lie inside task_grad_ranges(task) (or the sparse word table), everything outside must be zero."""
+    from oracle import planner_oracle as po
+    from oracle.make_golden_pretrain import make_case
+    from etpnav_amd.planner import GlocalTextPathNavCMT
+    cfg, P, batch = make_case()
+    m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.float32, device="cpu")
+    base = m.flat_params.data_ptr()
+    offs = {n: ((p.data_ptr() - base) // 4, p.numel()) for n, p in m.named_parameters()}
+    for task, fn in (("sap", po.sap_step_with_grads), ("mlm", po.mlm_step_with_grads)):
+        _, grads = fn(P, cfg, batch)
+        ranges, sparse = dp.task_grad_ranges(m, task)
+        assert (sparse is None) == (task == "mlm")
+        cover = torch.zeros(m.flat_grads.numel(), dtype=torch.bool)
+        for s, e in ranges:
+            assert 0 <= s < e <= cover.numel()
+            cover[s:e] = True
+        if sparse is not None:
+            cover[sparse[0]:sparse[0] + sparse[1] * sparse[2]] = True
+        n_used = n_unused = 0
+        for name, g in grads.items():
+            if name.startswith("__input__"):
+                continue
+            off, n = offs[name]
+            touched = bool(g.abs().max() > 0)
+            inside = bool(cover[off:off + n].all())
+            if touched:
+                assert inside, f"{task}: {name} has a gradient but is outside the task's buckets"
+            if not dp.task_uses_param(task, name):
+                assert not touched, f"{task}: {name} is declared unused but the oracle gives it a gradient"
+                assert not bool(cover[off:off + n].any()), f"{task}: unused {name} is inside a bucket"
+                n_unused += 1
+            else:
+                n_used += 1
+        assert n_used > 100 and n_unused > 10
+    with pytest.raises(ValueError):
+        dp.task_uses_param("mrc", "x")
+
+
+def test_meta_loader_mixes_tasks_by_ratio_and_restarts_exhausted_loaders():
+    from etpnav_amd.pretrain import MetaLoader
+    epochs = []
+    loaders = {"mlm": ([{"i": k} for k in range(3)], 1, lambda e: epochs.append(("mlm", e))),
+               "sap": ([{"i": 10 + k} for k in range(5)], 3, lambda e: epochs.append(("sap", e)))}
+    g = torch.Generator().manual_seed(0)
+    ml = MetaLoader(loaders, accum_steps=2, generator=g)
+    it = iter(ml)
+    seen = [next(it) for _ in range(400)]
+    names = [t for t, _ in seen]
+    for k in range(0, 400, 2):
+        assert names[k] == names[k + 1]                      # the task only changes every accum_steps steps
+    frac = names.count("sap") / len(names)
+    assert 0.65 < frac < 0.85                               # ratio 3 : 1
+    sap_items = [b["i"] for t, b in seen if t == "sap"]
+    assert sap_items[:7] == [10, 11, 12, 13, 14, 10, 11]     # exhausted loader re-created, in order
+    assert ("sap", 1) in epochs and any(t == "mlm" for t, _ in epochs)
+    plain = MetaLoader({"only": [1, 2]})
+    it = iter(plain)
+    assert [next(it)[1] for _ in range(5)] == [1, 2, 1, 2, 1]

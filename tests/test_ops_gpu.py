@@ -257,6 +257,59 @@ def test_attention_fwd_bwd(dtype, Lq, Lk):
     assert abs(db.item() - br.grad.item()) <= tol(dtype, 4) + 2e-3
 
 
+@pytest.mark.parametrize("Lq,Lk", [(512, 512), (200, 200), (16, 512), (130, 300), (64, 129), (300, 70)])
+@pytest.mark.parametrize("mask_mode", [0, 1])
+def test_streaming_attention_fwd_bwd(Lq, Lk, mask_mode):
+    """bf16 streaming ("flash") kernels for Lq or Lk > 128 (RxR's 512-token instructions): online softmax over 128-key tiles,
+    probabilities recomputed in the backward -- against torch autograd on the same bf16 operands.  A spiked key forces the
+    running-max rescale path in a LATER tile (cdna guide rule 26: the rare branch needs its own input)."""
+    torch.manual_seed(Lq * 7 + Lk + mask_mode)
+    dtype, t = _lib.ETP_BF16, torch.bfloat16
+    B, nh, dh = 2, 3, 64
+    H = nh * dh
+    ldS = (Lk + 7) // 8 * 8
+    q = torch.randn(B * Lq, H, device=DEV).to(t)
+    kv = torch.randn(B * Lk, 2 * H, device=DEV).to(t)
+    if Lk > 140:
+        kv[Lk - 3, :H] = q[0, :H] * 3.0                       # batch 0: the last tile holds the row max of query 0
+    km = torch.rand(B, Lk, device=DEV) > 0.2
+    km[:, 0] = True
+    km[1, Lk // 2:] = False                                  # batch 1: whole trailing tiles masked out
+    qr = q.float().requires_grad_(True); kvr = kv.float().requires_grad_(True)
+    qh = qr.view(B, Lq, nh, dh).permute(0, 2, 1, 3)
+    kh = kvr[:, :H].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    vh = kvr[:, H:].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    add = torch.where(km, 0.0, float("-inf") if mask_mode else -10000.0)[:, None, None, :]
+    s = qh @ kh.transpose(-1, -2) / 8.0 + add
+    ctx_ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Lq, H)
+    P = torch.full((B, nh, Lq, ldS), float("nan"), device=DEV, dtype=t)
+    ctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
+    d = AttnDesc()
+    d.dtype, d.B, d.heads, d.Lq, d.Lk, d.ldS = dtype, B, nh, Lq, Lk, ldS
+    d.Q, d.ldq = q.data_ptr(), H
+    d.K, d.ldk = kv.data_ptr(), 2 * H
+    d.V, d.ldv = kv.data_ptr() + H * q.element_size(), 2 * H
+    d.P, d.ctx, d.ldc = P.data_ptr(), ctx.data_ptr(), H
+    d.keymask, d.mask_mode = km.data_ptr(), mask_mode
+    d.alpha = 0.125
+    check(L().etp_attn_fwd(ctypes.byref(d), stream()), "attn_fwd")
+    torch.cuda.synchronize()
+    assert (ctx.float() - ctx_ref).abs().max().item() <= tol(dtype, 2)
+    dctx = torch.randn(B * Lq, H, device=DEV).to(t)
+    ctx_ref.backward(dctx.float())
+    bd = AttnBwdDesc()
+    bd.f = d
+    dP = torch.empty_like(P); dq = torch.full_like(q, float("nan")); dkv = torch.full_like(kv, float("nan"))
+    bd.dctx, bd.ldd, bd.dP = dctx.data_ptr(), H, dP.data_ptr()
+    bd.dQ, bd.lddq = dq.data_ptr(), H
+    bd.dK, bd.lddk = dkv.data_ptr(), 2 * H
+    bd.dV, bd.lddv = dkv.data_ptr() + H * q.element_size(), 2 * H
+    check(L().etp_attn_bwd(ctypes.byref(bd), stream()), "attn_bwd")
+    torch.cuda.synchronize()
+    assert (dq.float() - qr.grad).abs().max().item() <= tol(dtype, 3) * max(1.0, qr.grad.abs().max().item() / 4)
+    assert (dkv.float() - kvr.grad).abs().max().item() <= tol(dtype, 3) * max(1.0, kvr.grad.abs().max().item() / 4)
+
+
 def test_cross_entropy_and_gather():
     torch.manual_seed(5)
     B, G = 7, 11
