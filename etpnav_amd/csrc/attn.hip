@@ -872,8 +872,15 @@ int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ld
   k.drop = drop;
   k.P = P; k.ctx = ctx; k.ldc = ldc;
   k.nq = (a.Lq + 63) / 64;                        // 64 queries per workgroup
-  const int blocks = a.B * nh * k.nq;
+  int blocks = a.B * nh * k.nq;
   if (dt == ETP_BF16) {     // key tile = 64 / 96 / 128 columns: the 80-token instruction takes the 96 one, not a 128 pad
+    static const bool q96 = [] { const char* e = getenv("ETP_ATTN_Q96"); return !(e && e[0] == '0'); }();
+    if (q96 && a.Lq > 64 && a.Lq <= 96 && a.Lk > 64 && a.Lk <= 96) {
+      // the 80-token self-attention: ONE 96-query workgroup per (batch, head) instead of a full and a quarter-full 64-query
+      // one (K/V staged once, half the workgroups)
+      k.nq = 1;
+      return launch_fwd<bf16_t, 96, 96>(k, a.B * nh, st);
+    }
     if (a.Lk > 96) return launch_fwd<bf16_t, 64, 128>(k, blocks, st);
     if (a.Lk > 64) return launch_fwd<bf16_t, 64, 96>(k, blocks, st);
     return launch_fwd<bf16_t, 64, 64>(k, blocks, st);

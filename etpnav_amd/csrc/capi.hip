@@ -223,6 +223,17 @@ int etp_stream_create(etp_stream_t* out) {
   *out = (etp_stream_t)s;
   return ETP_OK;
 }
+int etp_stream_create_prio(etp_stream_t* out, int level) {
+  // level < 0: lowest priority the device offers (leaf work: weight gradients), 0: default, > 0: highest
+  ETP_REQUIRE(out, "null pointer");
+  int least = 0, greatest = 0;
+  ETP_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int prio = level < 0 ? least : (level > 0 ? greatest : (least + greatest) / 2);
+  hipStream_t s;
+  ETP_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  *out = (etp_stream_t)s;
+  return ETP_OK;
+}
 int etp_stream_destroy(etp_stream_t s) { ETP_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return ETP_OK; }
 int etp_stream_sync(etp_stream_t s) { ETP_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return ETP_OK; }
 int etp_stream_after(etp_stream_t from, etp_stream_t to) {

@@ -124,13 +124,16 @@ class PlannerStep:
         # side streams: `aux` carries the weight-gradient GEMMs, `s2` the panorama branch (independent of the text branch)
         self.overlap = overlap
         self.aux = self.s2 = None
+        # leaf work (weight gradients; the panorama branch) runs at the lowest stream priority: whenever its workgroups and the
+        # dependent chain's wait for the same CUs, the chain's are dispatched first (ETP_STREAM_PRIO=0: all default)
+        low = -1 if os.environ.get("ETP_STREAM_PRIO", "1") != "0" else 0
         if overlap in (True, "aux", "both"):
             a = ctypes.c_void_p()
-            check(self.L.etp_stream_create(ctypes.byref(a)), "stream_create")
+            check(self.L.etp_stream_create_prio(ctypes.byref(a), low), "stream_create")
             self.aux = a.value
         if overlap in (True, "s2", "both"):
             b2 = ctypes.c_void_p()
-            check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
+            check(self.L.etp_stream_create_prio(ctypes.byref(b2), low), "stream_create")
             self.s2 = b2.value
         self.aux2 = None
         if self.aux is not None and os.environ.get("ETP_DTXT_STREAM", "1") != "0":

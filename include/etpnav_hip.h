@@ -399,6 +399,9 @@ int etp_mlm_bwd(etp_planner* p, const float* txt_embeds, const uint8_t* txt_mask
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct etp_graph etp_graph;
 int etp_stream_create(etp_stream_t* out);
+/* level < 0: the lowest priority the device offers (for leaf work such as weight gradients, so that the dependent chain's
+ * workgroups are dispatched first whenever both wait for a CU), 0: default, > 0: highest. */
+int etp_stream_create_prio(etp_stream_t* out, int level);
 int etp_stream_destroy(etp_stream_t s);
 int etp_stream_sync(etp_stream_t s);
 /* make `to` wait for the work enqueued so far on `from` (fork / join of parallel branches; capturable) */

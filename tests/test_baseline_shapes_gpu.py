@@ -323,15 +323,27 @@ def test_same_seed_steps_are_bit_identical_where_no_atomics_are_involved():
     model = build_model(cfg, P, torch.bfloat16)
     step = PlannerStep(model, batch, dropout=(0.1, 0.1, 0.1, 0.4), drop_seed=9)
     runs = []
-    for _ in range(2):
+    for _ in range(int(os.environ.get("ETP_DET_RUNS", "3"))):
         step.step_no = 0
         step.run_eager(); torch.cuda.synchronize()
         runs.append(({k: v.clone() for k, v in step_outputs(step).items()}, model.flat_grads.clone()))
-    for k in runs[0][0]:
-        a, b = runs[0][0][k], runs[1][0][k]
-        assert torch.equal(torch.nan_to_num(a, neginf=-1e30), torch.nan_to_num(b, neginf=-1e30)), k
     nm = model._engine.n_matrix
-    assert torch.equal(runs[0][1][:nm], runs[1][1][:nm])
-    tail = (runs[0][1][nm:] - runs[1][1][nm:]).abs().max().item()
-    assert tail <= 1e-5 * max(1.0, runs[0][1][nm:].abs().max().item())
+    for r in runs[1:]:
+        for k in runs[0][0]:
+            a, b = runs[0][0][k], r[0][k]
+            assert torch.equal(torch.nan_to_num(a, neginf=-1e30), torch.nan_to_num(b, neginf=-1e30)), k
+        assert torch.equal(runs[0][1][:nm], r[1][:nm])
+        worst = []
+        for name, shape, off in model._engine.table:
+            if off < nm:
+                continue
+            n = 1
+            for d in shape:
+                n *= d
+            a, b = runs[0][1][off:off + n], r[1][off:off + n]
+            worst.append(((a - b).abs().max().item(), a.abs().max().item(), name))
+        worst.sort(reverse=True)
+        # fp32 atomics commute but do not associate: sums of a few hundred terms with cancellation move in the 1e-3 relative range
+        bad = [(d, m, n) for d, m, n in worst if d > 5e-3 * max(1.0, m)]
+        assert not bad, f"atomically reduced gradients differ beyond rounding between identical runs: {bad[:5]}"
     step.close()

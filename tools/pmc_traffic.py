@@ -25,7 +25,7 @@ csv.field_size_limit(1 << 30)
 
 
 def bench_name(kernel: str):
-    m = re.search(r"gemm(_dma)?_kernel<([^>]*)>", kernel)
+    m = re.search(r"gemm(_dma|_group)?_kernel<([^>]*)>", kernel)
     if not m:
         m2 = re.search(r"(\w+_kernel)<", kernel) or re.search(r"::(\w+_kernel)", kernel) or re.search(r"(\w+_kernel)", kernel)
         return m2.group(1) if m2 else kernel[:60]
