@@ -80,6 +80,16 @@ class MlmStep:
             check(self.L.etp_stream_create(ctypes.byref(b2)), "stream_create")
             self.aux, self.s2 = a.value, b2.value
 
+    @staticmethod
+    def batch_shape_key(batch):
+        B, Lt = batch["txt_ids"].shape
+        Bp, V = batch["rgb_fts"].shape[:2]
+        return (B, Lt, Bp, V, batch["gmap_step_ids"].shape[1], int((batch["txt_labels"] != -1).sum()))
+
+    def shape_key(self):
+        B, Lt, Bp, V, G, _ = self.dims
+        return (B, Lt, Bp, V, G, self.Nm)
+
     def close(self):
         self.L.etp_planner_set_aux_stream(self.eng.handle, None)
         for st in (self.aux, self.s2):
@@ -179,3 +189,98 @@ class MetaLoader:
                 self.name2iter[task] = iter(self.name2loader[task])
                 batch = next(self.name2iter[task])
             yield task, batch
+
+
+class PretrainDriver:
+    """The multi-task pre-training loop of train_r2r.py:229-300 on the MI355X planner: MetaLoader task mixing -> one
+    device-side step of the drawn task (SAP = PlannerStep over trajectories, MLM = MlmStep) -> (multi-GPU) mean of exactly
+    the gradient ranges that task writes (etpnav_amd.dp.task_grad_ranges: static per-task bucket sets instead of DDP's
+    find_unused_parameters=True, utils/misc.py:58) -> warm-up-linear learning rate (optim/sched.py) -> fused AdamW with the
+    reference's decay grouping and gradient clipping (optim/misc.py, optim/adamw.py, train_r2r.py:283-300).
+
+    Step objects (preallocated stash / workspace / streams) are cached per batch shape and refilled in place for SAP; the MLM
+    step is rebuilt per batch (its masked-token count changes the buffer plan)."""
+
+    def __init__(self, model: GlocalTextPathNavCMT, loaders: Dict, learning_rate: float = 5e-5, warmup_steps: int = 10000,
+                 num_train_steps: int = 100000, grad_norm: float = 5.0, accum_steps: int = 1, dropout="config", seed: int = 0,
+                 distributed: bool = False, max_cached_steps: int = 4, generator=None):
+        from .optim import FusedAdamW, WarmupLinearLR
+        from . import dp
+        if accum_steps != 1:
+            raise NotImplementedError("gradient_accumulation_steps > 1 (the reference's configs use 1: run_pt/*.json)")
+        self.model, self.dropout, self.seed = model, dropout, int(seed)
+        self.meta = MetaLoader(loaders, accum_steps=accum_steps, distributed=distributed, device=model._engine.device,
+                               generator=generator)
+        self.opt = FusedAdamW(model, lr=learning_rate, hf_style=True, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
+                              max_grad_norm=grad_norm, no_decay=FusedAdamW.reference_no_decay)
+        self.sched = WarmupLinearLR(self.opt, learning_rate, warmup_steps, num_train_steps)
+        self.global_step = 0
+        self.distributed = distributed
+        self._sap = {}                      # shape key -> PlannerStep
+        self._max = max_cached_steps
+        self.reducers = {}
+        if distributed:
+            for task in ("sap", "mlm"):
+                ranges, sparse = dp.task_grad_ranges(model, task)
+                self.reducers[task] = dp.GradReducer(model.flat_grads, ranges, sparse_rows=sparse)
+        self.task_losses = {}
+
+    def _sap_step(self, batch):
+        from .step import PlannerStep
+        key = PlannerStep.batch_shape_key(batch)
+        st = self._sap.get(key)
+        if st is None:
+            if len(self._sap) >= self._max:
+                self._sap.pop(next(iter(self._sap))).close()
+            # accumulate-mode gradients + full zeroing: the pre-training variant carries weights this task does not touch
+            st = PlannerStep(self.model, batch, dropout=self.dropout, drop_seed=self.seed, zero_grads=True, grad_overwrite=False)
+            self._sap[key] = st
+        else:
+            st.load_batch(batch)
+        return st
+
+    def train_step(self, name: str, batch) -> torch.Tensor:
+        """One optimizer step on `batch` of task `name` ('sap...' / 'mlm...': the part before '_' selects the task, as
+        train_r2r.py:235).  Returns the device loss tensor (no host sync)."""
+        task = name.split("_")[0]
+        if task == "sap":
+            st = self._sap_step(batch)
+            st.step_no = self.global_step
+            st.run_eager()
+            ids = st.inp["txt_ids"]
+        elif task == "mlm":
+            st = MlmStep(self.model, batch, dropout=self.dropout, drop_seed=self.seed)
+            st.step_no = self.global_step
+            st.run_eager()
+            ids = None
+        else:
+            raise ValueError(f"unknown task {task!r}: this fork pre-trains with 'mlm' and 'sap' (pretrain_cmt.py:141-163,223-283)")
+        loss = st.loss.clone()
+        if self.distributed:
+            red = self.reducers[task]
+            for i in range(len(red.ranges)):
+                red.reduce_bucket(i)
+            if ids is not None:
+                red.reduce_sparse_rows(ids)
+            red.finish()
+        self.global_step += 1
+        self.sched.step(self.global_step)
+        self.opt.step()
+        if task == "mlm":
+            torch.cuda.current_stream().synchronize()      # the per-batch MLM step object is released: its buffers must be idle
+            st.close()
+        self.task_losses.setdefault(name, []).append(loss)
+        return loss
+
+    def run(self, num_steps: int):
+        it = iter(self.meta)
+        out = []
+        for _ in range(num_steps):
+            name, batch = next(it)
+            out.append((name, self.train_step(name, batch)))
+        return out
+
+    def close(self):
+        for st in self._sap.values():
+            st.close()
+        self._sap.clear()

@@ -150,6 +150,36 @@ class PlannerStep:
         self.graphs = []
         self.stream = None
 
+    def shape_key(self):
+        return (self.B, self.Lt, self.Bp, self.V, self.G)
+
+    @staticmethod
+    def batch_shape_key(batch):
+        B, Lt = batch["txt_ids"].shape
+        Bp, V = batch["rgb_fts"].shape[:2]
+        return (B, Lt, Bp, V, batch["gmap_step_ids"].shape[1])
+
+    def load_batch(self, batch: Dict[str, torch.Tensor]):
+        """Refill the preallocated device inputs with another batch of the SAME shapes (the stash / workspace buffers and the
+        streams are reused; only the small CSR index arrays of the node aggregation are rebuilt)."""
+        if self.batch_shape_key(batch) != self.shape_key():
+            raise ValueError(f"batch shapes {self.batch_shape_key(batch)} differ from this step's {self.shape_key()}")
+        names = {"txt_ids": "txt_ids", "txt_masks": "txt_masks", "rgb": "rgb_fts", "dep": "dep_fts", "loc": "loc_fts", "nav": "nav_types",
+                 "view_lens": "view_lens", "step_ids": "gmap_step_ids", "pos": "gmap_pos_fts", "gmask": "gmap_masks",
+                 "visited": "gmap_visited_masks", "dists": "gmap_pair_dists", "labels": "labels"}
+        for k, src in names.items():
+            t = self.inp[k]
+            t.copy_(batch[src].to(t.dtype), non_blocking=True)
+        dev = self.eng.device
+        if "traj" in batch:
+            from .graph_inputs import pack_traj_csr
+            tr = batch["traj"]
+            f, b = pack_traj_csr(tr["traj_vp_lens"], tr["traj_vpids"], tr["traj_cand_vpids"], tr["gmap_vpids"], self.V, self.G)
+        else:
+            f, b = build_node_csr(batch["view_lens"].cpu(), self.V, self.G)
+        self.csr_f = tuple(x.to(dev) for x in f)
+        self.csr_b = tuple(x.to(dev) for x in b)
+
     # ------------------------------------------------------------------------------------------
     def enqueue_main(self, s: int, backward: bool = True, join_pano: bool = True):
         """Everything except the text-encoder backward: weight refresh, zero grads, the three forwards, loss and the

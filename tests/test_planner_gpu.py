@@ -364,3 +364,38 @@ def test_mlm_pretraining_step_matches_oracle(dtype, atol, rel):
         for k, g in grads.items():
             err = (mine[k] - g).abs().max().item()
             assert err < atol + rel * g.abs().max().item(), f"train {k}: {err}"
+
+
+def test_pretrain_driver_mixes_sap_and_mlm_steps_and_trains():
+    """SURVEY.md §8f N3 remainder: MetaLoader task mixing + per-task steps + warm-up-linear LR + fused AdamW
+    (train_r2r.py:229-300).  The first step of each task reproduces the oracle's loss for that batch (eval-mode dropout so the
+    numbers are comparable), the schedule drives the optimizer's rate, same-shape SAP batches reuse one preallocated step, and
+    the losses on the (two-batch) synthetic streams go down."""
+    from oracle.make_golden_pretrain import make_case
+    from etpnav_amd.pretrain import PretrainDriver
+    from etpnav_amd.synthetic import make_sap_batch
+    from etpnav_amd.optim import get_lr_sched
+    cfg, P, mlm_batch = make_case()
+    sap_batches = [make_sap_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, B=3, L=19, T=3, V=9, n_cand=4,
+                                  seed=70 + i, ragged=False) for i in range(2)]
+    model = build_model(cfg, P, torch.float32)
+    g = torch.Generator().manual_seed(1)
+    drv = PretrainDriver(model, {"mlm": ([mlm_batch], 1, lambda e: None), "sap": (sap_batches, 1, lambda e: None)},
+                         learning_rate=2e-4, warmup_steps=4, num_train_steps=40, dropout=None, generator=g)
+    ref = {"sap": po.sap_step_with_grads(P, cfg, sap_batches[0])[0]["loss"].item(),
+           "mlm": po.mlm_step_with_grads(P, cfg, mlm_batch)[0]["loss"].item()}
+    seen, first = {"sap": [], "mlm": []}, None
+    for k, (name, loss) in enumerate(drv.run(24)):
+        seen[name].append(loss)
+        if k == 0:
+            first = name
+            assert abs(loss.item() - ref[name]) < 3e-4, (name, loss.item(), ref[name])     # untouched weights: oracle parity
+        assert drv.opt.lr == pytest.approx(get_lr_sched(k + 1, 2e-4, 4, 40))
+    torch.cuda.synchronize()
+    assert len(seen["sap"]) >= 4 and len(seen["mlm"]) >= 4
+    assert len(drv._sap) == 1                                           # both SAP batches share one preallocated step
+    for name, ls in seen.items():
+        v = [x.item() for x in ls]
+        assert all(torch.isfinite(torch.tensor(v))), (name, v)
+        assert sum(v[-2:]) / 2 < sum(v[:2]) / 2, (name, v)               # it trains
+    drv.close()
