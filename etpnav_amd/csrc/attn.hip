@@ -455,21 +455,57 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnKArgs a) {
 // layer backward at B = 16, L = 512) with three kernels whose HBM traffic is Q, K, V, O, dO in and ctx / dQ, dK, dV out.
 // =========================================================================================================
 constexpr int FBQ = 64, FBKV = 128;
-struct FlashLds {
-  static constexpr int PQ = Nat<bf16_t, 64>::PITCH, PP = Nat<bf16_t, FBKV>::PITCH;
-  static constexpr int Q_OFF = 0, DO_OFF = FBQ * PQ, K_OFF = 2 * FBQ * PQ, V_OFF = K_OFF + FBKV * PQ, T_OFF = V_OFF + FBKV * PQ;
+constexpr int FBKV2 = 64;       // key tile of the dK/dV kernel: half the accumulators -> two to three workgroups per CU
+template <int BKV> struct FlashLdsT {
+  static constexpr int PQ = Nat<bf16_t, 64>::PITCH, PP = Nat<bf16_t, BKV>::PITCH;
+  static constexpr int Q_OFF = 0, DO_OFF = FBQ * PQ, K_OFF = 2 * FBQ * PQ, V_OFF = K_OFF + BKV * PQ, T_OFF = V_OFF + BKV * PQ;
   static constexpr int RS_OFF = T_OFF + FBQ * PP;              // row max / row sum exchange [2][2][FBQ] fp32 (also D)
   static constexpr int TOTAL = RS_OFF + 4 * FBQ * 4;
-  static_assert(FBKV * 68 * 4 <= V_OFF, "dK/dV fp32 staging [128][68] sits over the Q, dO and K tiles");
-  static_assert(FBQ * 68 * 4 <= T_OFF - K_OFF, "ctx/dQ fp32 staging [64][68] sits over the K and V tiles");
+  static_assert(BKV * 68 * 4 <= T_OFF, "dK/dV fp32 staging [BKV][68] sits over the Q, dO, K (and V) tiles");
+  static_assert(FBQ * 68 * 4 <= T_OFF - K_OFF || BKV < 128, "ctx/dQ fp32 staging [64][68] sits over the K and V tiles");
 };
+using FlashLds = FlashLdsT<FBKV>;
+
+// global -> registers now, registers -> LDS tile later: the next tile's rows travel while the current tile is computed
+template <typename T, int ROWS, int COLS> struct NatRegs {
+  static constexpr int N = (ROWS * Nat<T, COLS>::CPR + 255) / 256;
+  uint4 v[N];
+};
+template <typename T, int ROWS, int COLS>
+__device__ __forceinline__ void nat_fetch(NatRegs<T, ROWS, COLS>& r, const T* __restrict__ g, long ld, int rows_valid, int cols_valid,
+                                          int tid) {
+  using N = Nat<T, COLS>;
+  constexpr int TOTAL = ROWS * N::CPR;
+#pragma unroll
+  for (int j = 0; j < NatRegs<T, ROWS, COLS>::N; ++j) {
+    const int q = tid + j * 256;
+    const int qq = (TOTAL % 256 != 0 && q >= TOTAL) ? TOTAL - 1 : q;
+    const int row = qq / N::CPR, c = (qq % N::CPR) * N::EPC;
+    const bool ok = row < rows_valid && c < cols_valid;
+    const int rc = min(row, max(rows_valid - 1, 0)), cc = min(c, cols_valid - N::EPC);
+    uint4 v = *reinterpret_cast<const uint4*>(g + (long)rc * ld + cc);
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    r.v[j] = v;
+  }
+}
+template <typename T, int ROWS, int COLS>
+__device__ __forceinline__ void nat_commit(char* lds, const NatRegs<T, ROWS, COLS>& r, int tid) {
+  using N = Nat<T, COLS>;
+  constexpr int TOTAL = ROWS * N::CPR;
+#pragma unroll
+  for (int j = 0; j < NatRegs<T, ROWS, COLS>::N; ++j) {
+    const int q = tid + j * 256;
+    if (TOTAL % 256 != 0 && q >= TOTAL) break;
+    *reinterpret_cast<uint4*>(lds + (q / N::CPR) * N::PITCH + (q % N::CPR) * 16) = r.v[j];
+  }
+}
 
 // additive key term of this lane's NT columns of the key tile starting at k0 (columns >= Lk: excluded)
-template <int NT>
+template <int NT, int BKV>
 __device__ __forceinline__ void key_terms(float (&kadd)[NT], const uint8_t* km, int k0, int Lk, int mask_mode, int wc, int i) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int col = k0 + wc * (FBKV / 2) + n * 16 + i;
+    const int col = k0 + wc * (BKV / 2) + n * 16 + i;
     float v = 0.f;
     if (col >= Lk) v = -INFINITY;
     else if (km && !km[col]) v = mask_mode ? -INFINITY : -10000.0f;
@@ -498,6 +534,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const AttnKArgs a) {
   float* lse = reinterpret_cast<float*>(a.P) + (long)bh * a.Lq + q0;
   const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
 
+  NatRegs<T, FBKV, 64> rk, rv;
+  nat_fetch<T, FBKV, 64>(rk, Kg, a.ldk, min(FBKV, a.Lk), 64, tid);
+  nat_fetch<T, FBKV, 64>(rv, Vg, a.ldv, min(FBKV, a.Lk), 64, tid);
   nat_load<T, FBQ, 64>(qt, Qg, a.ldq, Lq, 64, tid);
   float m_run[MT][4], l_run[MT][4];
   f32x4_t oc[MT][2];
@@ -508,12 +547,16 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const AttnKArgs a) {
     for (int r = 0; r < 4; ++r) { m_run[m][r] = -INFINITY; l_run[m][r] = 0.f; }
 
   for (int k0 = 0; k0 < a.Lk; k0 += FBKV) {
-    const int nk = min(FBKV, a.Lk - k0);
     __syncthreads();                                   // the previous tile's P.V is done with vt / pt
-    nat_load<T, FBKV, 64>(kt, Kg + (long)k0 * a.ldk, a.ldk, nk, 64, tid);
-    nat_load<T, FBKV, 64>(vt, Vg + (long)k0 * a.ldv, a.ldv, nk, 64, tid);
+    nat_commit<T, FBKV, 64>(kt, rk, tid);
+    nat_commit<T, FBKV, 64>(vt, rv, tid);
+    if (k0 + FBKV < a.Lk) {                            // next tile's rows travel while this one is computed
+      const int nn = min(FBKV, a.Lk - k0 - FBKV);
+      nat_fetch<T, FBKV, 64>(rk, Kg + (long)(k0 + FBKV) * a.ldk, a.ldk, nn, 64, tid);
+      nat_fetch<T, FBKV, 64>(rv, Vg + (long)(k0 + FBKV) * a.ldv, a.ldv, nn, 64, tid);
+    }
     float kadd[NT];
-    key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+    key_terms<NT, FBKV>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
     __syncthreads();
     f32x4_t sc[MT][NT];
     acc_zero(sc);
@@ -591,9 +634,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const AttnKArgs a) {
   store_rows64<T, FBQ>(ct, Cg, a.ldc, Lq, tid);
 }
 
-// P = exp(alpha*S + key term - lse), the dropout multiplier and dS = P*(dP*mult - D) for one 64x128 tile of scores;
-// `pd_out` (P*mult) and `ds_out` may alias sc / dp register arrays of the caller
-template <int MT, int NT>
+// P = exp(alpha*S + key term - lse), the dropout multiplier and dS = P*(dP*mult - D) for one 64 x BKV tile of scores;
+// on return sc holds the DROPPED probabilities (dV operand) and dp the score gradient (dQ / dK operand)
+template <int MT, int NT, int BKV>
 __device__ __forceinline__ void flash_bwd_tile(f32x4_t (&sc)[MT][NT], f32x4_t (&dp)[MT][NT], const float (&kadd)[NT],
                                                const float (&lse_r)[MT][4], const float (&d_r)[MT][4], const bool (&row_ok)[MT][4],
                                                const AttnKArgs& a, uint32_t bh, int q0, int k0, int wr, int wc, int i, int g) {
@@ -605,18 +648,18 @@ __device__ __forceinline__ void flash_bwd_tile(f32x4_t (&sc)[MT][NT], f32x4_t (&
       const uint32_t rbase = (bh * (uint32_t)a.Lq + (uint32_t)(q0 + row)) * (uint32_t)a.Lk + (uint32_t)k0;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int col = wc * (FBKV / 2) + n * 16 + i;
+        const int col = wc * (BKV / 2) + n * 16 + i;
         float p = row_ok[m][r] ? __expf(sc[m][n][r] * a.alpha + kadd[n] - lse_r[m][r]) : 0.f;
         float mult = 1.f;
         if (a.drop.p > 0.f) mult = drop_mult(a.drop.seed, rbase + col, a.drop.p, a.drop.inv_keep);
         const float ds = p * (dp[m][n][r] * mult - d_r[m][r]);
-        sc[m][n][r] = p * mult;        // dropped probabilities (dV operand)
-        dp[m][n][r] = ds;              // score gradient (dQ / dK operand)
+        sc[m][n][r] = p * mult;
+        dp[m][n][r] = ds;
       }
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int BKV>
 __device__ __forceinline__ void acc_to_tile(const f32x4_t (&x)[MT][NT], char* tile, int PP, int wr, int wc, int i, int g) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -625,7 +668,7 @@ __device__ __forceinline__ void acc_to_tile(const f32x4_t (&x)[MT][NT], char* ti
       const int row = wr * (FBQ / 2) + m * 16 + g * 4 + r;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(tile + row * PP) + wc * (FBKV / 2) + n * 16 + i, x[m][n][r]);
+        Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(tile + row * PP) + wc * (BKV / 2) + n * 16 + i, x[m][n][r]);
     }
 }
 
@@ -651,6 +694,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const AttnKArgs a, co
   float* delta = reinterpret_cast<float*>(a.P) + (long)gridDim.x / a.nq * a.Lq + (long)bh * a.Lq + q0;     // D, behind all lse rows
   const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
 
+  NatRegs<T, FBKV, 64> rk, rv;
+  nat_fetch<T, FBKV, 64>(rk, Kg, a.ldk, min(FBKV, a.Lk), 64, tid);
+  nat_fetch<T, FBKV, 64>(rv, Vg, a.ldv, min(FBKV, a.Lk), 64, tid);
   nat_load<T, FBQ, 64>(qt, Qg, a.ldq, Lq, 64, tid);
   nat_load<T, FBQ, 64>(dot, Dg, a.ldd, Lq, 64, tid);
   nat_load<T, FBQ, 64>(kt, Og, ldo, Lq, 64, tid);                  // O parked in the K tile for the row dots
@@ -680,19 +726,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const AttnKArgs a, co
   f32x4_t dq[MT][2];
   acc_zero(dq);
   for (int k0 = 0; k0 < a.Lk; k0 += FBKV) {
-    const int nk = min(FBKV, a.Lk - k0);
-    __syncthreads();
-    nat_load<T, FBKV, 64>(kt, Kg + (long)k0 * a.ldk, a.ldk, nk, 64, tid);
-    nat_load<T, FBKV, 64>(vt, Vg + (long)k0 * a.ldv, a.ldv, nk, 64, tid);
+    __syncthreads();                                   // previous tile's dQ product is done with kt / dst (first pass: the O rows)
+    nat_commit<T, FBKV, 64>(kt, rk, tid);
+    nat_commit<T, FBKV, 64>(vt, rv, tid);
+    if (k0 + FBKV < a.Lk) {
+      const int nn = min(FBKV, a.Lk - k0 - FBKV);
+      nat_fetch<T, FBKV, 64>(rk, Kg + (long)(k0 + FBKV) * a.ldk, a.ldk, nn, 64, tid);
+      nat_fetch<T, FBKV, 64>(rv, Vg + (long)(k0 + FBKV) * a.ldv, a.ldv, nn, 64, tid);
+    }
     float kadd[NT];
-    key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+    key_terms<NT, FBKV>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
     __syncthreads();
     f32x4_t sc[MT][NT], dp[MT][NT];
     acc_zero(sc); acc_zero(dp);
     tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (FBKV / 2), lane);
     tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(dp, dot, wr * (FBQ / 2), vt, wc * (FBKV / 2), lane);
-    flash_bwd_tile<MT, NT>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
-    acc_to_tile<MT, NT>(dp, dst, PP, wr, wc, i, g);
+    flash_bwd_tile<MT, NT, FBKV>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
+    acc_to_tile<MT, NT, FBKV>(dp, dst, PP, wr, wc, i, g);
     __syncthreads();
     tile_mma<T, MT, 2, FBKV / 32, false, true, PP, PQ>(dq, dst, wr * (FBQ / 2), kt, wc * 32, lane);
   }
@@ -703,18 +753,20 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const AttnKArgs a, co
   store_rows64<T, FBQ>(ct, dQg, a.lddq, Lq, tid);
 }
 
+// one workgroup per (batch, head, BKV keys): K/V tile resident, loops over the query tiles
+template <int BKV>
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const AttnKArgs a, int nkv) {
   using T = bf16_t;
-  using L = FlashLds;
-  constexpr int PQ = L::PQ, PP = L::PP, MT = FBQ / 32, NT = FBKV / 32, MTk = FBKV / 32;
+  using L = FlashLdsT<BKV>;
+  constexpr int PQ = L::PQ, PP = L::PP, MT = FBQ / 32, NT = BKV / 32, MTk = BKV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *qt = smem + L::Q_OFF, *dot = smem + L::DO_OFF, *kt = smem + L::K_OFF, *vt = smem + L::V_OFF, *tt = smem + L::T_OFF;
-  float* ct = reinterpret_cast<float*>(smem);                       // staging [128][68] fp32 over Q/dO/K tiles (34.8 KB)
+  float* ct = reinterpret_cast<float*>(smem);                       // staging [BKV][68] fp32 over the Q / dO / K tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x / nkv, k0 = (blockIdx.x % nkv) * FBKV;
+  const int bh = blockIdx.x / nkv, k0 = (blockIdx.x % nkv) * BKV;
   const int b = bh / a.nh, h = bh % a.nh;
-  const int nk = min(FBKV, a.Lk - k0);
+  const int nk = min(BKV, a.Lk - k0);
   const T* Qg = reinterpret_cast<const T*>(a.Q) + (long)b * a.Lq * a.ldq + h * 64;
   const T* Kg = reinterpret_cast<const T*>(a.K) + ((long)b * a.Lk + k0) * a.ldk + h * 64;
   const T* Vg = reinterpret_cast<const T*>(a.V) + ((long)b * a.Lk + k0) * a.ldv + h * 64;
@@ -723,17 +775,17 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const AttnKArgs a, i
   const float* delta = reinterpret_cast<const float*>(a.P) + (long)gridDim.x / nkv * a.Lq + (long)bh * a.Lq;
   const uint8_t* km = a.keymask ? a.keymask + (long)b * a.Lk : nullptr;
 
-  nat_load<T, FBKV, 64>(kt, Kg, a.ldk, nk, 64, tid);
-  nat_load<T, FBKV, 64>(vt, Vg, a.ldv, nk, 64, tid);
+  NatRegs<T, FBQ, 64> rq, rd;
+  nat_fetch<T, FBQ, 64>(rq, Qg, a.ldq, min(FBQ, a.Lq), 64, tid);
+  nat_fetch<T, FBQ, 64>(rd, Dg, a.ldd, min(FBQ, a.Lq), 64, tid);
+  nat_load<T, BKV, 64>(kt, Kg, a.ldk, nk, 64, tid);
+  nat_load<T, BKV, 64>(vt, Vg, a.ldv, nk, 64, tid);
   float kadd[NT];
-  key_terms<NT>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
+  key_terms<NT, BKV>(kadd, km, k0, a.Lk, a.mask_mode, wc, i);
   f32x4_t dk[MTk][2], dv[MTk][2];
   acc_zero(dk); acc_zero(dv);
   for (int q0 = 0; q0 < a.Lq; q0 += FBQ) {
     const int nq = min(FBQ, a.Lq - q0);
-    __syncthreads();                                   // the previous query tile's products are done with qt / dot / tt
-    nat_load<T, FBQ, 64>(qt, Qg + (long)q0 * a.ldq, a.ldq, nq, 64, tid);
-    nat_load<T, FBQ, 64>(dot, Dg + (long)q0 * a.ldd, a.ldd, nq, 64, tid);
     float lse_r[MT][4], d_r[MT][4];
     bool row_ok[MT][4];
 #pragma unroll
@@ -745,30 +797,38 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const AttnKArgs a, i
         lse_r[m][r] = row < nq ? lse[q0 + row] : 0.f;
         d_r[m][r] = row < nq ? delta[q0 + row] : 0.f;
       }
+    __syncthreads();                                   // the previous query tile's products are done with qt / dot / tt
+    nat_commit<T, FBQ, 64>(qt, rq, tid);
+    nat_commit<T, FBQ, 64>(dot, rd, tid);
+    if (q0 + FBQ < a.Lq) {                             // next query tile travels while this one is computed
+      const int nn = min(FBQ, a.Lq - q0 - FBQ);
+      nat_fetch<T, FBQ, 64>(rq, Qg + (long)(q0 + FBQ) * a.ldq, a.ldq, nn, 64, tid);
+      nat_fetch<T, FBQ, 64>(rd, Dg + (long)(q0 + FBQ) * a.ldd, a.ldd, nn, 64, tid);
+    }
     __syncthreads();
     f32x4_t sc[MT][NT], dp[MT][NT];
     acc_zero(sc); acc_zero(dp);
-    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (FBKV / 2), lane);
-    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(dp, dot, wr * (FBQ / 2), vt, wc * (FBKV / 2), lane);
-    flash_bwd_tile<MT, NT>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
-    acc_to_tile<MT, NT>(sc, tt, PP, wr, wc, i, g);                 // dropped P
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(sc, qt, wr * (FBQ / 2), kt, wc * (BKV / 2), lane);
+    tile_mma<T, MT, NT, 2, false, false, PQ, PQ>(dp, dot, wr * (FBQ / 2), vt, wc * (BKV / 2), lane);
+    flash_bwd_tile<MT, NT, BKV>(sc, dp, kadd, lse_r, d_r, row_ok, a, (uint32_t)bh, q0, k0, wr, wc, i, g);
+    acc_to_tile<MT, NT, BKV>(sc, tt, PP, wr, wc, i, g);            // dropped P
     __syncthreads();
-    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dv, tt, wr * (FBKV / 2), dot, wc * 32, lane);     // dV += (P*mask)^T dO
+    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dv, tt, wr * (BKV / 2), dot, wc * 32, lane);     // dV += (P*mask)^T dO
     __syncthreads();
-    acc_to_tile<MT, NT>(dp, tt, PP, wr, wc, i, g);                 // dS over the same tile
+    acc_to_tile<MT, NT, BKV>(dp, tt, PP, wr, wc, i, g);            // dS over the same tile
     __syncthreads();
-    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dk, tt, wr * (FBKV / 2), qt, wc * 32, lane);      // dK += dS^T Q
+    tile_mma<T, MTk, 2, FBQ / 32, true, true, PP, PQ>(dk, tt, wr * (BKV / 2), qt, wc * 32, lane);      // dK += dS^T Q
   }
   __syncthreads();
   T* dKg = reinterpret_cast<T*>(a.dK) + ((long)b * a.Lk + k0) * a.lddk + h * 64;
   T* dVg = reinterpret_cast<T*>(a.dV) + ((long)b * a.Lk + k0) * a.lddv + h * 64;
-  acc_to_lds(dv, ct, 68, wr * (FBKV / 2), wc * 32, 1.0f, lane);
+  acc_to_lds(dv, ct, 68, wr * (BKV / 2), wc * 32, 1.0f, lane);
   __syncthreads();
-  store_rows64<T, FBKV>(ct, dVg, a.lddv, nk, tid);
+  store_rows64<T, BKV>(ct, dVg, a.lddv, nk, tid);
   __syncthreads();
-  acc_to_lds(dk, ct, 68, wr * (FBKV / 2), wc * 32, a.alpha, lane);
+  acc_to_lds(dk, ct, 68, wr * (BKV / 2), wc * 32, a.alpha, lane);
   __syncthreads();
-  store_rows64<T, FBKV>(ct, dKg, a.lddk, nk, tid);
+  store_rows64<T, BKV>(ct, dKg, a.lddk, nk, tid);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -836,7 +896,8 @@ static int flash_attr() {
   if (done) return ETP_OK;
   ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
   ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
-  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
+  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<FBKV2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FlashLdsT<FBKV2>::TOTAL));
   done = true;
   return ETP_OK;
 }
@@ -859,10 +920,10 @@ int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, lo
   k.P = const_cast<void*>(P); k.dctx = dctx; k.ldd = ldd;
   k.dQ = dQ; k.dK = dK; k.dV = dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv;
   k.nq = (a.Lq + FBQ - 1) / FBQ;
-  const int nkv = (a.Lk + FBKV - 1) / FBKV;
+  const int nkv = (a.Lk + FBKV2 - 1) / FBKV2;
   ETP_LAUNCH(flash_bwd_dq_kernel, dim3(a.B * nh * k.nq), dim3(256), FlashLds::TOTAL, st, k, a.O, a.ldo);
   ETP_CHECK_LAUNCH("flash_bwd_dq");
-  ETP_LAUNCH(flash_bwd_dkv_kernel, dim3(a.B * nh * nkv), dim3(256), FlashLds::TOTAL, st, k, nkv);
+  ETP_LAUNCH(flash_bwd_dkv_kernel<FBKV2>, dim3(a.B * nh * nkv), dim3(256), FlashLdsT<FBKV2>::TOTAL, st, k, nkv);
   ETP_CHECK_LAUNCH("flash_bwd_dkv");
   return ETP_OK;
 }

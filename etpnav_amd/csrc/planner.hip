@@ -53,7 +53,7 @@ struct etp_planner {
   float p_hidden = 0.f, p_attn = 0.f, p_env = 0.f, p_head = 0.f;
   // 1: etp_nav_bwd / etp_pano_bwd leave their weight-gradient GEMMs running on the aux stream instead of joining them
   // before returning; the caller joins later (etp_txt_bwd* always joins, or etp_planner_join_aux)
-  bool lazy_join = false;
+  int lazy_join = 0;          // 0: every backward entry point joins; 1: nav / pano leave their leaf work running; 2: also text ranges that stop above layer 0
   // 1: weight-gradient GEMMs STORE into the matrix region of the gradient arena instead of accumulating (no fp32 read of
   // C, and the caller zeroes only the vector/table tail [n_matrix, total) per step).  Valid when every matrix is touched by
   // exactly one weight-gradient product between two optimizer steps (one planner step per optimizer step).
@@ -697,7 +697,7 @@ int etp_planner_set_aux2_stream(etp_planner* p, etp_stream_t aux2) {
 }
 int etp_planner_set_lazy_join(etp_planner* p, int lazy) {
   ETP_REQUIRE(p, "null planner");
-  p->lazy_join = lazy != 0;
+  p->lazy_join = lazy < 0 ? 0 : (lazy > 2 ? 2 : lazy);
   return ETP_OK;
 }
 int etp_planner_set_grad_overwrite(etp_planner* p, int on) {
@@ -810,6 +810,9 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
                            p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st,
                            hid(c, MODE_TXT, 0, SITE_EMBED)));
+  // a range that stops above layer 0 is followed by another one: with lazy level 2 its weight gradients keep running on the
+  // side stream (the final range, or etp_planner_join_aux, joins them)
+  if (p->lazy_join >= 2 && layer_lo > 0) return flush_side(c);
   return join_wgrads(c);
 }
 int etp_txt_bwd(etp_planner* p, const float* dout, const int64_t* ids, const uint8_t* mask, int B, int L, void* stash, void* ws,

@@ -224,6 +224,7 @@ class PretrainDriver:
                 ranges, sparse = dp.task_grad_ranges(model, task)
                 self.reducers[task] = dp.GradReducer(model.flat_grads, ranges, sparse_rows=sparse)
         self.task_losses = {}
+        self.lr_history = []
 
     def _sap_step(self, batch):
         from .step import PlannerStep
@@ -264,7 +265,7 @@ class PretrainDriver:
                 red.reduce_sparse_rows(ids)
             red.finish()
         self.global_step += 1
-        self.sched.step(self.global_step)
+        self.lr_history.append(self.sched.step(self.global_step))
         self.opt.step()
         if task == "mlm":
             torch.cuda.current_stream().synchronize()      # the per-batch MLM step object is released: its buffers must be idle

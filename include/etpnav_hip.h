@@ -255,7 +255,8 @@ int etp_planner_set_aux2_stream(etp_planner* p, etp_stream_t aux2);
 /* With an aux stream: lazy = 1 lets etp_nav_bwd* / etp_pano_bwd return WITHOUT joining their weight-gradient GEMMs back
  * (nothing downstream of them reads weight gradients), so the text backward does not wait for the navigation weight
  * gradients; the gradients are complete in `stream` order only after a later joining call: etp_txt_bwd / etp_txt_bwd_range
- * / etp_nav_kv_bwd (always join) or etp_planner_join_aux.  Default 0: every backward entry point joins before it returns. */
+ * / etp_nav_kv_bwd (always join) or etp_planner_join_aux.  Default 0: every backward entry point joins before it returns.
+ * lazy = 2: additionally etp_txt_bwd_range calls that stop above layer 0 do not join (the next range continues the chain). */
 int etp_planner_set_lazy_join(etp_planner* p, int lazy);
 /* on = 1: weight-gradient products STORE into the matrix region [0, etp_planner_matrix_elems) of the gradient arena instead of
  * accumulating (torch's `.grad +=`, the default): no fp32 read of the old gradient and no per-step zeroing of that region.

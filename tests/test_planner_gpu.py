@@ -390,7 +390,7 @@ def test_pretrain_driver_mixes_sap_and_mlm_steps_and_trains():
         if k == 0:
             first = name
             assert abs(loss.item() - ref[name]) < 3e-4, (name, loss.item(), ref[name])     # untouched weights: oracle parity
-        assert drv.opt.lr == pytest.approx(get_lr_sched(k + 1, 2e-4, 4, 40))
+        assert drv.lr_history[k] == pytest.approx(get_lr_sched(k + 1, 2e-4, 4, 40))     # rate used by optimizer step k+1
     torch.cuda.synchronize()
     assert len(seen["sap"]) >= 4 and len(seen["mlm"]) >= 4
     assert len(drv._sap) == 1                                           # both SAP batches share one preallocated step

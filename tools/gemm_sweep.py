@@ -63,7 +63,23 @@ def time_variant(kind, M, N, K, variant, iters=24):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def ksweep_cold_vs_warm():
+    """Fixed cost of a launch with cold (6 rotating operand sets) vs warm (one set, L2/MALL-resident) operands."""
+    global NSETS
+    out = {}
+    for nsets in (6, 1):
+        NSETS = nsets
+        for M in (2560, 512):
+            for K in (128, 768, 3072):
+                out[f"nsets{nsets}:fwd_s:{M}x768x{K}"] = round(time_variant("fwd_s", M, 768, K, "64s3"), 2)
+                out[f"nsets{nsets}:fwd:{M}x768x{K}"] = round(time_variant("fwd", M, 768, K, "64s3"), 2)
+    os.environ["ETP_GEMM_TILE"] = ""
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if os.environ.get("KSWEEP_ONLY"):
+        return ksweep_cold_vs_warm()
     H, I = 768, 3072
     shapes = []
     for M in (2560, 1152, 512):                    # text / panorama / node tokens of config 2
