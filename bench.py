@@ -199,6 +199,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock settle: the boxes idle at ~450 MHz and ramp under load; a few untimed steps in front of the W warm-up steps keep a
+    # short --warmup from timing the ramp (disclosed in config.settle_steps; not part of W or K)
+    settle = 30
+    for _ in range(settle):
+        one_step()
+    barrier()
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -311,7 +317,7 @@ def main():
                                    + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
                        "global_batch": w["B"] * world, "parallelism": f"dp{world}",
-                       "graph": use_graph, "mode": args.mode,
+                       "graph": use_graph, "mode": args.mode, "settle_steps": settle,
                        "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
                                     "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
                        "grad_comm_dtype": args.comm_dtype if world > 1 else None},

@@ -130,6 +130,10 @@ class GradReducer:
         rows = (table.index_select(0, ids) * first[:, None]).to(self.comm_dtype)
         all_ids = [torch.empty_like(ids) for _ in range(self.world)]
         all_rows = [torch.empty_like(rows) for _ in range(self.world)]
+        if self.native is not None:
+            # two communicators (the library's and torch's) must not have collectives in flight at the same time: order
+            # torch's gathers after every bucket issued so far (NCCL/RCCL: concurrent communicators can deadlock)
+            self.native.wait()
         dist.all_gather(all_ids, ids, group=self.group)
         dist.all_gather(all_rows, rows, group=self.group)
         table.index_fill_(0, ids, 0.0)                                    # own rows come back inside the gathered block
