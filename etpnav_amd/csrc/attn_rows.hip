@@ -1,0 +1,479 @@
+// Register-resident attention for the planner's short sequences (bf16, head dim 64, Lq, Lk <= 128) on gfx950.
+//
+//   ctx = dropout(softmax(alpha * Q K^T + keymask + (w*dist + b))) V     BertSelfAttention.forward vilmodel_cmt.py:103-141,
+//                                                                        BertOutAttention.forward :325-352 (cross attention),
+//                                                                        GraphLXRTXLayer :721-741 (sprel bias on the graph),
+//                                                                        nn.MultiheadAttention (common/transformer.py:138)
+//
+// The tile kernels of attn.hip spend their time in VALU work around the MFMAs (about 2 700 instructions per wavefront for an
+// 80x80 head: scores leave the accumulators through LDS as single bf16 values, the row statistics travel through 16-lane
+// shuffles and two workgroup barriers, the probabilities are written and re-read).  Here every product is arranged so that its
+// RESULT is already the operand layout of the next one and nothing but K, V (and Q, dO in backward) touches LDS:
+//
+//   * one wavefront owns 16 query rows and ALL keys.  S^T = K Q^T (v_mfma 16x16x32: A = K rows from LDS, B = Q rows straight
+//     from global) leaves lane (i, g) with keys 16n+4g..+3 of query i: the softmax statistics of a query are an in-lane
+//     reduction plus two cross-lane steps, and the four probabilities of a lane are exactly the B operand (k = 4g..4g+3, column i)
+//     of the k=16 MFMA.  O^T = V^T P^T then takes V through ds_read_b64_tr_b16 and P from REGISTERS; its result (4
+//     consecutive head-dim values of query i per lane) crosses a 2 KB wave-private LDS strip so that global sees full 128-byte
+//     rows.  One workgroup barrier (K/V staged), no probability tile.
+//   * the probabilities are not written: the forward stores lse = max + log(sum) per query row (fp32, in the front of the
+//     probability buffer, the convention of the streaming kernels) and the backward recomputes P = exp(s - lse) on the MFMA
+//     accumulators.  Backward, one workgroup per (batch, head), Q, dO, K, V tiles resident in LDS:
+//       role A  (wavefront = 16 queries)  S^T, dP^T = V dO^T;  D = sum_k P dP;  dS^T = P^T (dP^T - D);  dQ^T = K^T dS^T
+//       role B  (wavefront = 16 keys)     S = Q K^T, dP = dO V^T in the other orientation (query 4g+r, key i), whose P / dS are
+//                                         the B operands of  dV^T = dO^T P  and  dK^T = Q^T dS  (reduction over the queries)
+//     Two barriers (tiles staged; D published).  Dropout is the counter hash of common.h in both directions.
+//
+// Host code at the bottom; the planner (planner.hip attn_fwd_impl / attn_bwd_impl) takes this path for every bf16 attention
+// with both axes <= 128, the tile kernels of attn.hip keep the fp32 (parity) mode.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace etp {
+namespace {
+
+// pitch (bytes) of a natural [rows][64] bf16 tile: 128-byte row + 16-byte pad = 36 dwords, so the 16 rows of a ds_read_b128
+// operand fetch (lane i -> row i) start at 16 different multiples of 4 banks (conflict-free); the 4x16 blocks of
+// ds_read_b64_tr_b16 (rows 36 dwords apart, 2 dwords per lane) are conflict-free within a 16-lane group as well
+constexpr int TP = 144;
+
+struct RowArgs {
+  const bf16_t *Q, *K, *V; long ldq, ldk, ldv;
+  float* lse;                                    // [B*heads*Lq] fp32: row max + log(row sum)
+  bf16_t* ctx; long ldc;
+  int nh, Lq, Lk;
+  Drop drop;                                     // on the probabilities; element index = ((b*heads+h)*Lq + q)*Lk + k
+  const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
+  float alpha;
+  const bf16_t* dO; long ldd;
+  bf16_t *dQ, *dK, *dV; long lddq, lddk, lddv;
+  float *d_sp_w, *d_sp_b;
+};
+
+__device__ __forceinline__ f32x4_t mma32(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma16(const short4_t& a, const short4_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ short4_t pack4(float a, float b, float c, float d) {
+  const uint2 u = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
+  return __builtin_bit_cast(short4_t, u);
+}
+// operand of the k=32 product: 8 consecutive head-dim values (32*s + 8*(lane>>4) + e) of tile row row0 + (lane&15)
+__device__ __forceinline__ uint4 frag(const char* tile, int row0, int s, int lane) {
+  return *reinterpret_cast<const uint4*>(tile + (row0 + (lane & 15)) * TP + s * 64 + (lane >> 4) * 16);
+}
+// A operand of the k=16 product taken DOWN the tile rows: lane (i, g) <- tile[row0 + 4g + e][col0 + i], e = 0..3
+__device__ __forceinline__ short4_t frag_t4(const char* tile, int row0, int col0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const char* p = tile + (row0 + 4 * g + (i >> 2)) * TP + (col0 + (i & 3) * 4) * 2;
+  typedef short4_t __attribute__((address_space(3))) * lds_s4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p));
+}
+
+// global [rows_valid][64] (row stride ld) -> registers -> LDS natural tile [rows_pad][64], zero rows beyond rows_valid.  All
+// loads of all tiles are issued before the first LDS write (one round trip); the workgroup has >= 256 threads.
+template <int MAXROWS> struct TileRegs {
+  static constexpr int N = (MAXROWS * 8 + 255) / 256;
+  uint4 v[N];
+};
+template <int MAXROWS>
+__device__ __forceinline__ void tile_fetch(TileRegs<MAXROWS>& r, const bf16_t* __restrict__ g, long ld, int rows_valid, int rows_pad,
+                                           int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < TileRegs<MAXROWS>::N; ++j) {
+    const int q = tid + j * nthr, row = q >> 3, c = (q & 7) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < rows_pad) {
+      const bool ok = row < rows_valid;
+      v = *reinterpret_cast<const uint4*>(g + (long)min(row, rows_valid - 1) * ld + c);
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    }
+    r.v[j] = v;
+  }
+}
+template <int MAXROWS>
+__device__ __forceinline__ void tile_commit(char* lds, const TileRegs<MAXROWS>& r, int rows_pad, int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < TileRegs<MAXROWS>::N; ++j) {
+    const int q = tid + j * nthr, row = q >> 3;
+    if (row < rows_pad) *reinterpret_cast<uint4*>(lds + row * TP + (q & 7) * 16) = r.v[j];
+  }
+}
+
+// 16 x 64 result tile of a wavefront (accumulators of O^T / dQ^T / dK^T / dV^T: lane (i, g) holds columns 16t+4g..+3 of row
+// i) -> global rows as full 128-byte lines, through a wave-private LDS strip [16][TP] (LDS operations of one wavefront
+// complete in order: no barrier)
+__device__ __forceinline__ void store_rows16(char* strip, const f32x4_t (&acc)[4], float scale, bf16_t* __restrict__ g0, long ld,
+                                             int rows_valid, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    *reinterpret_cast<uint2*>(strip + i * TP + (16 * t + 4 * g) * 2) =
+        make_uint2(pack_bf16(acc[t][0] * scale, acc[t][1] * scale), pack_bf16(acc[t][2] * scale, acc[t][3] * scale));
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = lane + 64 * j, row = c >> 3, part = c & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(strip + row * TP + part * 16);
+    if (row < rows_valid) *reinterpret_cast<uint4*>(g0 + (long)row * ld + part * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float key_term(const uint8_t* km, int col, int Lk, int mask_mode) {
+  if (col >= Lk) return -INFINITY;
+  if (km && !km[col]) return mask_mode ? -INFINITY : -10000.0f;
+  return 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: grid = batch*heads, block = 64 * max(4, ceil(Lq/16)) threads; NKT = ceil(Lk/16)
+template <int NKT, bool HAS_DIST>
+__global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
+  constexpr int BKV = NKT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kt = smem; char* vt = smem + BKV * TP;
+  float* kadd = reinterpret_cast<float*>(smem + 2 * BKV * TP);
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+  char* strip = smem + 2 * BKV * TP + BKV * 4 + wave * 16 * TP;
+
+  TileRegs<BKV> rk, rv;
+  tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
+  tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
+  // this wavefront's 16 queries go straight into the B-operand registers (rows past Lq repeat the last one; never stored)
+  const int q = wave * 16 + i, qc = min(q, a.Lq - 1);
+  const bf16_t* Qr = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * 64 + g * 8;
+  const uint4 qf0 = *reinterpret_cast<const uint4*>(Qr), qf1 = *reinterpret_cast<const uint4*>(Qr + 32);
+  if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+  tile_commit<BKV>(kt, rk, BKV, tid, nthr);
+  tile_commit<BKV>(vt, rv, BKV, tid, nthr);
+  __syncthreads();
+  if (wave * 16 >= a.Lq) return;               // helper wavefronts of a short query axis only staged K / V
+
+  f32x4_t s[NKT];
+#pragma unroll
+  for (int n = 0; n < NKT; ++n) {
+    s[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    s[n] = mma32(frag(kt, 16 * n, 0, lane), qf0, s[n]);
+    s[n] = mma32(frag(kt, 16 * n, 1, lane), qf1, s[n]);
+  }
+  float w = 0.f, b0 = 0.f;
+  const float* drow = nullptr;
+  if constexpr (HAS_DIST) { w = a.sp_w[0]; b0 = a.sp_b[0]; drow = a.dist + ((long)b * a.Lq + qc) * a.Lk; }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NKT; ++n) {
+    const float4 ka4 = *reinterpret_cast<const float4*>(kadd + 16 * n + 4 * g);
+    const float ka[4] = {ka4.x, ka4.y, ka4.z, ka4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s[n][r] * a.alpha + ka[r];
+      if constexpr (HAS_DIST) {
+        const int key = 16 * n + 4 * g + r;
+        if (key < a.Lk) v += w * drow[key] + b0;
+      }
+      s[n][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NKT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __expf(s[n][r] - mx);
+      s[n][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (g == 0 && q < a.Lq) a.lse[(long)bh * a.Lq + q] = mx + __logf(sum);
+
+  short4_t pb[NKT];
+  const bool dropping = a.drop.p > 0.f;
+  const uint32_t rbase = ((uint32_t)bh * a.Lq + q) * (uint32_t)a.Lk;
+#pragma unroll
+  for (int n = 0; n < NKT; ++n) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = s[n][r] * inv;
+      if (dropping) p[r] *= drop_mult(a.drop.seed, rbase + 16 * n + 4 * g + r, a.drop.p, a.drop.inv_keep);
+    }
+    pb[n] = pack4(p[0], p[1], p[2], p[3]);
+  }
+  f32x4_t o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < NKT; ++n)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = mma16(frag_t4(vt, 16 * n, 16 * t, lane), pb[n], o[t]);
+  store_rows16(strip, o, 1.0f, a.ctx + ((long)b * a.Lq + wave * 16) * a.ldc + h * 64, a.ldc, a.Lq - wave * 16, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward: grid = batch*heads, block = 64 * max(4, ceil(Lq/16), ceil(Lk/16)) threads
+struct BwdLds {                                  // byte offsets for BQ = 16*ceil(Lq/16) query rows and BKV key rows
+  int q, d, k, v, kadd, lse, D, red, strip, total;
+  __host__ __device__ BwdLds(int BQ, int BKV) {
+    q = 0; d = BQ * TP; k = 2 * BQ * TP; v = k + BKV * TP; kadd = v + BKV * TP;
+    lse = kadd + BKV * 4; D = lse + 128 * 4; red = D + 128 * 4; strip = red + 16 * 4; total = strip + 8 * 16 * TP;
+  }
+};
+
+template <int NKT, bool HAS_DIST>
+__global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
+  constexpr int BKV = NKT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nqt = (a.Lq + 15) >> 4, BQ = nqt * 16;
+  const BwdLds L(BQ, BKV);
+  char *qt = smem + L.q, *dt = smem + L.d, *kt = smem + L.k, *vt = smem + L.v;
+  float* kadd = reinterpret_cast<float*>(smem + L.kadd);
+  float* lse = reinterpret_cast<float*>(smem + L.lse);
+  float* Dl = reinterpret_cast<float*>(smem + L.D);
+  float* red = reinterpret_cast<float*>(smem + L.red);
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+  const bool dropping = a.drop.p > 0.f;
+  char* strip = smem + L.strip + wave * 16 * TP;
+
+  {
+    TileRegs<128> rq, rd;
+    TileRegs<BKV> rk, rv;
+    tile_fetch<128>(rq, a.Q + (long)b * a.Lq * a.ldq + h * 64, a.ldq, a.Lq, BQ, tid, nthr);
+    tile_fetch<128>(rd, a.dO + (long)b * a.Lq * a.ldd + h * 64, a.ldd, a.Lq, BQ, tid, nthr);
+    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
+    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
+    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+    // padded query rows: lse = +inf makes their recomputed probabilities exactly 0
+    if (tid < 128) lse[tid] = tid < a.Lq ? a.lse[(long)bh * a.Lq + tid] : INFINITY;
+    tile_commit<128>(qt, rq, BQ, tid, nthr);
+    tile_commit<128>(dt, rd, BQ, tid, nthr);
+    tile_commit<BKV>(kt, rk, BKV, tid, nthr);
+    tile_commit<BKV>(vt, rv, BKV, tid, nthr);
+  }
+  float w = 0.f, b0 = 0.f;
+  if constexpr (HAS_DIST) { w = a.sp_w[0]; b0 = a.sp_b[0]; }
+  __syncthreads();
+
+  // ---- role A: 16 queries x all keys -> D, dQ (and the sprel gradients) ----
+  float aw = 0.f, ab = 0.f;
+  if (wave < nqt) {
+    const int q = wave * 16 + i;
+    const bool qok = q < a.Lq;
+    const uint4 qf0 = frag(qt, 16 * wave, 0, lane), qf1 = frag(qt, 16 * wave, 1, lane);
+    const uint4 df0 = frag(dt, 16 * wave, 0, lane), df1 = frag(dt, 16 * wave, 1, lane);
+    const float lse_i = lse[q];
+    const float* drow = HAS_DIST ? a.dist + ((long)b * a.Lq + min(q, a.Lq - 1)) * a.Lk : nullptr;
+    const uint32_t rbase = ((uint32_t)bh * a.Lq + q) * (uint32_t)a.Lk;
+    f32x4_t p[NKT], dp[NKT];
+    float dv4[NKT][4];                            // pairwise distances of this lane's elements (HAS_DIST only)
+    float Dp = 0.f;
+#pragma unroll
+    for (int n = 0; n < NKT; ++n) {
+      f32x4_t st = f32x4_t{0.f, 0.f, 0.f, 0.f}, dpt = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st = mma32(frag(kt, 16 * n, 0, lane), qf0, st);
+      st = mma32(frag(kt, 16 * n, 1, lane), qf1, st);
+      dpt = mma32(frag(vt, 16 * n, 0, lane), df0, dpt);
+      dpt = mma32(frag(vt, 16 * n, 1, lane), df1, dpt);
+      const float4 ka4 = *reinterpret_cast<const float4*>(kadd + 16 * n + 4 * g);
+      const float ka[4] = {ka4.x, ka4.y, ka4.z, ka4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * n + 4 * g + r;
+        float v = st[r] * a.alpha + ka[r];
+        if constexpr (HAS_DIST) {
+          const float dd = (qok && key < a.Lk) ? drow[key] : 0.f;
+          dv4[n][r] = dd;
+          if (key < a.Lk) v += w * dd + b0;
+        }
+        const float pe = __expf(v - lse_i);
+        float dpv = dpt[r];
+        if (dropping) dpv *= drop_mult(a.drop.seed, rbase + key, a.drop.p, a.drop.inv_keep);   // d P = d P_drop * mask/(1-p)
+        p[n][r] = pe; dp[n][r] = dpv;
+        Dp += pe * dpv;
+      }
+    }
+    Dp += __shfl_xor(Dp, 16, 64);
+    Dp += __shfl_xor(Dp, 32, 64);
+    if (g == 0) Dl[q] = Dp;
+    short4_t dsb[NKT];
+#pragma unroll
+    for (int n = 0; n < NKT; ++n) {
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ds[r] = p[n][r] * (dp[n][r] - Dp);
+        if constexpr (HAS_DIST) { aw += ds[r] * dv4[n][r]; ab += ds[r]; }
+      }
+      dsb[n] = pack4(ds[0], ds[1], ds[2], ds[3]);
+    }
+    f32x4_t dq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NKT; ++n)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dq[t] = mma16(frag_t4(kt, 16 * n, 16 * t, lane), dsb[n], dq[t]);
+    store_rows16(strip, dq, a.alpha, a.dQ + ((long)b * a.Lq + wave * 16) * a.lddq + h * 64, a.lddq, a.Lq - wave * 16, lane);
+  }
+  if constexpr (HAS_DIST) {
+    aw = wave_sum(aw); ab = wave_sum(ab);
+    if (lane == 0) { red[wave] = aw; red[8 + wave] = ab; }
+  }
+  __syncthreads();
+  if constexpr (HAS_DIST) {     // d sprel_linear.{weight,bias} (vilmodel_cmt.py:732-736): one atomic pair per workgroup
+    if (tid == 0 && a.d_sp_w != nullptr) {
+      float sw = 0.f, sb = 0.f;
+      for (int k = 0; k < (nthr >> 6); ++k) { sw += red[k]; sb += red[8 + k]; }
+      atomicAdd(a.d_sp_w, sw);
+      atomicAdd(a.d_sp_b, sb);
+    }
+  }
+
+  // ---- role B: 16 keys x all queries -> dK, dV ----
+  if (wave * 16 < a.Lk) {
+    const int key = wave * 16 + i;
+    const bool kok = key < a.Lk;
+    const uint4 kf0 = frag(kt, 16 * wave, 0, lane), kf1 = frag(kt, 16 * wave, 1, lane);
+    const uint4 vf0 = frag(vt, 16 * wave, 0, lane), vf1 = frag(vt, 16 * wave, 1, lane);
+    const float ka = kadd[key];
+    f32x4_t dv[4], dk[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int m = 0; m < nqt; ++m) {
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f}, dpm = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s = mma32(frag(qt, 16 * m, 0, lane), kf0, s);
+      s = mma32(frag(qt, 16 * m, 1, lane), kf1, s);
+      dpm = mma32(frag(dt, 16 * m, 0, lane), vf0, dpm);
+      dpm = mma32(frag(dt, 16 * m, 1, lane), vf1, dpm);
+      const float4 l4 = *reinterpret_cast<const float4*>(lse + 16 * m + 4 * g);
+      const float4 D4 = *reinterpret_cast<const float4*>(Dl + 16 * m + 4 * g);
+      const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+      float pd[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = 16 * m + 4 * g + r;
+        float v = s[r] * a.alpha + ka;
+        if constexpr (HAS_DIST) {
+          if (kok && qq < a.Lq) v += w * a.dist[((long)b * a.Lq + qq) * a.Lk + key] + b0;
+        }
+        const float pe = __expf(v - lr[r]);
+        float mult = 1.0f;
+        if (dropping) mult = drop_mult(a.drop.seed, ((uint32_t)bh * a.Lq + qq) * (uint32_t)a.Lk + key, a.drop.p, a.drop.inv_keep);
+        pd[r] = pe * mult;
+        ds[r] = pe * (dpm[r] * mult - Dr[r]);
+      }
+      const short4_t pb = pack4(pd[0], pd[1], pd[2], pd[3]), dsb = pack4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dv[t] = mma16(frag_t4(dt, 16 * m, 16 * t, lane), pb, dv[t]);
+        dk[t] = mma16(frag_t4(qt, 16 * m, 16 * t, lane), dsb, dk[t]);
+      }
+    }
+    store_rows16(strip, dv, 1.0f, a.dV + ((long)b * a.Lk + wave * 16) * a.lddv + h * 64, a.lddv, a.Lk - wave * 16, lane);
+    store_rows16(strip, dk, a.alpha, a.dK + ((long)b * a.Lk + wave * 16) * a.lddk + h * 64, a.lddk, a.Lk - wave * 16, lane);
+  }
+}
+
+template <int NKT, bool HAS_DIST> int launch_rows_fwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  const int smem = 2 * NKT * 16 * TP + NKT * 16 * 4 + (threads / 64) * 16 * TP;
+  ETP_LAUNCH((rows_fwd_kernel<NKT, HAS_DIST>), dim3(blocks), dim3(threads), smem, st, k);
+  ETP_CHECK_LAUNCH("attn_rows_fwd");
+  return ETP_OK;
+}
+template <int NKT, bool HAS_DIST> int launch_rows_bwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  const BwdLds L(((k.Lq + 15) >> 4) * 16, NKT * 16);
+  static bool attr = false;
+  auto kern = rows_bwd_kernel<NKT, HAS_DIST>;
+  if (!attr) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      BwdLds(128, NKT * 16).total));
+    attr = true;
+  }
+  ETP_LAUNCH(kern, dim3(blocks), dim3(threads), L.total, st, k);
+  ETP_CHECK_LAUNCH("attn_rows_bwd");
+  return ETP_OK;
+}
+
+template <bool HAS_DIST> int dispatch_fwd(int nkt, const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  switch (nkt) {
+    case 1: return launch_rows_fwd<1, HAS_DIST>(k, blocks, threads, st);
+    case 2: return launch_rows_fwd<2, HAS_DIST>(k, blocks, threads, st);
+    case 3: return launch_rows_fwd<3, HAS_DIST>(k, blocks, threads, st);
+    case 4: return launch_rows_fwd<4, HAS_DIST>(k, blocks, threads, st);
+    case 5: return launch_rows_fwd<5, HAS_DIST>(k, blocks, threads, st);
+    case 6: return launch_rows_fwd<6, HAS_DIST>(k, blocks, threads, st);
+    case 7: return launch_rows_fwd<7, HAS_DIST>(k, blocks, threads, st);
+    default: return launch_rows_fwd<8, HAS_DIST>(k, blocks, threads, st);
+  }
+}
+template <bool HAS_DIST> int dispatch_bwd(int nkt, const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  switch (nkt) {
+    case 1: return launch_rows_bwd<1, HAS_DIST>(k, blocks, threads, st);
+    case 2: return launch_rows_bwd<2, HAS_DIST>(k, blocks, threads, st);
+    case 3: return launch_rows_bwd<3, HAS_DIST>(k, blocks, threads, st);
+    case 4: return launch_rows_bwd<4, HAS_DIST>(k, blocks, threads, st);
+    case 5: return launch_rows_bwd<5, HAS_DIST>(k, blocks, threads, st);
+    case 6: return launch_rows_bwd<6, HAS_DIST>(k, blocks, threads, st);
+    case 7: return launch_rows_bwd<7, HAS_DIST>(k, blocks, threads, st);
+    default: return launch_rows_bwd<8, HAS_DIST>(k, blocks, threads, st);
+  }
+}
+
+RowArgs make_row_args(int nh, const AttnBuf& a, void* P, float alpha, Drop drop) {
+  RowArgs k;
+  memset(&k, 0, sizeof(k));
+  k.Q = (const bf16_t*)a.Q; k.K = (const bf16_t*)a.K; k.V = (const bf16_t*)a.V; k.ldq = a.ldq; k.ldk = a.ldk; k.ldv = a.ldv;
+  k.lse = (float*)P; k.nh = nh; k.Lq = a.Lq; k.Lk = a.Lk; k.drop = drop;
+  k.keymask = a.keymask; k.mask_mode = a.mask_mode; k.dist = a.dist; k.sp_w = a.sp_w; k.sp_b = a.sp_b; k.alpha = alpha;
+  return k;
+}
+
+}  // namespace
+
+// bf16, both axes <= 128, 16-byte aligned operands; the probability buffer must hold Lq fp32 per (batch, head)
+bool attn_rows_ok(int dt, const AttnBuf& a, long ldc) {
+  static const bool on = [] { const char* e = getenv("ETP_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  if (!on || dt != ETP_BF16) return false;
+  if (a.Lq > 128 || a.Lk > 128 || a.Lq < 1 || a.Lk < 1 || a.ldS < 2) return false;
+  if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || ldc % 8) return false;
+  if (((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V) % 16) return false;
+  if (a.dist != nullptr && (a.sp_w == nullptr || a.sp_b == nullptr)) return false;
+  return true;
+}
+
+int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
+  ETP_REQUIRE((uintptr_t)ctx % 16 == 0, "ctx must be 16-byte aligned");
+  RowArgs k = make_row_args(nh, a, P, alpha, drop);
+  k.ctx = (bf16_t*)ctx; k.ldc = ldc;
+  const int nqt = (a.Lq + 15) / 16, nkt = (a.Lk + 15) / 16;
+  const int threads = 64 * (nqt > 4 ? nqt : 4);
+  return a.dist ? dispatch_fwd<true>(nkt, k, a.B * nh, threads, st) : dispatch_fwd<false>(nkt, k, a.B * nh, threads, st);
+}
+
+int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
+                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop) {
+  ETP_REQUIRE(ldd % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 &&
+                  ((uintptr_t)dctx | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) % 16 == 0,
+              "gradient operands of the register-resident attention must be 16-byte aligned");
+  RowArgs k = make_row_args(nh, a, const_cast<void*>(P), alpha, drop);
+  k.dO = (const bf16_t*)dctx; k.ldd = ldd;
+  k.dQ = (bf16_t*)dQ; k.dK = (bf16_t*)dK; k.dV = (bf16_t*)dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv;
+  k.d_sp_w = d_sp_w; k.d_sp_b = d_sp_b;
+  const int nqt = (a.Lq + 15) / 16, nkt = (a.Lk + 15) / 16;
+  int nw = nqt > nkt ? nqt : nkt;
+  if (nw < 4) nw = 4;
+  return a.dist ? dispatch_bwd<true>(nkt, k, a.B * nh, 64 * nw, st) : dispatch_bwd<false>(nkt, k, a.B * nh, 64 * nw, st);
+}
+
+}  // namespace etp

@@ -17,11 +17,14 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-to-nearest-even
-  return (bf16_t)(u >> 16);
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN): one instruction per PAIR of
+// values instead of the ~7 VALU operations of the integer rounding sequence
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -49,8 +52,8 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   uint2 t;
-  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  t.x = pack_bf16(v[0], v[1]);
+  t.y = pack_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 

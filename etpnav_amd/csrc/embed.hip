@@ -693,10 +693,10 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     if (i + 8 <= n) {
       const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
       uint4 o;
-      o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-      o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-      o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-      o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+      o.x = pack_bf16(a.x, a.y);
+      o.y = pack_bf16(a.z, a.w);
+      o.z = pack_bf16(b.x, b.y);
+      o.w = pack_bf16(b.z, b.w);
       *reinterpret_cast<uint4*>(dst + i) = o;
     } else {
       for (long j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);

@@ -98,10 +98,10 @@ template <> __device__ __forceinline__ void unpack8<float>(const uint4* p, float
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   uint4 o;
-  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-  o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  o.x = pack_bf16(v[0], v[1]);
+  o.y = pack_bf16(v[2], v[3]);
+  o.z = pack_bf16(v[4], v[5]);
+  o.w = pack_bf16(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = o;
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {

@@ -92,6 +92,12 @@ bool attn_flash_ok(int dt, const AttnBuf& a, long ldc);
 int attn_flash_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
 int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
                    void* dV, long lddv, float alpha, hipStream_t st, Drop drop);
+// register-resident kernels (attn_rows.hip): bf16, Lq and Lk <= 128 -- every R2R-CE shape of the planner.  Like the streaming
+// kernels they keep lse (1 fp32 per query row) in the front of the P buffer and recompute the probabilities in backward.
+bool attn_rows_ok(int dt, const AttnBuf& a, long ldc);
+int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
+int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
+                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop);
 int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS, Drop drop, hipStream_t st);
 // fused single-kernel variants (attn.hip) for Lq, Lk <= 128
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);

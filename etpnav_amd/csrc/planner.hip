@@ -423,6 +423,7 @@ static inline void* offs(void* p, long elems, size_t es) { return reinterpret_ca
 
 int attn_fwd_impl(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   const int dh = 64;
+  if (attn_rows_ok(dt, a, ldc)) return attn_rows_fwd(nh, a, P, ctx, ldc, alpha, st, drop);
   if (attn_fused_ok(dt, a, ldc)) return attn_fused_fwd(dt, nh, a, P, ctx, ldc, alpha, st, drop);
   if (attn_flash_ok(dt, a, ldc)) return attn_flash_fwd(nh, a, P, ctx, ldc, alpha, st, drop);
   ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
@@ -454,6 +455,8 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   const int dh = 64;
   {
     const int epc = dt == ETP_BF16 ? 8 : 4;
+    // the forward of these shapes left lse, not probabilities, in P: no other backward can read it
+    if (attn_rows_ok(dt, a, ldd)) return attn_rows_bwd(nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
     if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
       return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
     if (a.O != nullptr && attn_flash_ok(dt, a, ldd) && a.ldo % epc == 0 && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)

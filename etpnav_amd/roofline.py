@@ -28,16 +28,18 @@ def _rows(name, M, H, reads, writes) -> Kernel:
 
 
 def _attn_fwd(B, nh, Lq, Lk) -> Kernel:
+    """the probabilities never reach HBM (csrc/attn_rows.hip, streaming kernels of csrc/attn.hip): the forward leaves one
+    fp32 log-sum-exp per query row and the backward recomputes P on the matrix cores"""
     dh = 64
     fl = 2.0 * B * nh * Lq * Lk * dh * 2                       # QK^T and PV
-    by = B * nh * ((Lq + 2 * Lk) * dh * 2 + Lq * dh * 2 + Lq * Lk * 2)   # q,k,v in; ctx, P out
+    by = B * nh * ((Lq + 2 * Lk) * dh * 2 + Lq * dh * 2 + Lq * 4)        # q,k,v in; ctx, lse out
     return ("attn", fl, float(by))
 
 
 def _attn_bwd(B, nh, Lq, Lk) -> Kernel:
     dh = 64
-    fl = 2.0 * B * nh * Lq * Lk * dh * 4                       # dP, dV, dQ, dK
-    by = B * nh * ((Lq + 2 * Lk) * dh * 2 + Lq * dh * 2 + Lq * Lk * 2 + (Lq + 2 * Lk) * dh * 2)   # q,k,v,dO,P in; dq,dk,dv out
+    fl = 2.0 * B * nh * Lq * Lk * dh * 4                       # dP, dV, dQ, dK (the recomputation of QK^T is not counted)
+    by = B * nh * ((Lq + 2 * Lk) * dh * 2 + Lq * dh * 2 + Lq * 4 + (Lq + 2 * Lk) * dh * 2)   # q,k,v,dO,lse in; dq,dk,dv out
     return ("attn", fl, float(by))
 
 

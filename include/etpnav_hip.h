@@ -88,13 +88,16 @@ int etp_softmax_bwd(int dtype, const void* P, void* dP, const float* dist, float
                     int Lq, int Lk, int ldS, etp_stream_t stream);
 
 /* softmax(alpha*Q.K^T + mask)V for [B,heads] problems with head dim 64, head-interleaved row layouts
- * (BertSelfAttention / BertOutAttention / nn.MultiheadAttention).  P [B,heads,Lq,ldS] is saved for backward. */
+ * (BertSelfAttention / BertOutAttention / nn.MultiheadAttention).  P [B,heads,Lq,ldS] is the buffer the forward leaves for the
+ * backward of the SAME shape/dtype: probabilities on the tile / batched-GEMM paths (fp32; bf16 with dist on an axis > 128),
+ * and for bf16 otherwise only lse = rowmax + log(rowsum) (fp32, [B,heads,Lq] in the front of the buffer) -- the register-resident
+ * (both axes <= 128) and streaming kernels recompute the probabilities in backward.  Callers must treat it as opaque. */
 typedef struct etp_attn_desc {
   int32_t dtype, B, heads, Lq, Lk, ldS;
   const void* Q; int64_t ldq;   /* Q rows [B*Lq], head h at column h*64 */
   const void* K; int64_t ldk;
   const void* V; int64_t ldv;
-  void* P;                      /* [B,heads,Lq,ldS] scratch/saved probabilities */
+  void* P;                      /* [B,heads,Lq,ldS] saved for etp_attn_bwd (opaque, see above) */
   void* ctx; int64_t ldc;       /* [B*Lq, heads*64] */
   const uint8_t* keymask;       /* [B,Lk] 1 = valid */
   int32_t mask_mode;

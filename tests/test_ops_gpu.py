@@ -202,9 +202,13 @@ def test_softmax(dtype, mask_mode):
 
 
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
-@pytest.mark.parametrize("Lq,Lk", [(80, 80), (9, 20), (36, 36), (16, 512), (16, 80), (100, 120), (70, 40), (96, 72)])
-def test_attention_fwd_bwd(dtype, Lq, Lk):
-    """softmax(QK^T/8 + mask + sprel)V and its backward against torch autograd (head dim 64)."""
+@pytest.mark.parametrize("with_dist", [True, False])
+@pytest.mark.parametrize("Lq,Lk", [(80, 80), (9, 20), (36, 36), (16, 512), (16, 80), (100, 120), (70, 40), (96, 72), (128, 128),
+                                   (37, 37), (23, 80), (80, 17), (1, 1), (113, 16)])
+def test_attention_fwd_bwd(dtype, Lq, Lk, with_dist):
+    """softmax(QK^T/8 + mask + sprel)V and its backward against torch autograd (head dim 64).  bf16 with both axes <= 128 runs
+    the register-resident kernels (attn_rows.hip: one wavefront per 16 queries / 16 keys, every tile count 1..8 on either
+    axis is covered by the shape list), with and without the pairwise-distance bias of the graph self-attention."""
     torch.manual_seed(4)
     t = tdt(dtype)
     B, nh, dh = 2, 3, 64
@@ -221,7 +225,9 @@ def test_attention_fwd_bwd(dtype, Lq, Lk):
     qh = qr.view(B, Lq, nh, dh).permute(0, 2, 1, 3)
     kh = kvr[:, :H].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
     vh = kvr[:, H:].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
-    s = qh @ kh.transpose(-1, -2) / 8.0 + (1.0 - km.float())[:, None, None, :] * -10000.0 + (wr * dist + br)[:, None]
+    s = qh @ kh.transpose(-1, -2) / 8.0 + (1.0 - km.float())[:, None, None, :] * -10000.0
+    if with_dist:
+        s = s + (wr * dist + br)[:, None]
     ctx_ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Lq, H)
     P = torch.empty(B, nh, Lq, ldS, device=DEV, dtype=t)
     ctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
@@ -232,7 +238,8 @@ def test_attention_fwd_bwd(dtype, Lq, Lk):
     d.V, d.ldv = kv.data_ptr() + H * q.element_size(), 2 * H
     d.P, d.ctx, d.ldc = P.data_ptr(), ctx.data_ptr(), H
     d.keymask, d.mask_mode = km.data_ptr(), 0
-    d.dist, d.sp_w, d.sp_b = dist.data_ptr(), w.data_ptr(), b0.data_ptr()
+    if with_dist:
+        d.dist, d.sp_w, d.sp_b = dist.data_ptr(), w.data_ptr(), b0.data_ptr()
     d.alpha = 0.125
     check(L().etp_attn_fwd(ctypes.byref(d), stream()), "attn_fwd")
     torch.cuda.synchronize()
@@ -241,20 +248,22 @@ def test_attention_fwd_bwd(dtype, Lq, Lk):
     ctx_ref.backward(dctx.float())
     bd = AttnBwdDesc()
     bd.f = d
-    dP = torch.empty_like(P); dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+    dP = torch.empty_like(P); dq = torch.full_like(q, float("nan")); dkv = torch.full_like(kv, float("nan"))
     dw = torch.zeros(1, device=DEV); db = torch.zeros(1, device=DEV)
     bd.dctx, bd.ldd, bd.dP = dctx.data_ptr(), H, dP.data_ptr()
     bd.dQ, bd.lddq = dq.data_ptr(), H
     bd.dK, bd.lddk = dkv.data_ptr(), 2 * H
     bd.dV, bd.lddv = dkv.data_ptr() + H * q.element_size(), 2 * H
-    bd.d_sp_w, bd.d_sp_b = dw.data_ptr(), db.data_ptr()
+    if with_dist:
+        bd.d_sp_w, bd.d_sp_b = dw.data_ptr(), db.data_ptr()
     check(L().etp_attn_bwd(ctypes.byref(bd), stream()), "attn_bwd")
     torch.cuda.synchronize()
     sc = 4 if dtype == _lib.ETP_F32 else 3
     assert (dq.float() - qr.grad).abs().max().item() <= tol(dtype, sc)
     assert (dkv.float() - kvr.grad).abs().max().item() <= tol(dtype, sc)
-    assert abs(dw.item() - wr.grad.item()) <= tol(dtype, 4) + 2e-3
-    assert abs(db.item() - br.grad.item()) <= tol(dtype, 4) + 2e-3
+    if with_dist:
+        assert abs(dw.item() - wr.grad.item()) <= tol(dtype, 4) + 2e-3
+        assert abs(db.item() - br.grad.item()) <= tol(dtype, 4) + 2e-3
 
 
 @pytest.mark.parametrize("Lq,Lk", [(512, 512), (200, 200), (16, 512), (130, 300), (64, 129), (300, 70)])

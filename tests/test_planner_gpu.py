@@ -33,6 +33,24 @@ def grads_of(model):
     return {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
 
 
+def schedule_mismatches(model, ref_flat, rel, floor=1.0, k=6):
+    """Parameters whose gradient in model.flat_grads deviates from ref_flat by more than rel * max(floor, |ref| of THAT
+    parameter).  The two sides are the same computation under different stream schedules: everything on the dependent chain
+    is bit-identical, leaf reductions that end in fp32 atomics (bias / LayerNorm / embedding-table gradients, e.g.
+    gmap_pos_embeddings with its metre-scale position features) differ by summation order only -- hence a bound relative to
+    the parameter's own magnitude, not to the largest gradient of the model."""
+    rows = []
+    for name, p in model.named_parameters():
+        off = (p.grad.data_ptr() - model.flat_grads.data_ptr()) // 4
+        r = ref_flat[off:off + p.numel()]
+        d = (p.grad.detach().reshape(-1) - r).abs()
+        m = d.max().item()
+        if m > rel * max(floor, r.abs().max().item()):
+            rows.append((m, name, int((d > 0).sum().item()), p.numel(), r.abs().max().item()))
+    rows.sort(reverse=True)
+    return "; ".join(f"{n}: max diff {m:.3e} of |ref| {a:.3e} ({c}/{t} differ)" for m, n, c, t, a in rows[:k])
+
+
 def step_outputs(step):
     torch.cuda.synchronize()
     return {"txt_embeds": step.txt, "pano_embeds": step.pano, "gmap_embeds": step.gemb, "global_logits": step.logits,
@@ -139,7 +157,8 @@ def test_text_backward_in_layer_ranges_equals_single_call():
     for lo, hi in ((6, 9), (3, 6), (0, 3)):
         step.enqueue_txt_bwd(s, lo, hi)
     torch.cuda.synchronize()
-    assert (model.flat_grads - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    bad = schedule_mismatches(model, ref, rel=2e-5)
+    assert not bad, bad
 
 
 # ---- training mode: dropout at the reference's sites, masks from the documented counter-based generator ---------------
@@ -257,7 +276,8 @@ def test_bf16_train_mode_step_close_to_oracle_with_same_masks():
     for lo, hi in ((6, 9), (3, 6), (0, 3)):
         step.enqueue_txt_bwd(s, lo, hi)
     torch.cuda.synchronize()
-    assert (model.flat_grads - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-4
+    bad = schedule_mismatches(model, ref, rel=2e-3, floor=5e-2)
+    assert not bad, bad
     step.close()
 
 
