@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="force hipGraph replay of the three-stream step (explicitly recorded graph, PlannerStep.record)")
     ap.add_argument("--eager", action="store_true", help="force eager three-stream issue (no graph)")
+    ap.add_argument("--micro", type=int, default=1,
+                    help="issue the step as this many micro-batches on independent stream sets (etpnav_amd.step.MicroBatchedStep: "
+                         "same full-batch gradient, the chains hide each other's launch/drain gaps); single-GPU eager mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-AdamW leg")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
@@ -154,8 +157,13 @@ def main():
         batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"],
                            seed=1234 + rank)                      # each rank owns its episodes
     use_graph = args.graph and not args.eager
-    step = PlannerStep(model, batch, overlap=True,
-                       dropout="config" if args.mode == "train" else None, drop_seed=rank)
+    micro = args.micro if (world == 1 and not use_graph and args.workload != "sap") else 1
+    if micro > 1:
+        from etpnav_amd.step import MicroBatchedStep
+        step = MicroBatchedStep(model, batch, n_micro=micro, dropout="config" if args.mode == "train" else None, drop_seed=rank)
+    else:
+        step = PlannerStep(model, batch, overlap=True,
+                           dropout="config" if args.mode == "train" else None, drop_seed=rank)
     reducer = None
     if world > 1:
         ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=3)
@@ -317,7 +325,7 @@ def main():
                                    + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
                        "global_batch": w["B"] * world, "parallelism": f"dp{world}",
-                       "graph": use_graph, "mode": args.mode, "settle_steps": settle,
+                       "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro,
                        "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
                                     "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
                        "grad_comm_dtype": args.comm_dtype if world > 1 else None},

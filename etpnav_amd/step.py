@@ -53,7 +53,7 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
 class PlannerStep:
     def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], overlap: bool = True,
                  dropout=None, drop_seed: int = 0, refresh_weights: bool = True, zero_grads: bool = True,
-                 grad_overwrite: Optional[bool] = None):
+                 grad_overwrite: Optional[bool] = None, share_side_streams: Optional["PlannerStep"] = None):
         """dropout: None (eval-mode step), "config" (the model config's rates, the reference's policy.train()), or a
         tuple (p_hidden, p_attn, p_head, p_env).  refresh_weights / zero_grads = False when etpnav_amd.optim.FusedAdamW
         closes the step: its kernel already wrote the bf16 weight shadow and zeroed the gradient arena.
@@ -74,6 +74,7 @@ class PlannerStep:
         self.dropout = dropout
         self.drop_seed = int(drop_seed) & 0xFFFFFFFF
         self.step_no = 0
+        self.loss_scale = 1.0 / batch["txt_ids"].shape[0]      # cross_entropy(sum) / batch_size (ss_trainer_ETP.py:892)
         eng = self.eng = model._engine
         eng.require_gpu()
         dev = eng.device
@@ -127,7 +128,10 @@ class PlannerStep:
         # leaf work (weight gradients; the panorama branch) runs at the lowest stream priority: whenever its workgroups and the
         # dependent chain's wait for the same CUs, the chain's are dispatched first (ETP_STREAM_PRIO=0: all default)
         low = -1 if os.environ.get("ETP_STREAM_PRIO", "1") != "0" else 0
-        if overlap in (True, "aux", "both"):
+        self._own_aux = share_side_streams is None
+        if not self._own_aux:                  # MicroBatchedStep: one weight-gradient / d_txt stream for all micro-batches
+            self.aux = share_side_streams.aux
+        elif overlap in (True, "aux", "both"):
             a = ctypes.c_void_p()
             check(self.L.etp_stream_create_prio(ctypes.byref(a), low), "stream_create")
             self.aux = a.value
@@ -136,7 +140,9 @@ class PlannerStep:
             check(self.L.etp_stream_create_prio(ctypes.byref(b2), low), "stream_create")
             self.s2 = b2.value
         self.aux2 = None
-        if self.aux is not None and os.environ.get("ETP_DTXT_STREAM", "1") != "0":
+        if not self._own_aux:
+            self.aux2 = share_side_streams.aux2
+        elif self.aux is not None and os.environ.get("ETP_DTXT_STREAM", "1") != "0":
             a2 = ctypes.c_void_p()
             check(self.L.etp_stream_create(ctypes.byref(a2)), "stream_create")
             self.aux2 = a2.value
@@ -195,6 +201,12 @@ class PlannerStep:
         """Everything except the text-encoder backward: weight refresh, zero grads, the three forwards, loss and the
         navigation + panorama backward.  The panorama branch (forward and backward) runs on a second stream beside the
         text branch; with join_pano=False its backward is left running and joined by enqueue_txt_bwd."""
+        self.enqueue_fwd(s, backward)
+        if backward:
+            self.enqueue_bwd_main(s, join_pano, defer_pano)
+
+    def enqueue_fwd(self, s: int, backward: bool = True, after_prologue=None):
+        """weight refresh, gradient zeroing, forward_txt || forward_panorama, node assembly, forward_navigation, loss"""
         s2 = self.s2 if self.s2 is not None else s
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
@@ -215,6 +227,8 @@ class PlannerStep:
             # overwrite mode: the matrix region [0, n_matrix) is fully rewritten by this step's weight-gradient stores
             lo = eng.n_matrix if self.grad_overwrite else 0
             check(L.etp_memset_async(eng.grads.data_ptr() + lo * 4, 0, (eng.grads.numel() - lo) * 4, s2), "memset grads")
+        if after_prologue is not None:         # MicroBatchedStep: the other micro-batches' streams are ordered after the casts / memset
+            after_prologue(s, s2)
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), self.Bp, V,
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
@@ -225,10 +239,17 @@ class PlannerStep:
                             ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.gemb), ptr(self.logits),
                             ptr(self.st_nav), s), "nav_fwd")
         check(L.etp_sap_ce(ptr(self.logits), ptr(i["labels"]), ptr(self.loss), ptr(self.dlogits) if backward else None, B, G,
-                           1.0 / B, -100, s), "sap_ce")
-        if not backward:
-            check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
-            return
+                           self.loss_scale, -100, s), "sap_ce")
+        check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")     # the mode never leaks to other users of the planner
+
+    def enqueue_bwd_main(self, s: int, join_pano: bool = True, defer_pano: bool = False):
+        """navigation backward, node assembly backward, panorama backward (on the panorama stream)"""
+        s2 = self.s2 if self.s2 is not None else s
+        L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
+        B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
+        dt = _lib.ETP_F32
+        eng.set_dropout(self._drop_state())
+        check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
         check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
@@ -391,7 +412,88 @@ class PlannerStep:
         self.L.etp_planner_set_lazy_join(self.eng.handle, 0)
         self.L.etp_planner_set_aux_stream(self.eng.handle, None)
         self.L.etp_planner_set_aux2_stream(self.eng.handle, None)
-        for st in (self.aux, self.s2, getattr(self, "aux2", None)):
+        for st in ((self.aux, self.s2, getattr(self, "aux2", None)) if self._own_aux else (self.s2,)):
             if st is not None:
                 self.L.etp_stream_destroy(st)
         self.aux = self.s2 = self.aux2 = None
+
+
+class MicroBatchedStep:
+    """The same training step (one gradient of the mean loss over the whole batch, ss_trainer_ETP.py:892,1055) issued as
+    `n_micro` micro-batches on INDEPENDENT stream sets.
+
+    A planner step is a dependent chain of ~240 short kernels: each one ramps up, runs a few microseconds
+    at partial occupancy and drains before the next may start, and those fixed costs -- not bandwidth or MFMA rate -- bound
+    the step.  Two half-batch chains have no dependency on each other, so the hardware runs one chain's kernel in the other's
+    ramp / drain gaps; the per-kernel work halves while the fixed cost is hidden instead of paid twice.  Gradients: the first
+    micro-batch's weight-gradient GEMMs store (first touch), the others accumulate behind it on the shared weight-gradient
+    stream (in issue order, so no atomics are needed on the matrices); vector / table gradients are atomics as before.  The
+    loss of every micro-batch is scaled by 1/B of the WHOLE batch, so the arena ends up with exactly the full-batch gradient
+    (fp32 summation order aside).  Dropout draws an independent mask stream per micro-batch."""
+
+    def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], n_micro: int = 2, dropout=None,
+                 drop_seed: int = 0):
+        if "traj" in batch:
+            raise ValueError("MicroBatchedStep splits along the episode axis: trajectory-list batches are not supported")
+        B = batch["txt_ids"].shape[0]
+        if n_micro < 1 or B % n_micro != 0:
+            raise ValueError(f"batch size {B} is not a multiple of n_micro={n_micro}")
+        self.model, self.eng, self.L = model, model._engine, model._engine.L
+        self.B, self.n = B, n_micro
+        mb = B // n_micro
+        self.parts = []
+        for k in range(n_micro):
+            sub = {key: (v[k * mb:(k + 1) * mb] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for key, v in batch.items()}
+            p = PlannerStep(model, sub, overlap=True, dropout=dropout, drop_seed=drop_seed * n_micro + k,
+                            refresh_weights=(k == 0), zero_grads=(k == 0), grad_overwrite=(None if k == 0 else False),
+                            share_side_streams=self.parts[0] if k > 0 else None)
+            p.loss_scale = 1.0 / B
+            self.parts.append(p)
+        h = self.eng.handle
+        # ONE weight-gradient stream and ONE d_txt stream for all micro-batches: in-order issue is what lets the later
+        # micro-batches accumulate onto the first one's stores without atomics
+        check(self.L.etp_planner_set_aux_stream(h, self.parts[0].aux), "set_aux_stream")
+        check(self.L.etp_planner_set_aux2_stream(h, self.parts[0].aux2), "set_aux2_stream")
+        check(self.L.etp_planner_set_lazy_join(h, 1), "set_lazy_join")
+        self.mains = [None]
+        for _ in range(1, n_micro):
+            m = ctypes.c_void_p()
+            check(self.L.etp_stream_create(ctypes.byref(m)), "stream_create")
+            self.mains.append(m.value)
+
+    @property
+    def loss(self):
+        return sum(p.loss for p in self.parts)
+
+    @property
+    def inp(self):
+        return self.parts[0].inp
+
+    def run_eager(self, stream: Optional[int] = None):
+        s = stream if stream is not None else self.eng.stream()
+        mains = [s] + self.mains[1:]
+        L = self.L
+
+        def fork_others(s_main, s_side):           # after micro-batch 0's weight casts and gradient memset are enqueued
+            for m in mains[1:]:
+                check(L.etp_stream_after(s_main, m), "fork")
+                check(L.etp_stream_after(s_side, m), "fork")
+
+        # issue order = order on the shared weight-gradient stream: all forwards (their text K/V projections run there), then
+        # the navigation / panorama backward of every micro-batch, then the text backward of every micro-batch
+        for k, (p, m) in enumerate(zip(self.parts, mains)):
+            p.enqueue_fwd(m, True, after_prologue=fork_others if k == 0 else None)
+        for p, m in zip(self.parts, mains):
+            p.enqueue_bwd_main(m, join_pano=False)
+        for p, m in zip(self.parts, mains):
+            p.enqueue_txt_bwd(m)                   # joins this micro-batch's panorama branch and the weight-gradient stream
+        for m in mains[1:]:
+            check(L.etp_stream_after(m, s), "join")
+
+    def close(self):
+        torch.cuda.synchronize()
+        for p in reversed(self.parts):
+            p.close()
+        for m in self.mains[1:]:
+            self.L.etp_stream_destroy(m)
+        self.mains = [None]

@@ -161,6 +161,30 @@ def test_text_backward_in_layer_ranges_equals_single_call():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype,rel", [(torch.float32, 2e-5), (torch.bfloat16, 2e-4)])
+def test_micro_batched_step_equals_full_batch_step(dtype, rel):
+    """MicroBatchedStep: two half-batch chains on independent stream sets, the second accumulating onto the first one's
+    weight-gradient stores, must leave the gradient of the full-batch mean loss (ss_trainer_ETP.py:892) -- and re-store it
+    on the next step instead of accumulating across steps."""
+    from etpnav_amd.step import MicroBatchedStep
+    cfg = po.PlannerConfig.r2r(vocab_size=4096)
+    P = po.init_params(cfg, seed=2)
+    batch = po.make_batch(cfg, B=4, L=24, V=14, G=8, seed=5, ragged=True)
+    model = build_model(cfg, P, dtype)
+    full = PlannerStep(model, batch)
+    full.run_eager(); torch.cuda.synchronize()
+    ref, loss_ref = model.flat_grads.clone(), full.loss.item()
+    full.close()
+    model.flat_grads.fill_(float("nan"))                 # the micro-batched step owns the zeroing / first-touch stores
+    mb = MicroBatchedStep(model, batch, n_micro=2)
+    for _ in range(2):
+        mb.run_eager(); torch.cuda.synchronize()
+        assert abs(mb.loss.item() - loss_ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+        bad = schedule_mismatches(model, ref, rel=rel)
+        assert not bad, bad
+    mb.close()
+
+
 # ---- training mode: dropout at the reference's sites, masks from the documented counter-based generator ---------------
 RATES = (0.1, 0.1, 0.1, 0.4)     # hidden, attention-probs, SAP head (vlnbert_init.py:58), drop_env (Policy_ViewSelection_ETP.py:102)
 

@@ -15,7 +15,7 @@ python bench.py --workload c4 --steps 30 --warmup 5 --no-cpu-baseline --no-optim
 ETP_ATTN_FLASH=0 python bench.py --workload c4 --steps 30 --warmup 5 --no-cpu-baseline --no-optimizer > $O/bench_c4_noflash.json 2>> $O/bench_c4.err
 python bench.py --workload c5 --no-cpu-baseline --no-optimizer > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --workload sap --steps 100 --no-cpu-baseline --no-optimizer > $O/bench_sap.json 2> $O/bench_sap.err
-for v in "ETP_WGRAD_GROUP=0 ETP_GRAD_OVERWRITE=0 ETP_LNBWD_TWO_STAGE=0" "ETP_STREAM_PRIO=0" "ETP_ATTN_Q96=0" "ETP_DTXT_STREAM=0" "ETP_CHAIN_FIRST=1"; do
+for v in "ETP_WGRAD_GROUP=0 ETP_GRAD_OVERWRITE=0 ETP_LNBWD_TWO_STAGE=0" "ETP_STREAM_PRIO=0" "ETP_ATTN_ROWS=0" "ETP_DTXT_STREAM=0" "ETP_CHAIN_FIRST=1"; do
   env $v python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-optimizer > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
 done
 python bench.py --graph --steps 100 --warmup 10 --no-cpu-baseline --no-optimizer > $O/bench_graph.json 2> $O/bench_graph.err
@@ -35,3 +35,6 @@ python tools/gemm_sweep.py > $O/gemm_sweep.json 2> $O/gemm_sweep.err
 KSWEEP_ONLY=1 python tools/gemm_sweep.py > $O/ksweep_cold_vs_warm.json 2>> $O/gemm_sweep.err
 GEMM_GROUP_ONLY=1 GEMM_GROUP_TABLE=1 python tools/gemm_bench.py > $O/gemm_group_table.txt 2>&1
 python tools/host_timing.py > $O/host_timing.txt 2>&1
+python tools/attn_bench.py > $O/attn_bench_rows_kernels.json 2> $O/attn_bench.err
+ETP_ATTN_ROWS=0 python tools/attn_bench.py > $O/attn_bench_tile_kernels.json 2>> $O/attn_bench.err
+for m in 2 4; do python bench.py --micro $m --steps 100 --warmup 20 --no-cpu-baseline --no-optimizer > $O/bench_micro$m.json 2>> $O/bench_ab.err; done
