@@ -169,7 +169,10 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
   }
 }
 
-// backward: scatter-add into word rows (padding_idx 0 gets none: vilmodel_cmt.py:53), pos rows, type row 0
+// backward: scatter-add into word rows (padding_idx 0 gets none: vilmodel_cmt.py:53), pos rows, type row 0.
+// One workgroup per POSITION l, its 4 waves split the batch (rows b*L + l): the position-embedding gradient of l is a
+// segment sum over the batch held in registers and flushed once per column (B-way same-address atomics before: every sample
+// hit the same L rows), the word rows -- distinct ids with few repeats -- stay atomics.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids,
                                                              const float* __restrict__ word, const float* __restrict__ pos,
@@ -182,29 +185,34 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
   __shared__ float scratch[4 * H];
   Row<NCH> a_g, a_b, a_t;   // dgamma, dbeta, dtype0
   row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_t);
-  const int lane = threadIdx.x & 63;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    const long id = ids[row];
-    const int l = row % L;
-    Row<NCH> x, t, d;
-    row_load<NCH>(x, word + id * H, lane);
-    row_load<NCH>(t, pos + (long)l * H, lane);
-    row_add<NCH>(x, t);
-    row_load<NCH>(t, type0, lane);
-    row_add<NCH>(x, t);
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, B = M / L;
+  for (int l = blockIdx.x; l < L; l += gridDim.x) {
+    Row<NCH> a_p, pl, ty;     // d pos[l]; pos[l] and type[0] are the same for every row of this segment
+    row_zero<NCH>(a_p);
+    row_load<NCH>(pl, pos + (long)l * H, lane);
+    row_load<NCH>(ty, type0, lane);
+    for (int b = wave; b < B; b += 4) {
+      const int row = b * L + l;
+      const long id = ids[row];
+      Row<NCH> x, d;
+      row_load<NCH>(x, word + id * H, lane);
+      row_add<NCH>(x, pl);                                // same association as the forward: (word + pos) + type
+      row_add<NCH>(x, ty);
+      const float mean = stats[2 * row], rstd = stats[2 * row + 1];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+      for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x.v[c][e] = (x.v[c][e] - mean) * rstd;
-    row_load<NCH>(d, dy + (long)row * H, lane);
-    row_dropout<NCH>(d, drop, row, lane);
-    acc_mul<NCH>(a_g, d, x);
-    acc_scaled<NCH>(a_b, d, 1.0f);
-    row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
-    acc_scaled<NCH>(a_t, d, 1.0f);
-    if (id != 0) global_acc<NCH>(dword + id * H, d, lane);
-    global_acc<NCH>(dpos + (long)l * H, d, lane);
+        for (int e = 0; e < 4; ++e) x.v[c][e] = (x.v[c][e] - mean) * rstd;
+      row_load<NCH>(d, dy + (long)row * H, lane);
+      row_dropout<NCH>(d, drop, row, lane);
+      acc_mul<NCH>(a_g, d, x);
+      acc_scaled<NCH>(a_b, d, 1.0f);
+      row_ln_bwd<NCH>(d, x, gamma, rstd, lane);
+      acc_scaled<NCH>(a_p, d, 1.0f);
+      if (id != 0) global_acc<NCH>(dword + id * H, d, lane);
+    }
+    block_flush<NCH>(scratch, a_p, dpos + (long)l * H, 1, 0);
+    acc_scaled<NCH>(a_t, a_p, 1.0f);                      // d type[0] = sum over all rows
   }
   block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
   block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
@@ -763,7 +771,7 @@ int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* 
                    int B, int L, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   (void)dtype;
-  const int M = B * L, grid = row_grid(M, 128);
+  const int M = B * L, grid = L < 1024 ? L : 1024;      // one workgroup per position (segment sum of its gradient over the batch)
   ETP_DISPATCH_H(H, ETP_LAUNCH((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
   ETP_CHECK_LAUNCH("text_embed_bwd");
   return ETP_OK;

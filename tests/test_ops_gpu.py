@@ -319,6 +319,40 @@ def test_streaming_attention_fwd_bwd(Lq, Lk, mask_mode):
     assert (dkv.float() - kvr.grad).abs().max().item() <= tol(dtype, 3) * max(1.0, kvr.grad.abs().max().item() / 4)
 
 
+@pytest.mark.parametrize("B,Lt", [(5, 24), (32, 80), (2, 130), (1, 7)])
+def test_text_embedding_fwd_bwd(B, Lt):
+    """BertEmbeddings (vilmodel_cmt.py:62-77): LN(word[id] + pos[l] + type[0]) and its backward -- the position-embedding
+    gradient is a per-position segment sum over the batch, the word-table gradient a scatter-add with repeated ids and the
+    padding row 0 left at zero (:53)."""
+    torch.manual_seed(B * 131 + Lt)
+    H, vocab = 768, 300
+    word = torch.randn(vocab, H, device=DEV); pos = torch.randn(Lt + 3, H, device=DEV); typ = torch.randn(2, H, device=DEV)
+    gamma = torch.rand(H, device=DEV) + 0.5; beta = torch.randn(H, device=DEV)
+    ids = torch.randint(1, vocab, (B, Lt), device=DEV)
+    ids[:, Lt // 2:] = ids[:, :Lt - Lt // 2].clone()            # every id at least twice in a row of the batch
+    ids[0, -2:] = 0                                          # padding id
+    wr, pr, tr = (t.clone().requires_grad_(True) for t in (word, pos, typ))
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    emb = torch.nn.functional.embedding(ids, wr, padding_idx=0) + pr[:Lt][None] + tr[0]
+    ref = torch.nn.functional.layer_norm(emb, (H,), gr, br, 1e-12)
+    y = torch.empty(B * Lt, H, device=DEV); stats = torch.empty(B * Lt, 2, device=DEV)
+    check(L().etp_text_embed_fwd(_lib.ETP_F32, ptr(ids), ptr(word), ptr(pos), ptr(typ), ptr(gamma), ptr(beta), ptr(y), None,
+                                  ptr(stats), B, Lt, H, 1e-12, stream()), "text_embed_fwd")
+    assert (y.view(B, Lt, H) - ref).abs().max().item() < 2e-5
+    dy = torch.randn(B * Lt, H, device=DEV)
+    ref.backward(dy.view(B, Lt, H))
+    dword = torch.zeros_like(word); dpos = torch.zeros_like(pos); dtyp = torch.zeros(H, device=DEV)
+    dg = torch.zeros(H, device=DEV); db = torch.zeros(H, device=DEV)
+    check(L().etp_text_embed_bwd(_lib.ETP_F32, ptr(dy), ptr(ids), ptr(word), ptr(pos), ptr(typ), ptr(gamma), ptr(stats),
+                                  ptr(dword), ptr(dpos), ptr(dtyp), ptr(dg), ptr(db), B, Lt, H, stream()), "text_embed_bwd")
+    torch.cuda.synchronize()
+    tol_ = lambda g: 2e-5 * max(1.0, g.abs().max().item())
+    assert (dword - wr.grad).abs().max().item() < tol_(wr.grad) and dword[0].abs().max().item() == 0
+    assert (dpos - pr.grad).abs().max().item() < tol_(pr.grad)
+    assert (dtyp - tr.grad[0]).abs().max().item() < tol_(tr.grad)
+    assert (dg - gr.grad).abs().max().item() < tol_(gr.grad) and (db - br.grad).abs().max().item() < tol_(br.grad)
+
+
 def test_cross_entropy_and_gather():
     torch.manual_seed(5)
     B, G = 7, 11
