@@ -14,7 +14,9 @@ from typing import Dict, List, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "etpnav_hip.h")
-LIB_PATH = os.path.join(HERE, "libetpnav_hip.so")
+# ETP_LIB selects another build of the same library for same-box A/B measurements (e.g. the previous round's binary kept
+# beside the new one); symbols that build lacks are skipped, everything else is bound as declared.
+LIB_PATH = os.environ.get("ETP_LIB") or os.path.join(HERE, "libetpnav_hip.so")
 
 ETP_F32, ETP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
@@ -150,6 +152,8 @@ def lib() -> ctypes.CDLL:
     L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (res, args) in _protos.items():
+        if os.environ.get("ETP_LIB") and not hasattr(L, name):
+            continue
         fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -318,6 +318,13 @@ int etp_graph_time(etp_graph* g, etp_stream_t s, int iters, float* ms_out) {
 int etp_ktime_enable(int on) { ktime_enable(on != 0); return ETP_OK; }
 int etp_ktime_reset(void) { ktime_reset(); return ETP_OK; }
 int64_t etp_ktime_report(char* buf, int64_t cap) { return (buf && cap > 0) ? ktime_report(buf, (long)cap) : 0; }
+int etp_gemm_probe_enable(uint64_t* dev_buf, int64_t max_launches) {
+  ETP_REQUIRE(dev_buf == nullptr || max_launches > 0, "max_launches must be positive");
+  gemm_probe_set(reinterpret_cast<unsigned long long*>(dev_buf), (long)max_launches);
+  return ETP_OK;
+}
+int64_t etp_gemm_probe_count(void) { return gemm_probe_count(); }
+int etp_gemm_probe_meta(int64_t i, char* name, int cap, int32_t* dims) { return gemm_probe_meta((long)i, name, cap, dims); }
 int etp_prof_enable(int on) { prof_enable(on != 0); return ETP_OK; }
 int etp_prof_reset(void) { prof_reset(); return ETP_OK; }
 int etp_prof_report(etp_prof_entry* out, int cap) {

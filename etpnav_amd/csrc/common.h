@@ -68,9 +68,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (vilmodel_cmt.py:30-37, exact erf, not the tanh form) and its derivative.  erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 before fp32 rounding): one v_exp, one v_rcp and six FMAs instead of the ~40 VALU operations of the
+// library erff -- the GELU epilogues run 64 of these per thread on a 128x128 tile.  Both functions share
+// q = exp(-x^2/2): erf(x/sqrt2) = sign(x) * (1 - poly(t) * q),  t = 1 / (1 + p |x| / sqrt2).
+__device__ __forceinline__ void gelu_parts(float x, float& phi_cdf, float& q) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  q = __expf(-0.5f * x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * q;                     // erf(|x| / sqrt2)
+  phi_cdf = 0.5f * (1.0f + copysignf(e, x));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float c, q;
+  gelu_parts(x, c, q);
+  return x * c;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float c, q;
+  gelu_parts(x, c, q);
+  return c + x * 0.39894228040143267794f * q;
 }
 
 // ---- counter-based dropout: mask bit = hash(seed, element index); forward and backward recompute the same mask, none is
@@ -139,6 +160,7 @@ struct GemmArgs {
   int xcd_map;                        // 1: XCD-aware workgroup->tile order (set by launch_gemm; env ETP_GEMM_XCD=0 disables)
   Drop drop;                          // dropout on the epilogue value (after activation / its backward, before the residual);
                                       // element index = row * N + col
+  unsigned long long* dbg;            // phase-probe records (8 x u64 per workgroup, tools/gemm_phase_probe.py) or null
 };
 int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& g, int nbatch, hipStream_t st);
 // Several independent, unbatched, unsplit products of ONE (dtype, c_dtype, transA, transB) class in a single grid (LDS-DMA
@@ -154,6 +176,9 @@ void rec_abort();
 void ktime_enable(bool on);
 void ktime_reset();
 long ktime_report(char* buf, long cap);
+void gemm_probe_set(unsigned long long* buf, long launches);
+long gemm_probe_count();
+int gemm_probe_meta(long i, char* name, int cap, int* dims);
 void prof_enable(bool on);
 void prof_reset();
 int prof_report(etp_prof_entry* out, int cap);

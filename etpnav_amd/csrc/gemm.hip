@@ -212,12 +212,16 @@ __device__ __forceinline__ void frag_load(Frag<T>& f, const char* lds, int row16
 // round trips behind it (operand reads, then the bias) were a fifth of the launch (K sweep: 7 us intercept,
 // profiles/r02_gemm_sweep.json).  Larger tiles keep the fetch in the epilogue (too many registers).
 // (No arrays in these structs on purpose: a runtime-indexed member array keeps the whole object in scratch memory.)
-struct EpiChunk { uint4 r0, r1, c0, c1, z0, z1; float4 b0, b1; };
+struct EpiChunk { uint4 r0, r1, c0, c1, z0, z1; };
 template <typename T, typename TC, int BM, int BN> struct EpiPre {
   static constexpr int NCHUNK = BM * (BN / 8) / 256;
   static constexpr bool ON = NCHUNK <= 2;
   EpiChunk k0, k1;
   bool valid;
+  // bias of the thread's 8 columns: every chunk of a thread sits in the same columns (256 % (BN / 8) == 0), so it is
+  // fetched once, before the reduction, for every tile size
+  float4 b0, b1;
+  bool bias_valid;
 };
 template <typename T, typename TC, int BN>
 __device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmArgs& g, const TC* C, int m0, int n0, int ks, int tid) {
@@ -241,18 +245,22 @@ __device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmAr
     k.z0 = p[0];
     if constexpr (VPT == 2) k.z1 = p[1];
   }
-  if (g.bias != nullptr && ks == 0) {
-    k.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
-    k.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
-  }
 }
 template <typename T, typename TC, int BM, int BN>
 __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN>& pre, const GemmArgs& g, const TC* C, int m0, int n0, int ks,
                                              int tid) {
   using E = EpiPre<T, TC, BM, BN>;
+  static_assert(256 % (BN / 8) == 0, "a thread's chunks must share their columns");
   pre.valid = false;
+  pre.bias_valid = false;
+  if (!g.vec_epilogue) return;
+  if (g.bias != nullptr && ks == 0) {
+    const int colc = min(n0 + (tid % (BN / 8)) * 8, (g.N - 1) / 8 * 8);
+    pre.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
+    pre.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+    pre.bias_valid = true;
+  }
   if constexpr (E::ON) {
-    if (!g.vec_epilogue) return;
     pre.valid = true;
     epi_fetch_chunk<T, TC, BN>(pre.k0, 0, g, C, m0, n0, ks, tid);
     if constexpr (E::NCHUNK == 2) epi_fetch_chunk<T, TC, BN>(pre.k1, 1, g, C, m0, n0, ks, tid);
@@ -293,19 +301,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
     const bool has_r = g.R != nullptr, has_zr = (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD),
                has_c = (g.out_mode == 1);
     const bool has_bias = (g.bias != nullptr && ks == 0);
-    constexpr int HC = NCHUNK >= 4 ? NCHUNK / 4 : 1;       // chunks per pass (bounds the live epilogue registers)
+    // chunks per pass: all global reads of a pass are issued together (ONE memory round trip per pass; round 2 made four
+    // dependent round trips on a 128x128 tile), at most 4 chunks per pass to bound the live epilogue registers
+    constexpr int HC = NCHUNK >= 4 ? 4 : NCHUNK;
     const int col_last = (g.N - 1) / 8 * 8;
 #pragma unroll
     for (int h0 = 0; h0 < NCHUNK; h0 += HC) {
     uint4 rr[HC][VPC], cc[HC][VPC], zz[HC][VPT];
     const bool use_pre = pre.valid;
-    EpiChunk pk;
     if (use_pre) {
-      if constexpr (EpiPre<T, TC, BM, BN>::ON) {      // fetched before the main loop (HC == 1 for these tiles: chunk h0)
-        if (h0 == 0) pk = pre.k0; else pk = pre.k1;
-        rr[0][0] = pk.r0; cc[0][0] = pk.c0; zz[0][0] = pk.z0;
-        if constexpr (VPC == 2) { rr[0][1] = pk.r1; cc[0][1] = pk.c1; }
-        if constexpr (VPT == 2) zz[0][1] = pk.z1;
+      if constexpr (EpiPre<T, TC, BM, BN>::ON) {      // fetched before the main loop (these tiles have HC == NCHUNK <= 2: one pass)
+        rr[0][0] = pre.k0.r0; cc[0][0] = pre.k0.c0; zz[0][0] = pre.k0.z0;
+        if constexpr (VPC == 2) { rr[0][1] = pre.k0.r1; cc[0][1] = pre.k0.c1; }
+        if constexpr (VPT == 2) zz[0][1] = pre.k0.z1;
+        if constexpr (HC == 2) {
+          rr[1][0] = pre.k1.r0; cc[1][0] = pre.k1.c0; zz[1][0] = pre.k1.z0;
+          if constexpr (VPC == 2) { rr[1][1] = pre.k1.r1; cc[1][1] = pre.k1.c1; }
+          if constexpr (VPT == 2) zz[1][1] = pre.k1.z1;
+        }
       }
     }
 #pragma unroll
@@ -346,8 +359,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
       }
       if (has_bias) {
         float4 b0, b1;
-        if (use_pre) {
-          if constexpr (EpiPre<T, TC, BM, BN>::ON) { b0 = pk.b0; b1 = pk.b1; }
+        if (pre.bias_valid) {
+          b0 = pre.b0; b1 = pre.b1;
         } else {
           b0 = *reinterpret_cast<const float4*>(g.bias + colc); b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
         }
@@ -534,6 +547,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   __syncthreads();   // every wave is done reading the operand tiles before the C tile overwrites them
   EpiPre<T, TC, BM, BN> pre;
   pre.valid = false;
+  pre.bias_valid = false;
   gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
 }
 
@@ -617,9 +631,51 @@ template <int PER_SLAB, int MAXS> __device__ __forceinline__ void wait_slabs(int
   }
 }
 
+// ---- phase probe (tools/gemm_phase_probe.py; profiles/r03_gemm_phases.txt) --------------------------------------------
+// With GemmArgs::dbg set, thread 0 of every workgroup records s_memrealtime (100 MHz, chip-wide) at entry / exit and
+// s_memtime (shader clock) at entry, first slab visible, end of the reduction and end of the epilogue, plus HW_ID / XCC_ID.
+struct PhaseProbe {
+  unsigned long long rt0, mt0, mt1, mt2;
+  bool on;
+};
+__device__ __forceinline__ void probe_begin(PhaseProbe& p, const GemmArgs& g) {
+  p.on = g.dbg != nullptr && threadIdx.x == 0;
+  if (p.on) { p.rt0 = __builtin_amdgcn_s_memrealtime(); p.mt0 = __builtin_amdgcn_s_memtime(); p.mt1 = p.mt2 = p.mt0; }
+}
+__device__ __forceinline__ void probe_end(const PhaseProbe& p, const GemmArgs& g, int rec, int nk) {
+  if (!p.on) return;
+  unsigned long long* d = g.dbg + (size_t)rec * 8;
+  d[0] = p.rt0; d[1] = __builtin_amdgcn_s_memrealtime();
+  d[2] = p.mt0; d[3] = p.mt1; d[4] = p.mt2; d[5] = __builtin_amdgcn_s_memtime();
+  d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  d[7] = (unsigned long long)nk;
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN>
+__device__ __forceinline__ void load_frags(Frag<T> (&fa)[BM / 32], Frag<T> (&fb)[BN / 32], const char* sa, const char* sb, int s,
+                                           int wr, int wc, int lane) {
+#pragma unroll
+  for (int a = 0; a < BM / 32; ++a) frag_load<T, TA, BM, 0>(fa[a], sa, wr * (BM / 2) + a * 16, s, lane);
+#pragma unroll
+  for (int b = 0; b < BN / 32; ++b) frag_load<T, TB, BN, 0>(fb[b], sb, wc * (BN / 2) + b * 16, s, lane);
+}
+
 // One BM x BN output tile of problem `g` through the LDS-DMA main loop (shared by the single-problem and the grouped kernel).
+//
+// Software-pipelined reduction (round 3).  The round-2 loop was  wait -> barrier -> issue DMA -> ds_read -> MFMA  per
+// 128-byte slab: every wavefront exposed the LDS read latency twice per slab with nothing to cover it (one or two
+// wavefronts per SIMD), 440 cycles per workgroup-slab for 136 cycles of MFMA (K sweep, profiles/r02_gemm_sweep.json).
+// Now the fragments are double-buffered in registers and the ONE barrier of a slab sits between its sub-steps:
+//
+//     frags(t, s+1) <- LDS   ||  MFMA(t, s)                      (sub-steps before the last one)
+//     [slab t+1 landed: counted vmcnt] [lgkmcnt(0)] s_barrier      -> every wavefront holds all of slab t in registers,
+//     issue DMA of slab t+STAGES into slab t's buffer                 so that buffer is free: the ring keeps STAGES-1
+//     frags(t+1, 0) <- LDS   ||  MFMA(t, last)                        slabs in flight and one landed
+//
+// so each ds_read batch is covered by the previous sub-step's MFMAs and a DMA piece has STAGES-1 slab times to land.
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem) {
+__device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem,
+                                         int rec) {
   using GA = TileGeom<T, TA, BM, 0>;
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int BK = MmaTraits<T>::BK;
@@ -631,6 +687,8 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = tm * BM, n0 = tn * BN;
+  PhaseProbe probe;
+  probe_begin(probe, g);
 
   int kbeg = 0, kend = g.K;
   if (g.ksplit > 1) {
@@ -639,6 +697,20 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     kend = min(g.K, kbeg + per);
   }
   const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;     // host guarantees BK | (kend-kbeg)
+
+  DmaPlan<T, TA, BM> pa;
+  DmaPlan<T, TB, BN> pb;
+  dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+
+  // the whole ring goes in flight before anything else
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the ring
+#pragma unroll
+  for (int s = 0; s < STAGES; ++s)
+    if (s < nk) {
+      dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
+      dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
+    }
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -651,34 +723,20 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
 
   const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
   float colsum_acc = 0.f;
-  DmaPlan<T, TA, BM> pa;
-  DmaPlan<T, TB, BN> pb;
-  dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
-  dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
 
-  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the ring
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) {
-      dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
-      dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
-    }
+  Frag<T> fa0[MT], fb0[NT], fa1[MT], fb1[NT];               // the two fragment sets (indexed statically below)
+  if (nk > 0) {
+    wait_slabs<PER_SLAB, STAGES - 1>(min(STAGES - 1, nk - 1));   // slab 0 landed, the rest of the ring stays in flight
+    __builtin_amdgcn_s_barrier();
+    load_frags<T, TA, TB, BM, BN>(fa0, fb0, smem, smem + GA::BYTES, 0, wr, wc, lane);
+  }
+  if (probe.on) probe.mt1 = __builtin_amdgcn_s_memtime();
 
-  for (int t = 0; t < nk; ++t) {
-    // slab t must have landed; the younger slabs actually issued (at most STAGES-2, fewer at the tail of the reduction) stay
-    // in flight across the barrier.  (Round-2 fix: with STAGES >= 4 the count must shrink over the last STAGES-2 slabs.)
-    wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 1 - t));
-    __builtin_amdgcn_s_barrier();   // (a) every wave's pieces of slab t are in LDS, (b) buffer (t-1)%STAGES is free
-    if (t + STAGES - 1 < nk) {
-      const unsigned dst = lds0 + ((t + STAGES - 1) % STAGES) * STAGE;
-      dma_issue<T, TA, BM>(pa, dst, g.lda);
-      dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);
-    }
-    const char* sa = smem + (t % STAGES) * STAGE;
-    const char* sb = sa + GA::BYTES;
+  auto colsum_slab = [&](int t) {
     if constexpr (TA) {
       // fused bias gradient: blocks of the first tile column also sum the A tile ([k][rows]) over k
       if (do_colsum) {
+        const char* sa = smem + (t % STAGES) * STAGE;
         constexpr int KQ = 256 / BM, RPT = BK / KQ;
         const int col = tid % BM, kq = tid / BM;
         const int chunk = col / GA::EPC, within = (col % GA::EPC) * (int)sizeof(T);
@@ -689,29 +747,87 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
         }
       }
     }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      Frag<T> fa[MT], fb[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) frag_load<T, TA, BM, 0>(fa[a], sa, wr * (BM / 2) + a * 16, s, lane);
-#pragma unroll
-      for (int b = 0; b < NT; ++b) frag_load<T, TB, BN, 0>(fb[b], sb, wc * (BN / 2) + b * 16, s, lane);
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) mma_step(acc[a][b], fa[a], fb[b]);
+  };
+#define ETP_MMA_SET(FA, FB)                                            \
+  _Pragma("unroll") for (int a = 0; a < MT; ++a)                       \
+      _Pragma("unroll") for (int b = 0; b < NT; ++b) mma_step(acc[a][b], FA[a], FB[b]);
+  // hand-over between slabs: slab t+1 landed, every wave's reads of slab t retired, next DMA into the freed buffer
+#define ETP_SLAB_HANDOVER(t)                                                                             \
+  wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 2 - (t)));                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  if ((t) + STAGES < nk) {                                                                               \
+    const unsigned dst = lds0 + ((t) % STAGES) * STAGE;                                                  \
+    dma_issue<T, TA, BM>(pa, dst, g.lda);                                                                \
+    dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);                                                    \
+  }
+
+  if constexpr (KS == 2) {                // bf16: two sub-steps per slab, set 0 then set 1
+    int t = 0;
+    for (; t + 1 < nk; ++t) {             // steady state: slab t+1 exists
+      const char* sa = smem + (t % STAGES) * STAGE;
+      colsum_slab(t);
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      ETP_SLAB_HANDOVER(t)
+      const char* sn = smem + ((t + 1) % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa0, fb0, sn, sn + GA::BYTES, 0, wr, wc, lane);
+      ETP_MMA_SET(fa1, fb1)
+    }
+    if (t < nk) {                         // last slab
+      const char* sa = smem + (t % STAGES) * STAGE;
+      colsum_slab(t);
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      ETP_MMA_SET(fa1, fb1)
+    }
+  } else {                                // fp32: one sub-step per slab, the sets alternate from slab to slab
+    static_assert(KS == 1, "slab = one or two MFMA k-steps");
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {          // slabs t, t+1 with t+2 existing
+      colsum_slab(t);
+      ETP_SLAB_HANDOVER(t)
+      const char* s1 = smem + ((t + 1) % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      colsum_slab(t + 1);
+      ETP_SLAB_HANDOVER(t + 1)
+      const char* s2 = smem + ((t + 2) % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa0, fb0, s2, s2 + GA::BYTES, 0, wr, wc, lane);
+      ETP_MMA_SET(fa1, fb1)
+    }
+    if (t + 1 < nk) {                     // two slabs left: t (set 0), t+1 (set 1)
+      colsum_slab(t);
+      ETP_SLAB_HANDOVER(t)
+      const char* s1 = smem + ((t + 1) % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      colsum_slab(t + 1);
+      ETP_MMA_SET(fa1, fb1)
+    } else if (t < nk) {                  // one slab left (set 0)
+      colsum_slab(t);
+      ETP_MMA_SET(fa0, fb0)
     }
   }
+#undef ETP_MMA_SET
+#undef ETP_SLAB_HANDOVER
   wait_vmcnt<0>();
+  if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();
   if constexpr (TA) {
     if (do_colsum && m0 + (tid % BM) < g.M) atomicAdd(g.a_colsum + m0 + (tid % BM), colsum_acc);
   }
   __syncthreads();
   gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
+  probe_end(probe, g, rec, nk);
 }
 
+// __launch_bounds__(256, w): w = wavefronts per SIMD the grid needs (2 for the 128-row tiles, 3 for 64x64).  Without it
+// hipcc (ROCm 7.2) assumes a 512-register budget, splits it into VGPRs + AGPRs and then shuttles accumulators and
+// fragments between the two files (~290 v_accvgpr_* moves per kernel, ~150 inside the reduction loop); with the bound
+// every MFMA takes the VGPR form and accumulates in place.
+template <int BM, int BN> struct TileWaves { static constexpr int MIN = (BM * BN <= 64 * 64) ? 3 : 2; };
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (g.N + BN - 1) / BN;
   int tm, tn;
@@ -721,7 +837,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
   const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
   const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem);
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Grouped launch: up to ETP_GEMM_GROUP_MAX independent products of one storage/dtype/tile class in ONE grid (the four
@@ -729,7 +845,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
 // into 8 contiguous chunks, one per XCD (workgroup i runs on XCD i % 8), so every private L2 sees a compact slab of one or
 // two problems; inside a problem tiles run along the longer tile axis first (same order as tile_of_block).
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_group_kernel(const GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x, nwg = gridDim.x;
   int id = bid;
@@ -748,7 +864,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup grp) {
   if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
   else { tn = local / tiles_m; tm = local % tiles_m; }
   dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
-                                          reinterpret_cast<TC*>(g.C), tm, tn, 0, smem);
+                                          reinterpret_cast<TC*>(g.C), tm, tn, 0, smem, bid);
 }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
@@ -789,8 +905,36 @@ int prof_report(etp_prof_entry* out, int cap) {
   return n;
 }
 
+// ---- phase probe (host side): a caller-owned device buffer of launches x PROBE_WG_MAX x 8 u64 ------------------------
+constexpr int PROBE_WG_MAX = 4096;
+struct ProbeMeta { char name[96]; int dims[4]; };     // grid, M, N, K
+static unsigned long long* g_probe_buf = nullptr;
+static long g_probe_cap = 0;
+static std::vector<ProbeMeta> g_probe_meta;
+void gemm_probe_set(unsigned long long* buf, long launches) {
+  g_probe_buf = buf; g_probe_cap = buf ? launches : 0;
+  g_probe_meta.clear();
+}
+long gemm_probe_count() { return (long)g_probe_meta.size(); }
+int gemm_probe_meta(long i, char* name, int cap, int* dims) {
+  if (i < 0 || i >= (long)g_probe_meta.size() || !name || cap <= 0 || !dims) return ETP_ERR_INVALID;
+  strncpy(name, g_probe_meta[i].name, cap - 1); name[cap - 1] = 0;
+  memcpy(dims, g_probe_meta[i].dims, sizeof(int) * 4);
+  return ETP_OK;
+}
+static unsigned long long* probe_slot(const char* name, long wgs, int M, int N, int K) {
+  if (!g_probe_buf || rec_active() || wgs > PROBE_WG_MAX || (long)g_probe_meta.size() >= g_probe_cap) return nullptr;
+  ProbeMeta m;
+  memset(&m, 0, sizeof(m));
+  strncpy(m.name, name, sizeof(m.name) - 1);
+  m.dims[0] = (int)wgs; m.dims[1] = M; m.dims[2] = N; m.dims[3] = K;
+  unsigned long long* p = g_probe_buf + g_probe_meta.size() * (size_t)PROBE_WG_MAX * 8;
+  g_probe_meta.push_back(m);
+  return p;
+}
+
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES /*0 = register-staged kernel*/>
-static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
+static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
   constexpr int PAD = STAGES == 0 ? 32 : 0;
   using GA = TileGeom<T, TA, BM, PAD>;
   using GB = TileGeom<T, TB, BN, PAD>;
@@ -804,14 +948,16 @@ static int launch_one(const GemmArgs& g, int nbatch, hipStream_t st) {
     ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  dim3 grid(tiles, nbatch * g.ksplit, 1);
+  const int tiles = ((g_in.M + BM - 1) / BM) * ((g_in.N + BN - 1) / BN);
+  dim3 grid(tiles, nbatch * g_in.ksplit, 1);
+  GemmArgs g = g_in;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "gemm%s<%s,%s,%s%s,%dx%d,s%d>", STAGES ? "_dma" : "", sizeof(T) == 2 ? "bf16" : "f32",
+           sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);   // BLAS-style opA,opB
+  g.dbg = (STAGES > 0 && g_probe_buf) ? probe_slot(nm, (long)tiles * nbatch * g_in.ksplit, g.M, g.N, g.K) : nullptr;
   ProfRec rec;
   const bool prof = g_prof_on && !rec_active();
   if (prof) {
-    char nm[96];
-    snprintf(nm, sizeof(nm), "gemm%s<%s,%s,%s%s,%dx%d>", STAGES ? "_dma" : "", sizeof(T) == 2 ? "bf16" : "f32",
-             sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN);   // BLAS-style opA,opB
     std::lock_guard<std::mutex> lk(g_prof_mu);
     rec.id = prof_id(nm);
     rec.flops = 2.0 * g.M * g.N * g.K * nbatch;
@@ -842,30 +988,32 @@ bool gemm_uses_dma(int dtype, int K, int ksplit) { return dma_ok(dtype == ETP_BF
 
 template <typename T, typename TC, bool TA, bool TB>
 static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
-  // Tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64 (fills 256 CUs on the
-  // planner's small-M products and keeps batched attention tiles from wasting MFMA work).
+  // Tile choice (round 3, after the pipelined main loop; sweep: tools/gemm_sweep.py -> profiles/r03_gemm_sweep.json).
+  // What bounds a tile class on this chip is the L2 -> LDS feed (~64 B/clk/CU): per 128-byte slab a 64x64 tile moves
+  // 16 KiB for 8 MFMAs per wave, 128x64 24 KiB for 16, 128x128 32 KiB for 32.  So: the largest tile that still gives
+  // (nearly) every CU a workgroup.
+  //   128x128 (ring 2, two workgroups per CU)   when it yields >= ~1.4 workgroups per CU,
+  //   128x64  (ring 4, one workgroup per CU)    when it yields >= ~0.8 per CU (the M = 2560, N = 768 products: 240),
+  //   64x64   (ring 3; ring 4 below one workgroup per CU) otherwise.
   constexpr int BK = MmaTraits<T>::BK;
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
-  bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);   // tools/gemm_bench.py: 128x128 only pays with >= ~1.4 waves of tiles
-  bool dma = dma_ok(BK, g.K, g.ksplit);
-  int stages = big ? 2 : 3;   // whole-step A/B on MI355X: 3-deep ring on 64x64 tiles 5.76 -> 5.37 ms/step
-  // cold-operand sweep (tools/gemm_sweep.py, profiles/r02_gemm_sweep.json): once a product has fewer 64x64 tiles than the
-  // chip has room for (one workgroup per CU or less: the M = 512 / 1152 products), a 4-deep ring wins 5-20 % -- the only
-  // way left to keep more bytes in flight per CU; at >= 2 workgroups per CU the 3-deep ring is as good or better
-  {
-    const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch * g.ksplit;
-    if (!big && t64 <= 320 && g.K >= 4 * BK) stages = 4;
-  }
-  bool wide = false;          // 128x64 tiles
-  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_bench.py): e.g. "128", "64", "128s3", "64r", "w", "64s6"
+  const long tw = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * nbatch * g.ksplit;
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch * g.ksplit;
+  bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);
+  bool wide = !big && g.M >= 128 && g.N >= 64 && tw >= 200 && tw <= 520 && nbatch == 1;
+  static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!wide_on) wide = false;
+  const bool dma = dma_ok(BK, g.K, g.ksplit);
+  int stages = big ? 2 : (wide ? 4 : 3);
+  if (!big && !wide && t64 <= 320 && g.K >= 4 * BK) stages = 4;
+  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_sweep.py): "128", "64", "w" + optional "s2".."s4", "64r"
   if (force && force[0]) {
-    if (force[0] == '1' || force[0] == '6') big = force[0] == '1';
+    if (force[0] == '1' || force[0] == '6') { big = force[0] == '1'; wide = false; }
     if (force[0] == 'w') { wide = true; big = false; }
-    stages = big ? 2 : 3;
+    stages = big ? 2 : (wide ? 4 : 3);
     if (strstr(force, "s2")) stages = 2;
     if (strstr(force, "s3")) stages = 3;
     if (strstr(force, "s4")) stages = 4;
-    if (strstr(force, "s6")) stages = 6;
   }
   if (!dma) {
     if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
@@ -877,13 +1025,12 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   }
   if (wide) {
     if (stages == 2) return launch_one<T, TC, TA, TB, 128, 64, 2>(g, nbatch, st);
-    if (stages == 4) return launch_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
-    return launch_one<T, TC, TA, TB, 128, 64, 3>(g, nbatch, st);
+    if (stages == 3) return launch_one<T, TC, TA, TB, 128, 64, 3>(g, nbatch, st);
+    return launch_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
   }
-  if (stages == 6) return launch_one<T, TC, TA, TB, 64, 64, 6>(g, nbatch, st);
   if (stages == 4) return launch_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
-  if (stages == 3) return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
-  return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);
+  if (stages == 2) return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);
+  return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
 }
 
 template <typename T, typename TC>
@@ -957,12 +1104,16 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
     bytes += ((double)g.M * g.K + (double)g.N * g.K) * sizeof(T) + (double)g.M * g.N * sizeof(TC);
   }
   for (int i = grp.n; i <= ETP_GEMM_GROUP_MAX; ++i) grp.tile_start[i] = tiles;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "gemm_group<%s,%s,%s%s,%dx%d,s%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
+           TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);
+  {
+    unsigned long long* slot = g_probe_buf ? probe_slot(nm, tiles, grp.g[0].M, grp.g[0].N, grp.g[0].K) : nullptr;
+    for (int i = 0; i < grp.n; ++i) grp.g[i].dbg = slot;
+  }
   ProfRec rec;
   const bool prof = g_prof_on && !rec_active();
   if (prof) {
-    char nm[96];
-    snprintf(nm, sizeof(nm), "gemm_group<%s,%s,%s%s,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
-             TA ? "T" : "N", TB ? "N" : "T", BM, BN);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     rec.id = prof_id(nm);
     rec.flops = flops; rec.bytes = bytes;

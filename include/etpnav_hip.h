@@ -461,6 +461,15 @@ int etp_ktime_reset(void);
 int64_t etp_ktime_report(char* buf, int64_t cap);
 int etp_prof_enable(int on);
 int etp_prof_reset(void);
+/* Phase probe of the LDS-DMA GEMM kernels (measurement aid, tools/gemm_phase_probe.py; the reference has only host
+ * time.time() counters, pretrain_src/pretrain_src/train_r2r.py:227,299-317).  With a device buffer of
+ * max_launches x 4096 x 8 uint64 installed, every following eager GEMM launch of <= 4096 workgroups records per workgroup
+ * { s_memrealtime at entry, at exit; s_memtime at entry, first slab visible, end of reduction, end of epilogue;
+ *   XCC_ID << 32 | HW_ID; slabs } in launch order; etp_gemm_probe_meta names launch i (dims = grid, M, N, K).
+ * dev_buf == NULL switches the probe off. */
+int etp_gemm_probe_enable(uint64_t* dev_buf, int64_t max_launches);
+int64_t etp_gemm_probe_count(void);
+int etp_gemm_probe_meta(int64_t i, char* name, int cap, int32_t* dims);
 int etp_prof_report(etp_prof_entry* out, int cap);
 
 #ifdef __cplusplus

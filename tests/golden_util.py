@@ -71,6 +71,57 @@ def compare_grads(z, grads, atol, rel=None, rel_sample=None, abs_rel=0.0):
     return worst
 
 
+# ---- bf16 (performance mode) gradient bounds --------------------------------------------------------------------------
+# Round-3 change: the bf16 bound used to be 8e-2 + 10 % of the tensor's abs-max.  Most gradient tensors
+# of this model have abs-max < 8e-2 (278 of 307 at the c2 fixture), so an all-zero gradient passed.  Now every bound is
+# RELATIVE TO THE TENSOR ITSELF (the reference's own bf16-autocast-vs-fp32 gap is ~7 % of abs-max per tensor):
+#   fixtures (48 strided samples + fingerprints):  sample err <= 6e-2 * absmax_ref + 1e-4,  |L2 - L2_ref| <= 5e-2 * L2_ref + 1e-4
+#   full tensors (fresh-input oracle tests):       ||g - g_ref|| <= 5e-2 * ||g_ref|| + 1e-4  and  cosine >= 0.995
+# The 1e-4 floors only matter for tensors whose reference gradient is numerically zero.
+BF16_SAMPLE_REL, BF16_L2_REL, BF16_ABS_FLOOR, BF16_COS_MIN = 6e-2, 5e-2, 1e-4, 0.995
+
+
+def compare_grads_bf16(z, grads):
+    """Golden-fixture check of a bf16-mode gradient set; returns (worst sample ratio, worst L2 ratio, their tensor names)."""
+    worst_s, worst_l = (0.0, ""), (0.0, "")
+    names = [k[4:] for k in z.files if k.startswith("gfp.")]
+    for name in names:
+        if name.startswith("__input__") and name not in grads:
+            continue
+        assert name in grads, f"missing gradient {name}"
+        g = grads[name].detach().double().cpu().reshape(-1)
+        fp, smp = z[f"gfp.{name}"], torch.from_numpy(z[f"gsm.{name}"]).double()
+        idx = torch.from_numpy(sample_idx(g.numel()))
+        err = float((g[idx] - smp).abs().max())
+        amax, l2 = float(fp[1]), float(fp[2])
+        assert err <= BF16_SAMPLE_REL * amax + BF16_ABS_FLOOR, \
+            f"grad {name}: sample err {err:.3e} > {BF16_SAMPLE_REL} * abs-max {amax:.3e} + {BF16_ABS_FLOOR}"
+        dl = abs(float(g.norm()) - l2)
+        assert dl <= BF16_L2_REL * l2 + BF16_ABS_FLOOR, f"grad {name}: |L2 - L2_ref| {dl:.3e} > {BF16_L2_REL} * {l2:.3e}"
+        if amax > 1e-6:
+            worst_s = max(worst_s, (err / amax, name))
+        if l2 > 1e-6:
+            worst_l = max(worst_l, (dl / l2, name))
+    return worst_s, worst_l
+
+
+def compare_full_bf16(mine, ref, skip_prefix="__input__"):
+    """Full-tensor check of a bf16-mode gradient set against oracle gradients: relative L2 error and cosine per tensor."""
+    worst_r, worst_c = (0.0, ""), (1.0, "")
+    for k, g in ref.items():
+        if k.startswith(skip_prefix):
+            continue
+        a, b = mine[k].detach().double().cpu().reshape(-1), g.detach().double().cpu().reshape(-1)
+        nb, d = float(b.norm()), float((a - b).norm())
+        assert d <= BF16_L2_REL * nb + BF16_ABS_FLOOR, f"grad {k}: ||err|| {d:.3e} > {BF16_L2_REL} * ||ref|| {nb:.3e}"
+        if nb > 1e-3:
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
+            assert cos >= BF16_COS_MIN, f"grad {k}: cosine {cos:.5f} < {BF16_COS_MIN}"
+            worst_c = min(worst_c, (cos, k))
+            worst_r = max(worst_r, (d / nb, k))
+    return worst_r, worst_c
+
+
 def load_rollout():
     import numpy as np
     from oracle.make_golden_rollout import make_case, CASE

@@ -10,7 +10,8 @@ surfaces that had no oracle check:
     as ss_trainer_ETP.py:801-892 calls it (Policy_ViewSelection_ETP.py:157-170,344-358)
 
 All through the C ABI of libetpnav_hip.so.  Tolerances as tests/test_planner_gpu.py: fp32 2e-4 abs (+2e-3 relative on
-gradients; BASELINE.json asks 1e-3), bf16 5e-2 outputs / 8e-2 + 10 % of abs-max on gradients.
+gradients; BASELINE.json asks 1e-3), bf16 5e-2 outputs / per-tensor RELATIVE gradient bounds (golden_util.compare_grads_bf16,
+compare_full_bf16: 6 % of the tensor's abs-max on samples, 5 % on its L2, cosine >= 0.995).
 """
 import os
 import tempfile
@@ -23,7 +24,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import planner_oracle as po  # noqa: E402  (checker only)
-from tests.golden_util import load_case, compare_outputs, compare_grads, load_rollout, compare_rollout  # noqa: E402
+from tests.golden_util import (load_case, compare_outputs, compare_grads, compare_grads_bf16, compare_full_bf16,  # noqa: E402
+                               load_rollout, compare_rollout)
 from etpnav_amd.planner import GlocalTextPathNavCMT  # noqa: E402
 from etpnav_amd.step import PlannerStep  # noqa: E402
 
@@ -57,7 +59,7 @@ def test_baseline_shape_step_matches_reference_golden(name, dtype):
         g = compare_grads(z, grads_of(model), atol=2e-4, rel=2e-3, rel_sample=2e-3)
     else:
         worst = compare_outputs(z, step_outputs(step), atol=5e-2)
-        g = compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
+        g = compare_grads_bf16(z, grads_of(model))
     print(name, dtype, "worst output err", worst, "worst grad err", g)
     step.close()
 
@@ -81,12 +83,7 @@ def test_benchmarked_shape_b32_bf16_train_mode_close_to_oracle():
     assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
     assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
-    mine = grads_of(model)
-    for k, g in grads.items():
-        if k.startswith("__input__"):
-            continue
-        err = (mine[k] - g).abs().max().item()
-        assert err < 8e-2 + 0.1 * g.abs().max().item(), f"{k}: {err}"
+    print("bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
     step.close()
 
 
@@ -121,7 +118,7 @@ def test_rollout_matches_reference_golden_with_and_without_text_kv_cache(cached,
         compare_grads(z, grads_of(model), atol=2e-4, rel=2e-3, rel_sample=2e-3)
     else:
         compare_rollout(z, outs, atol=5e-2)
-        compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
+        print("rollout bf16", compare_grads_bf16(z, grads_of(model)))
 
 
 def test_rollout_train_mode_matches_oracle_with_same_masks():
@@ -303,12 +300,7 @@ def test_long_instruction_bf16_train_mode_step_close_to_oracle_with_same_masks()
     for k in ("txt_embeds", "gmap_embeds"):
         assert (got[k].float().cpu() - outs[k]).abs().max().item() < 8e-2, k
     assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
-    mine = grads_of(model)
-    for k, g in grads.items():
-        if k.startswith("__input__"):
-            continue
-        err = (mine[k] - g).abs().max().item()
-        assert err < 8e-2 + 0.1 * g.abs().max().item(), f"{k}: {err}"
+    print("bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
     step.close()
 
 

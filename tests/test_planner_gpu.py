@@ -7,7 +7,9 @@ Tolerances: fp32 parity mode must meet BASELINE.json's "within 1e-3 fp32" — we
 outputs/gradients (observed ~1e-5) plus a 2e-3 per-tensor relative bound on gradient samples.
 bf16 performance mode (bf16 GEMM/attention operands, fp32 residual stream — autocast's policy) is compared with the
 bound the reference itself shows between its bf16-autocast and fp32 runs (8e-3 logits, 2.3e-2 embeds,
-5.7e-2 abs / ~7 % of abs-max on gradients): 5e-2 logits/embeds, 8e-2 + 10 % of the tensor's abs-max on gradients.
+5.7e-2 abs / ~7 % of abs-max on gradients): 5e-2 logits/embeds; gradients PER TENSOR, relative to that tensor: 6 % of its abs-max
+on the fixture samples, 5 % on its L2 norm, and on full tensors relative L2 error <= 5 % with cosine >= 0.995
+(tests/golden_util.py: compare_grads_bf16 / compare_full_bf16; tests/test_bf16_bounds_cpu.py shows the bounds can fail).
 """
 import pytest
 import torch
@@ -16,7 +18,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import planner_oracle as po  # noqa: E402  (checker only)
-from tests.golden_util import load_case, compare_outputs, compare_grads  # noqa: E402
+from tests.golden_util import load_case, compare_outputs, compare_grads, compare_grads_bf16, compare_full_bf16  # noqa: E402
 from etpnav_amd.planner import GlocalTextPathNavCMT  # noqa: E402
 from etpnav_amd.step import PlannerStep  # noqa: E402
 
@@ -107,7 +109,8 @@ def test_bf16_step_close_to_reference_golden(name):
     step = PlannerStep(model, batch)
     step.run_eager()
     compare_outputs(z, step_outputs(step), atol=5e-2)
-    compare_grads(z, grads_of(model), atol=8e-2, abs_rel=0.1)
+    ws, wl = compare_grads_bf16(z, grads_of(model))
+    print(name, "bf16 worst sample err / abs-max", ws, "worst |dL2| / L2", wl)
 
 
 def test_fp32_step_vs_oracle_fresh_inputs_and_graph_replay():
@@ -189,13 +192,18 @@ def test_micro_batched_step_equals_full_batch_step(dtype, rel):
 RATES = (0.1, 0.1, 0.1, 0.4)     # hidden, attention-probs, SAP head (vlnbert_init.py:58), drop_env (Policy_ViewSelection_ETP.py:102)
 
 
-def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3):
+def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3, bf16=False):
+    """bf16=True: outputs to `atol`, gradients by the per-tensor relative bf16 bounds (rel is ignored)."""
     for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
         assert (got[k].float().cpu() - outs[k]).abs().max().item() < atol, k
     fin = torch.isfinite(outs["global_logits"])
     assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < atol
     assert abs(got["loss"].item() - outs["loss"].item()) < atol
+    if bf16:
+        wr, wc = compare_full_bf16(mine, grads)
+        print("bf16 worst rel-L2", wr, "worst cosine", wc)
+        return
     for k, g in grads.items():
         if k.startswith("__input__"):
             continue
@@ -291,7 +299,7 @@ def test_bf16_train_mode_step_close_to_oracle_with_same_masks():
     step.run_eager()
     got = step_outputs(step)
     outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*RATES, seed=(5 << 32) | 1))
-    _assert_step_matches(outs, grads, got, grads_of(model), atol=8e-2, rel=0.1)
+    _assert_step_matches(outs, grads, got, grads_of(model), atol=8e-2, bf16=True)
     # ranged text backward (DP overlap schedule) recomputes the same masks
     ref = model.flat_grads.clone()
     s = model._engine.stream()
@@ -358,7 +366,7 @@ def test_text_kv_cache_rollout_equals_per_step_projection(dtype, tol):
 
 
 # ---- the pre-training SAP unit (SURVEY.md §8d second unit; pretrain_cmt.py:223-283) -----------------------------------
-@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 8e-2, 0.1)])
+@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 8e-2, None)])
 def test_sap_pretraining_step_matches_oracle(dtype, atol, rel):
     """T-step trajectories: panorama encoder over every step, node features aggregated over the steps (visited = pano
     mean, unvisited = mean of the candidate views that saw it), global encoder, SAP head, mean CE -- outputs and all
@@ -374,13 +382,13 @@ def test_sap_pretraining_step_matches_oracle(dtype, atol, rel):
     step = PlannerStep(model, batch)
     step.run_eager()
     got = step_outputs(step)
-    _assert_step_matches(outs, grads, got, grads_of(model), atol=atol, rel=rel)
+    _assert_step_matches(outs, grads, got, grads_of(model), atol=atol, rel=rel, bf16=dtype == torch.bfloat16)
     assert (step.gimg.cpu() - outs["gmap_img_fts"]).abs().max().item() < atol
     step.close()
 
 
 # ---- the pre-training MLM task (pretrain_cmt.py:141-163) --------------------------------------------
-@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 3e-4, 2e-3), (torch.bfloat16, 1e-1, 0.1)])
+@pytest.mark.parametrize("dtype,atol,rel", [(torch.float32, 3e-4, 2e-3), (torch.bfloat16, 1e-1, None)])
 def test_mlm_pretraining_step_matches_oracle(dtype, atol, rel):
     """Same case as tests/golden/pretrain_tasks.npz (where the oracle is pinned to the REAL pre-training model): text ->
     forward_lang2visn through every x-layer -> tied MLM head on the masked tokens -> mean CE; the loss and the gradient of
@@ -395,9 +403,12 @@ def test_mlm_pretraining_step_matches_oracle(dtype, atol, rel):
     torch.cuda.synchronize()
     assert abs(step.loss.item() - outs["loss"].item()) < atol * 3
     mine = grads_of(model)
-    for k, g in grads.items():
-        err = (mine[k] - g).abs().max().item()
-        assert err < atol + rel * g.abs().max().item(), f"{k}: {err}"
+    if dtype == torch.bfloat16:
+        print("mlm bf16", compare_full_bf16(mine, grads))
+    else:
+        for k, g in grads.items():
+            err = (mine[k] - g).abs().max().item()
+            assert err < atol + rel * g.abs().max().item(), f"{k}: {err}"
     # train mode: dropout through the language-side blocks with the oracle's masks
     if dtype == torch.float32:
         step = MlmStep(model, batch, dropout=(0.1, 0.1, 0.1, 0.0), drop_seed=9)
