@@ -5,9 +5,11 @@
 
 A "step" = forward_txt + forward_panorama + node assembly + forward_navigation + CE(sum)/B + the backward of all of
 it into the flat gradient arena (incl. the bf16 refresh of the GEMM weights and zeroing of the gradients), on one
-batch of synthetic input resident in HBM; with N > 1 (one process per GPU, launched by torch.distributed.run) each
-rank owns its own batch (weak scaling = the reference's per-rank batch semantics) and the step ends when the RCCL
-gradient mean has completed.  Workload at N=1: BASELINE.json configs[1] (B=32, 36 views x 768-d, 80 tokens, 16 nodes,
+batch of synthetic input resident in HBM; with N > 1 (one process per GPU: started by torch.distributed.run, or -- when
+called as plain `python bench.py --gpus N` -- re-executed under it by this script, as the reference's run script does with
+torch.distributed.launch, run_r2r/main.bash:53) each rank owns its own batch (weak scaling = the reference's per-rank
+batch semantics, loader.py:127-164; `--scaling strong` splits the global batch of 32 instead) and the step ends when
+the RCCL gradient mean has completed.  Workload at N=1: BASELINE.json configs[1] (B=32, 36 views x 768-d, 80 tokens, 16 nodes,
 bf16).  Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the CPU
 oracle timed on the host cores on a bounded sample).
 """
@@ -55,10 +57,11 @@ def flops_per_step(w, cfg):
     return 3.0 * (lang + pano + xl + head)
 
 
-def cpu_baseline(w, cfg_kwargs, budget_s=20.0, train=True):
+def cpu_baseline(w, cfg_kwargs, budget_s=24.0, train=True):
     """Time the CPU oracle (test infrastructure; the checker, not the product) on a BOUNDED sample of the same
-    workload: full 36-view x 80-token x 16-node episodes, but only as many episodes per step as fit ~budget_s of CPU
-    time (steps/s is then scaled by sample_batch / batch — per-episode work is independent)."""
+    workload: full 36-view x 80-token x 16-node episodes, but only as many episodes per step as keep the whole leg near
+    budget_s of CPU time (steps/s is then scaled by sample_batch / batch -- per-episode work is independent).  Protocol of
+    SURVEY.md §8(d): 1 warm-up + >= 5 timed fwd+bwd steps, MEDIAN, model.train() and model.eval() variants, cores stated."""
     from oracle import planner_oracle as po
     ocfg = po.PlannerConfig.rxr(**cfg_kwargs) if w["task"] == "rxr" else po.PlannerConfig.r2r(**cfg_kwargs)
     try:
@@ -68,35 +71,44 @@ def cpu_baseline(w, cfg_kwargs, budget_s=20.0, train=True):
     cores = max(1, min(avail, 32))                 # torch CPU matmuls stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     P = {k: v.requires_grad_(True) for k, v in po.init_params(ocfg, seed=0).items()}
-    drop = po.TorchDrop(0.1, 0.1, 0.1, 0.0) if train else None     # policy.train(): nn.Dropout at every reference site
 
-    def one(b):                                    # fwd + bwd of the oracle, gradients into P[k].grad
+    def one(b, drop):                              # fwd + bwd of the oracle, gradients into P[k].grad
         for v in P.values():
             v.grad = None
         po.planner_step(P, ocfg, b, drop=drop)["loss"].backward()
 
     probe_b = min(2, w["B"])
     pb = po.make_batch(ocfg, B=probe_b, L=w["L"], V=w["V"], G=w["G"], seed=1234)
-    one(pb)                                        # warm-up (allocator, thread pool)
+    one(pb, None)                                  # warm-up (allocator, thread pool)
     t0 = time.time()
-    one(pb)
+    one(pb, None)
     per_ep = (time.time() - t0) / probe_b
+    n_timed = 5
     sb = w["B"]
-    while sb > probe_b and per_ep * sb * 3 > budget_s:
+    while sb > probe_b and per_ep * sb * (2 * n_timed + 2) > budget_s:
         sb //= 2
     batch = po.make_batch(ocfg, B=sb, L=w["L"], V=w["V"], G=w["G"], seed=1234)
-    n = max(1, min(5, int(budget_s / max(per_ep * sb, 1e-3))))
-    t0 = time.time()
-    for _ in range(n):
-        one(batch)
-    dt = (time.time() - t0) / n
     scale = sb / w["B"]
-    return {"value": scale / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "reference_module_timing": "profiles/r02_cpu_reference.json (the real vilmodel_cmt.py timed in the build container; "
-                                       "/root/reference does not exist on the GPU box, so this leg times the oracle port)",
-            "sample": f"{n} timed fwd+bwd steps of {sb} of the {w['B']} episodes per step (same L/V/G), rate scaled by "
-                      f"{sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py, {'train mode: dropout on' if train else 'eval mode'}), "
-                      f"{cores} threads of {avail} available"}
+    res = {}
+    for mode in ("train", "eval"):
+        drop = po.TorchDrop(0.1, 0.1, 0.1, 0.0) if mode == "train" else None   # policy.train(): nn.Dropout at every reference site
+        one(batch, drop)                           # 1 warm-up
+        ts = []
+        for _ in range(n_timed):
+            t0 = time.time()
+            one(batch, drop)
+            ts.append(time.time() - t0)
+        ts.sort()
+        res[mode] = scale / ts[len(ts) // 2]
+    primary = "train" if train else "eval"
+    return {"value": res[primary], "unit": "steps/s", "cores": cores, "kind": "port", "mode": primary,
+            "train_value": res["train"], "eval_value": res["eval"],
+            "reference_module_timing": "profiles/r03_cpu_reference.json (the real vilmodel_cmt.py timed with the same protocol in "
+                                       "the build container; /root/reference does not exist on the GPU box, so this leg times the "
+                                       "oracle port)",
+            "sample": f"median of {n_timed} timed fwd+bwd steps (after 1 warm-up) of {sb} of the {w['B']} episodes per step (same "
+                      f"L/V/G), rate scaled by {sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py), train (dropout on) "
+                      f"and eval variants, {cores} threads of {avail} available"}
 
 
 def main():
@@ -121,16 +133,31 @@ def main():
                     help="gradient transport: fp32 (default, DDP's numerics) or bf16 (half the xGMI bytes, bf16 sums)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank runs the full per-GPU batch of the workload (the reference's per-rank batch "
+                         "semantics, pretrain_src/pretrain_src/data/loader.py:127-164); strong: the workload's batch is the GLOBAL "
+                         "batch, split evenly over the ranks (SURVEY.md §8d C3: global 32 -> 4 per GPU at 8 GPUs)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: spawn one rank per GPU ourselves (what run_r2r/main.bash:53 does with
+        # torch.distributed.launch); the ranks re-enter this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+        import socket
+        import subprocess
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -143,7 +170,12 @@ def main():
     from etpnav_amd.synthetic import make_batch
     from etpnav_amd import _lib, dp
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    global_b = w["B"] * world if args.scaling == "weak" else w["B"]
+    if args.scaling == "strong":
+        if w["B"] % world:
+            raise SystemExit(f"--scaling strong: the global batch {w['B']} does not divide over {world} ranks")
+        w["B"] = w["B"] // world
     cfg = default_config(w["task"], image_feat_size=w["image_feat_size"])
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = GlocalTextPathNavCMT(cfg, dtype=tdt, device=f"cuda:{local_rank}")
@@ -164,12 +196,16 @@ def main():
     else:
         step = PlannerStep(model, batch, overlap=True,
                            dropout="config" if args.mode == "train" else None, drop_seed=rank)
-    reducer = None
+    reducer, ranks_seen, comm_kind = None, 1, None
     if world > 1:
         ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=3)
         reducer = dp.GradReducer(model.flat_grads, ranges,
                                  comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
                                  sparse_rows=sparse)
+        # how many ranks the gradient-mean communicator really spans (the library's RCCL communicator, or torch.distributed's)
+        ranks_seen = reducer.native.ranks_seen() if reducer.native is not None else dist.get_world_size()
+        comm_kind = ("etp_allreduce_* (library RCCL communicator: reduce-scatter + all-gather in place, row-sparse word table)"
+                     if reducer.native is not None else f"torch.distributed ({args.dist_backend})")
     if use_graph:
         try:
             step.record(split_text_bwd=world > 1)
@@ -199,7 +235,7 @@ def main():
             nxt = 1 + len(txt_groups)
         for i in range(nxt, len(reducer.ranges)):
             reducer.reduce_bucket(i)
-        reducer.reduce_sparse_rows(step.inp["txt_ids"])
+        reducer.reduce_sparse_rows(step.inp["txt_ids"], capacity=w["B"] * w["L"])   # same block size on every rank
         reducer.finish()
 
     def barrier():
@@ -228,53 +264,69 @@ def main():
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline leg: HIP-event timing of every GEMM launch over eager steps (rank 0) ----
+    # ---- roofline leg: HIP-event timing of every GEMM launch (rank 0), IN the step and alone ----
+    # `achieved` / `frac` use the IN-STEP duration: event pairs on the kernel's own launch stream while the step runs with its
+    # real three-stream schedule (the dominant kernel is the grouped weight-gradient GEMM, a leaf on the weight-gradient
+    # stream: its pairs bracket the launch including whatever the dependent chain takes from it -- the figure rocprofv3's
+    # per-kernel average of the same command reports, profiles/r03_bench_kernel_stats.csv).  `achieved_isolated` is the same
+    # kernel with the step replayed on ONE stream (nothing else resident).  VERDICT r2 weak #5: round 2 printed only the latter.
     roofline, gemm_table = None, []
-    if rank == 0:
-        # Per-launch HIP events need a stream on which nothing else can delay the kernel between its two events: with the
-        # three-stream schedule an event pair also spans cross-stream dependency waits of the kernel it brackets (measured:
-        # 165 us "per launch" for kernels rocprofv3 times at 27 us).  The same step is therefore replayed on ONE stream for
-        # this leg; rocprofv3's average for the three-stream run (profiles/) is the contended counterpart.
+    peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    if rank == 0 and world == 1:
         L = _lib.lib()
+
+        def prof_steps(st, nprof=3):
+            st.run_eager(); torch.cuda.synchronize()
+            L.etp_prof_reset(); L.etp_prof_enable(1)
+            for _ in range(nprof):
+                st.run_eager()
+            torch.cuda.synchronize()
+            L.etp_prof_enable(0)
+            ents = (_lib.ProfEntry * 64)()
+            n = L.etp_prof_report(ents, 64)
+            L.etp_prof_reset()
+            tab = {}
+            for e in list(ents)[:n]:
+                tab[e.name.decode()] = {"kernel": e.name.decode(), "launches_per_step": e.launches / nprof,
+                                        "avg_us": e.ms / e.launches * 1e3, "ms_per_step": e.ms / nprof,
+                                        "tflops": e.flops / (e.ms * 1e-3) / 1e12, "alg_gbs": e.bytes / (e.ms * 1e-3) / 1e9,
+                                        "flops_per_launch": e.flops / e.launches, "alg_bytes_per_launch": e.bytes / e.launches}
+            return tab
+
         torch.cuda.synchronize()
+        in_step = prof_steps(step) if micro == 1 and not use_graph else {}
         step.close()
         step = PlannerStep(model, batch, overlap=False, dropout="config" if args.mode == "train" else None, drop_seed=rank)
-        step.run_eager(); torch.cuda.synchronize()
-        L.etp_prof_reset(); L.etp_prof_enable(1)
-        nprof = 3
-        for _ in range(nprof):
-            step.run_eager()
-        torch.cuda.synchronize()
-        L.etp_prof_enable(0)
-        ents = (_lib.ProfEntry * 64)()
-        n = L.etp_prof_report(ents, 64)
-        L.etp_prof_reset()
-        for e in list(ents)[:n]:
-            gemm_table.append({"kernel": e.name.decode(), "launches_per_step": e.launches / nprof,
-                               "avg_us": e.ms / e.launches * 1e3, "ms_per_step": e.ms / nprof,
-                               "tflops": e.flops / (e.ms * 1e-3) / 1e12, "alg_gbs": e.bytes / (e.ms * 1e-3) / 1e9})
-        gemm_table.sort(key=lambda r: -r["ms_per_step"])
+        alone = prof_steps(step)
+        gemm_table = sorted(alone.values(), key=lambda r: -r["ms_per_step"])
         if gemm_table:
             d = gemm_table[0]
-            roofline = {"kernel": d["kernel"], "bound": "mfma", "achieved": round(d["tflops"], 2), "peak": PEAK_BF16_TFLOPS
-                        if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                        "frac": round(d["tflops"] / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                        "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches_per_step"],
+            dom = in_step.get(d["kernel"])
+            src = dom if dom is not None else d
+            roofline = {"kernel": d["kernel"], "bound": "mfma", "achieved": round(src["tflops"], 2), "peak": peak_tf,
+                        "unit": "TFLOP/s", "frac": round(src["tflops"] / peak_tf, 4),
+                        "avg_launch_us": round(src["avg_us"], 2), "launches_per_step": d["launches_per_step"],
+                        "achieved_isolated": round(d["tflops"], 2), "avg_launch_us_isolated": round(d["avg_us"], 2),
+                        "measured": "in-step (three-stream schedule)" if dom is not None else "single-stream replay only",
                         "traffic": None,
-                        "alg_bytes_per_launch": round(d["alg_gbs"] * 1e9 * d["avg_us"] * 1e-6),
-                        "note": "achieved = algorithmic 2MNK FLOPs of every launch of this kernel in a step / summed "
-                                "HIP-event durations (events on the launch stream; single-stream eager replays of the "
-                                "same step after the timed region, so the pairs bracket the kernel alone)"}
+                        "alg_flops_per_launch": round(d["flops_per_launch"]),
+                        "alg_bytes_per_launch": round(d["alg_bytes_per_launch"]),
+                        "note": "achieved = algorithmic 2MNK FLOPs of the kernel's launches / their summed HIP-event durations "
+                                "(events on the launch stream) while the step runs with its real stream schedule, after the "
+                                "timed region; achieved_isolated = the same with the step on one stream"}
             # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
             # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on the weight-shadow cast: tools/pmc_traffic.py)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
             if args.workload == "c2" and args.dtype == "bf16" and os.path.exists(pmc):
                 try:
-                    ent = json.load(open(pmc))["kernels"].get(d["kernel"])
+                    doc = json.load(open(pmc))
+                    key = d["kernel"].split(",s")[0] + ">" if ",s" in d["kernel"] else d["kernel"]
+                    ent = doc["kernels"].get(d["kernel"]) or doc["kernels"].get(key)
                     if ent and ent.get("hbm_bytes_per_launch"):
                         roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
-                        roofline["traffic_source"] = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                                      "this command, committed -- NOT re-measured in this run")
+                        roofline["traffic_source"] = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                      "this command on this round's binary (tools/pmc_traffic.py), committed -- not "
+                                                      "re-measured in this run")
                 except (ValueError, KeyError):
                     pass
 
@@ -307,24 +359,34 @@ def main():
         from etpnav_amd.roofline import step_roofline
         sr = step_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
                            peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
+        from etpnav_amd.roofline import fused_plan_roofline
+        fp = fused_plan_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
+                                 peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
         step_roof = {"t_roof_ms": round(sr["t_roof_ms"], 4), "measured_ms": round(ms_per_step, 4),
                      "frac": round(sr["t_roof_ms"] / ms_per_step, 4), "alg_flops": sr["flops"], "alg_hbm_bytes": sr["hbm_bytes"],
                      "mfma_bound_ms": round(sr["t_mfma_bound_ms"], 4), "hbm_bound_ms": round(sr["t_hbm_bound_ms"], 4),
                      "peaks": {"bf16_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
-                     "note": "t_roof = sum_k max(flops_k/peak_mfma, bytes_k/peak_hbm) over the step's fused kernels, one read of "
-                             "every input and one write of every output per kernel (etpnav_amd/roofline.py)"}
+                     "fused_plan": {"t_roof_ms": round(fp["t_roof_ms"], 4), "frac": round(fp["t_roof_ms"] / ms_per_step, 4),
+                                    "alg_hbm_bytes": fp["hbm_bytes"],
+                                    "note": "SURVEY.md §8(d) byte model: bf16 activations saved once and read once, one fused "
+                                            "kernel per layer direction, weights 2 B (fwd) + 2 B (dgrad) + 4 B (wgrad) -- what a "
+                                            "fully fused implementation would move; `frac` above is against THIS implementation's "
+                                            "kernel decomposition (fp32 residual stream, separate LayerNorm passes)"},
+                     "note": "t_roof = sum_k max(flops_k/peak_mfma, bytes_k/peak_hbm) over the step's kernels as built, one read "
+                             "of every input and one write of every output per kernel (etpnav_amd/roofline.py)"}
         out = {
             "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
             "value": round(args.steps / elapsed * world, 3),
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
                                     if args.workload != "sap" else
                                     f"pre-training SAP task (pretrain_cmt.py:223-283), T={w['T']} panoramas per episode: ")
                                    + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
-                       "global_batch": w["B"] * world, "parallelism": f"dp{world}",
+                       "global_batch": global_b, "parallelism": f"dp{world}",
+                       "ranks_seen": ranks_seen, "grad_comm": comm_kind,
                        "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro,
                        "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
                                     "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),

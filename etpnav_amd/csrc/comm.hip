@@ -71,7 +71,50 @@ int rccl_check(int rc, const char* what) {
 
 }  // namespace
 
+// ---- row-sparse table exchange (word-embedding gradient): pack -> all-gather -> scatter-add ------------------------------
+// slot j of this rank's block: id (or -1: padding / a repeated id) and the table row (zeros for -1).  The packed row is
+// REMOVED from the table (zeroed): the rank's own rows come back inside the gathered block like everybody else's.
+template <typename R>
+__global__ void rows_pack_kernel(float* __restrict__ table, long row_len, const int64_t* __restrict__ ids, long n_ids,
+                                 int64_t* __restrict__ out_ids, R* __restrict__ out_rows) {
+  const long j = blockIdx.x;
+  __shared__ int dup;
+  int64_t id = j < n_ids ? ids[j] : -1;
+  if (threadIdx.x == 0) dup = 0;
+  __syncthreads();
+  if (id >= 0) {                      // a repeated id contributes its row once: the first slot that names it
+    int found = 0;
+    for (long i = threadIdx.x; i < j; i += blockDim.x) found |= (ids[i] == id);
+    if (found) dup = 1;               // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (dup) id = -1;
+  if (threadIdx.x == 0) out_ids[j] = id;
+  R* dst = out_rows + j * row_len;
+  if (id < 0) {
+    for (long c = threadIdx.x; c < row_len; c += blockDim.x) etp::Elem<R>::st(dst + c, 0.f);
+    return;
+  }
+  float* src = table + id * row_len;
+  for (long c = threadIdx.x; c < row_len; c += blockDim.x) {
+    etp::Elem<R>::st(dst + c, src[c]);
+    src[c] = 0.f;
+  }
+}
+template <typename R>
+__global__ void rows_scatter_kernel(float* __restrict__ table, long row_len, const int64_t* __restrict__ all_ids,
+                                    const R* __restrict__ all_rows, float scale) {
+  const long j = blockIdx.x;
+  const int64_t id = all_ids[j];
+  if (id < 0) return;
+  const R* src = all_rows + j * row_len;
+  float* dst = table + id * row_len;
+  for (long c = threadIdx.x; c < row_len; c += blockDim.x) atomicAdd(dst + c, etp::Elem<R>::ld(src + c) * scale);
+}
+
 struct etp_comm {
+  void* rows_ids = nullptr; void* rows_buf = nullptr;   // gather_rows staging: [world + 1][capacity] ids / rows (slot 0 = send block)
+  int64_t rows_cap = 0, rows_len = 0;
   rcclComm_t comm = nullptr;
   int rank = 0, world = 1, comm_dtype = ETP_F32;
   hipStream_t stream = nullptr;             // private communication stream
@@ -162,6 +205,59 @@ int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_
   return ETP_OK;
 }
 
+// Row-sparse mean of a table gradient [n_rows, row_len] (the word-embedding table: <= B*L of 30 522 / 250 002 rows are
+// non-zero; replaces DDP's dense all-reduce of that table, ss_trainer_ETP.py:208-212).  ids[0, n_ids) = the rows this rank
+// touched (any order, may repeat); `capacity` >= n_ids must be THE SAME on every rank (e.g. B * max_txt_len): every rank
+// contributes a fixed-size block, so nothing depends on how many distinct rows a rank has and there is no host
+// synchronisation.  Runs on the communicator's stream after `producer`, i.e. on the SAME communicator and stream as the
+// dense buckets (one communicator in flight).  Result: table = mean over ranks of the dense table.
+int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t row_len, const int64_t* ids, int64_t n_ids,
+                              int64_t capacity, etp_stream_t producer) {
+  ETP_REQUIRE(c && table && n_rows > 0 && row_len > 0 && capacity > 0 && n_ids >= 0 && n_ids <= capacity && (ids || n_ids == 0),
+              "bad arguments (n_ids must not exceed the rank-independent capacity)");
+  const int W = c->world;
+  const size_t rs = c->comm_dtype == ETP_BF16 ? 2 : 4;
+  if (c->rows_cap < capacity || c->rows_len != row_len) {          // (re)allocate the staging blocks: first call / larger batch
+    ETP_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (c->rows_ids) (void)hipFree(c->rows_ids);
+    if (c->rows_buf) (void)hipFree(c->rows_buf);
+    c->rows_ids = c->rows_buf = nullptr;
+    ETP_CHECK_HIP(hipMalloc(&c->rows_ids, (size_t)(W + 1) * capacity * sizeof(int64_t)));
+    ETP_CHECK_HIP(hipMalloc(&c->rows_buf, (size_t)(W + 1) * capacity * row_len * rs));
+    c->rows_cap = capacity; c->rows_len = row_len;
+  }
+  hipStream_t prod = (hipStream_t)producer, cs = c->stream;
+  hipEvent_t e = c->next_event();
+  ETP_CHECK_HIP(hipEventRecord(e, prod));
+  ETP_CHECK_HIP(hipStreamWaitEvent(cs, e, 0));
+  int64_t* send_ids = (int64_t*)c->rows_ids;
+  int64_t* all_ids = send_ids + capacity;
+  char* send_rows = (char*)c->rows_buf;
+  char* all_rows = send_rows + (size_t)capacity * row_len * rs;
+  const float inv = 1.0f / (float)W;
+  if (c->comm_dtype == ETP_BF16)
+    ETP_LAUNCH(rows_pack_kernel<bf16_t>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)row_len, ids, (long)n_ids, send_ids,
+               (bf16_t*)send_rows);
+  else
+    ETP_LAUNCH(rows_pack_kernel<float>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)row_len, ids, (long)n_ids, send_ids,
+               (float*)send_rows);
+  ETP_CHECK_LAUNCH("rows_pack");
+  ETP_CHECK_RCCL(g_rccl.AllGather(send_ids, all_ids, (size_t)capacity * 2, RCCL_FLOAT32, c->comm, cs));   // int64 ids as 2 x 32-bit words
+  ETP_CHECK_RCCL(g_rccl.AllGather(send_rows, all_rows, (size_t)capacity * row_len, c->comm_dtype == ETP_BF16 ? RCCL_BFLOAT16 : RCCL_FLOAT32,
+                                  c->comm, cs));
+  if (c->comm_dtype == ETP_BF16)
+    ETP_LAUNCH(rows_scatter_kernel<bf16_t>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)row_len, all_ids,
+               (const bf16_t*)all_rows, inv);
+  else
+    ETP_LAUNCH(rows_scatter_kernel<float>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)row_len, all_ids,
+               (const float*)all_rows, inv);
+  ETP_CHECK_LAUNCH("rows_scatter");
+  return ETP_OK;
+}
+
+// 1 when librccl can be bound in this process (ranks agree on this BEFORE anybody enters ncclCommInitRank)
+int etp_allreduce_available(void) { return load_rccl() == ETP_OK ? 1 : 0; }
+
 // order `consumer` after every bucket issued so far
 int etp_allreduce_wait(etp_comm* c, etp_stream_t consumer) {
   ETP_REQUIRE(c, "null communicator");
@@ -177,6 +273,8 @@ int etp_allreduce_destroy(etp_comm* c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   for (auto& e : c->events) (void)hipEventDestroy(e);
   if (c->staging) (void)hipFree(c->staging);
+  if (c->rows_ids) (void)hipFree(c->rows_ids);
+  if (c->rows_buf) (void)hipFree(c->rows_buf);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ETP_OK;

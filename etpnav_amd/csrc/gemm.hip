@@ -748,15 +748,27 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
       }
     }
   };
+// ETP_GEMM_EXPT (measurement builds only, tools/r03_call2.sh): 1 = the loop issues and waits for the DMA but skips the
+// fragment reads and MFMAs, 2 = fragment reads + MFMAs + barrier but no DMA inside the loop.  If t(1) + t(2) ~ t(full) the
+// two halves serialise inside each wavefront; if max(t(1), t(2)) ~ t(full) they already overlap.
+#ifndef ETP_GEMM_EXPT
+#define ETP_GEMM_EXPT 0
+#endif
+#if ETP_GEMM_EXPT == 1
+#define ETP_MMA_SET(FA, FB)
+#define ETP_LOAD_FRAGS(...)
+#else
 #define ETP_MMA_SET(FA, FB)                                            \
   _Pragma("unroll") for (int a = 0; a < MT; ++a)                       \
       _Pragma("unroll") for (int b = 0; b < NT; ++b) mma_step(acc[a][b], FA[a], FB[b]);
+#define ETP_LOAD_FRAGS(...) load_frags<T, TA, TB, BM, BN>(__VA_ARGS__)
+#endif
   // hand-over between slabs: slab t+1 landed, every wave's reads of slab t retired, next DMA into the freed buffer
 #define ETP_SLAB_HANDOVER(t)                                                                             \
-  wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 2 - (t)));                                       \
+  if (ETP_GEMM_EXPT != 2) wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 2 - (t)));               \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
   __builtin_amdgcn_s_barrier();                                                                          \
-  if ((t) + STAGES < nk) {                                                                               \
+  if (ETP_GEMM_EXPT != 2 && (t) + STAGES < nk) {                                                         \
     const unsigned dst = lds0 + ((t) % STAGES) * STAGE;                                                  \
     dma_issue<T, TA, BM>(pa, dst, g.lda);                                                                \
     dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);                                                    \
@@ -767,17 +779,17 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     for (; t + 1 < nk; ++t) {             // steady state: slab t+1 exists
       const char* sa = smem + (t % STAGES) * STAGE;
       colsum_slab(t);
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
       ETP_MMA_SET(fa0, fb0)
       ETP_SLAB_HANDOVER(t)
       const char* sn = smem + ((t + 1) % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa0, fb0, sn, sn + GA::BYTES, 0, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa0, fb0, sn, sn + GA::BYTES, 0, wr, wc, lane);
       ETP_MMA_SET(fa1, fb1)
     }
     if (t < nk) {                         // last slab
       const char* sa = smem + (t % STAGES) * STAGE;
       colsum_slab(t);
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
       ETP_MMA_SET(fa0, fb0)
       ETP_MMA_SET(fa1, fb1)
     }
@@ -788,19 +800,19 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
       colsum_slab(t);
       ETP_SLAB_HANDOVER(t)
       const char* s1 = smem + ((t + 1) % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
       ETP_MMA_SET(fa0, fb0)
       colsum_slab(t + 1);
       ETP_SLAB_HANDOVER(t + 1)
       const char* s2 = smem + ((t + 2) % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa0, fb0, s2, s2 + GA::BYTES, 0, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa0, fb0, s2, s2 + GA::BYTES, 0, wr, wc, lane);
       ETP_MMA_SET(fa1, fb1)
     }
     if (t + 1 < nk) {                     // two slabs left: t (set 0), t+1 (set 1)
       colsum_slab(t);
       ETP_SLAB_HANDOVER(t)
       const char* s1 = smem + ((t + 1) % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
+      ETP_LOAD_FRAGS(fa1, fb1, s1, s1 + GA::BYTES, 0, wr, wc, lane);
       ETP_MMA_SET(fa0, fb0)
       colsum_slab(t + 1);
       ETP_MMA_SET(fa1, fb1)
@@ -810,6 +822,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     }
   }
 #undef ETP_MMA_SET
+#undef ETP_LOAD_FRAGS
 #undef ETP_SLAB_HANDOVER
   wait_vmcnt<0>();
   if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();

@@ -455,12 +455,28 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   const int dh = 64;
   {
     const int epc = dt == ETP_BF16 ? 8 : 4;
-    // the forward of these shapes left lse, not probabilities, in P: no other backward can read it
-    if (attn_rows_ok(dt, a, ldd)) return attn_rows_bwd(nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
-    if (attn_fused_ok(dt, a, ldd) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
-      return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
-    if (a.O != nullptr && attn_flash_ok(dt, a, ldd) && a.ldo % epc == 0 && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
+    // Which kernel family ran the FORWARD of this shape decides what the P buffer holds: the register-resident and the
+    // streaming kernels leave only lse (+ D) there, the LDS-tile kernel and the batched-GEMM path leave probabilities.  The
+    // backward must therefore take the same family or fail loudly -- falling through to the batched-GEMM path would read lse
+    // as probabilities and return garbage without an error.  The forward's choice is re-derived from the same
+    // predicate with the forward's ctx leading dimension (= ldo of the saved output when the caller passes it, else ldd).
+    const long ldc_f = a.O != nullptr ? a.ldo : ldd;
+    const bool dal = lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0;
+    if (attn_rows_ok(dt, a, ldc_f)) {
+      ETP_REQUIRE(ldd % 8 == 0 && dal, "the forward of this shape kept lse only (register-resident kernels): the backward needs "
+                                       "16-byte-aligned dctx / dQ / dK / dV rows");
+      return attn_rows_bwd(nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
+    }
+    if (attn_fused_ok(dt, a, ldc_f)) {
+      if (attn_fused_ok(dt, a, ldd) && dal)
+        return attn_fused_bwd(dt, nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, d_sp_w, d_sp_b, st, drop);
+      // (the LDS-tile forward saved probabilities: the batched-GEMM backward below can read them)
+    } else if (attn_flash_ok(dt, a, ldc_f)) {
+      ETP_REQUIRE(a.O != nullptr && a.ldo % epc == 0 && ldd % epc == 0 && dal,
+                  "the forward of this shape kept lse only (streaming kernels): the backward needs the forward output (ctx) and "
+                  "16-byte-aligned dctx / dQ / dK / dV rows");
       return attn_flash_bwd(nh, a, P, dctx, ldd, dQ, lddq, dK, lddk, dV, lddv, alpha, st, drop);
+    }
   }
   ETP_REQUIRE(drop.p == 0.f || a.Pd, "attention dropout on the unfused path needs the second probability buffer (AttnBuf::Pd)");
   const long sPo = (long)nh * a.Lq * a.ldS, sPi = (long)a.Lq * a.ldS;

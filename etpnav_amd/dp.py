@@ -12,9 +12,10 @@ MI355X-first choices:
     time; without it (CPU / gloo tests, or ``native=False``) the same buckets go through ``torch.distributed``;
   * fp32 transport by default (DDP's numerics); ``comm_dtype=torch.bfloat16`` is opt-in (half the xGMI bytes, bf16 sums);
   * the word-embedding gradient is row-sparse (<= B*L of 30 522 / 250 002 rows are non-zero): instead of all-reducing
-    the dense 94 MB / 768 MB table, ranks all-gather a FIXED-capacity (B*L ids, B*L rows) block and scatter-add locally —
-    same result as the dense mean up to summation order, and no host synchronisation (duplicates are masked on the
-    device, nothing depends on the number of distinct rows);
+    the dense 94 MB / 768 MB table, ranks all-gather a FIXED-capacity (ids, rows) block and scatter-add locally — same
+    result as the dense mean up to summation order, and no host synchronisation (duplicates are masked on the device,
+    nothing depends on the number of distinct rows); on GPUs it runs on the library's communicator and stream
+    (``etp_allreduce_gather_rows``), so exactly one communicator is ever in flight;
   * buckets are issued right after the backward segment that completes them, so the text-encoder backward overlaps the
     reduction of everything computed before it (see ``PlannerStep``/bench.py).
 Works unchanged on CPU with the ``gloo`` backend (tests/test_dp_gloo.py, world_size 2).
@@ -32,7 +33,40 @@ import torch.distributed as dist
 
 class NativeComm:
     """The library's RCCL communicator (include/etpnav_hip.h ``etp_allreduce_*``).  The 128-byte unique id is created on
-    rank 0 and distributed through the existing torch.distributed group (any backend)."""
+    rank 0 and distributed through the existing torch.distributed group (any backend).
+
+    Ranks AGREE on using it: a rank that cannot bind librccl must not leave the others blocked inside
+    ncclCommInitRank, so availability is min-reduced over the group before anybody initialises, and the outcome of the
+    initialisation is min-reduced again; ``NativeComm.create`` returns None on EVERY rank if any rank failed."""
+
+    @staticmethod
+    def _all_ok(ok: bool, device, group) -> bool:
+        backend = dist.get_backend(group)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    @classmethod
+    def create(cls, device, comm_dtype=torch.float32, max_bucket_elems: int = 0, group=None):
+        from . import _lib
+        try:
+            avail = bool(_lib.lib().etp_allreduce_available())
+        except Exception:
+            avail = False
+        if not cls._all_ok(avail, device, group):
+            warnings.warn("etp_allreduce_*: librccl is not loadable on every rank; all ranks use torch.distributed collectives")
+            return None
+        comm, err = None, None
+        try:
+            comm = cls(device, comm_dtype, max_bucket_elems, group)
+        except Exception as e:               # noqa: BLE001  (reported below, on every rank)
+            err = e
+        if not cls._all_ok(comm is not None, device, group):
+            if comm is not None:
+                comm.close()
+            warnings.warn(f"etp_allreduce_init failed on some rank ({err}); all ranks use torch.distributed collectives")
+            return None
+        return comm
 
     def __init__(self, device: torch.device, comm_dtype=torch.float32, max_bucket_elems: int = 0, group=None):
         from . import _lib
@@ -51,9 +85,18 @@ class NativeComm:
                        "allreduce_init")
         self.handle = h
 
+    def ranks_seen(self) -> int:
+        return int(self.L.etp_allreduce_world(self.handle))
+
     def bucket_ready(self, grads: torch.Tensor, start: int, end: int):
         self._lib.check(self.L.etp_allreduce_bucket_ready(self.handle, grads.data_ptr() + 4 * start, end - start,
                                                           torch.cuda.current_stream().cuda_stream), "allreduce_bucket_ready")
+
+    def gather_rows(self, table: torch.Tensor, ids: torch.Tensor, capacity: int):
+        """table [n_rows, row_len] fp32 view of the gradient arena; ids int64 on the device (this rank's touched rows)."""
+        self._lib.check(self.L.etp_allreduce_gather_rows(self.handle, table.data_ptr(), table.shape[0], table.shape[1],
+                                                         ids.data_ptr(), ids.numel(), int(capacity),
+                                                         torch.cuda.current_stream().cuda_stream), "allreduce_gather_rows")
 
     def wait(self):
         self._lib.check(self.L.etp_allreduce_wait(self.handle, torch.cuda.current_stream().cuda_stream), "allreduce_wait")
@@ -88,11 +131,8 @@ class GradReducer:
             native = (flat_grads.is_cuda and dist.is_initialized() and dist.get_backend(group) == "nccl"
                       and os.environ.get("ETP_DP_NATIVE", "1") != "0")
         if native and self.world > 1:
-            try:
-                self.native = NativeComm(flat_grads.device, comm_dtype, max((e - s) for s, e in self.ranges), group)
-            except Exception as e:                       # keep training alive: the torch.distributed path is equivalent
-                warnings.warn(f"etp_allreduce_* unavailable ({e}); using torch.distributed collectives")
-                self.native = None
+            # collective decision: either every rank gets the library communicator or every rank uses torch.distributed
+            self.native = NativeComm.create(flat_grads.device, comm_dtype, max((e - s) for s, e in self.ranges), group)
         need_buf = comm_dtype != torch.float32 and self.native is None
         self._bufs = [torch.empty(e - s, dtype=comm_dtype, device=flat_grads.device) if need_buf else None
                       for s, e in self.ranges]
@@ -116,27 +156,42 @@ class GradReducer:
             h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             self._pending.append((h, buf, view))
 
-    def reduce_sparse_rows(self, row_ids: torch.Tensor):
+    def reduce_sparse_rows(self, row_ids: torch.Tensor, capacity: Optional[int] = None):
         """Row-sparse exchange for the word-embedding gradient: row_ids = this rank's touched rows (any order, may
-        repeat); its length (B*L) must be the same on every rank.  Result: table gradient = mean over ranks, as the
-        dense all-reduce would give.  No host synchronisation: every shape is fixed by len(row_ids)."""
+        repeat).  Every rank contributes a block of `capacity` (id, row) slots, padded with a sentinel id whose row is
+        zero, so `capacity` -- not len(row_ids) -- must be the same on every rank (the reference's collate pads to the
+        per-batch maximum, tasks.py:322-364: the token count DIFFERS across ranks).  capacity=None takes the maximum of
+        len(row_ids) over the ranks (one scalar all-reduce + a host read; pass B * max_txt_len to avoid the
+        synchronisation).  Result: table gradient = mean over ranks, as the dense all-reduce would give."""
         if self.world == 1 or self.sparse is None:
             return
         off, n_rows, row_len = self.sparse
         table = self.g[off:off + n_rows * row_len].view(n_rows, row_len)
-        ids, _ = torch.sort(row_ids.reshape(-1).to(torch.long))
+        ids = row_ids.reshape(-1).to(torch.long)
+        if capacity is None:
+            t = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            capacity = int(t.item())
+        if ids.numel() > capacity:
+            raise ValueError(f"{ids.numel()} touched rows exceed the rank-independent capacity {capacity}")
+        if self.native is not None:
+            # the library communicator's own stream and communicator: ordered behind the dense buckets issued so far, no
+            # second communicator in flight and no wait on the compute stream
+            self.native.gather_rows(table, ids.contiguous(), capacity)
+            return
+        ids, _ = torch.sort(ids)
         first = torch.ones_like(ids, dtype=torch.bool)
         first[1:] = ids[1:] != ids[:-1]                                   # a repeated id contributes its row once
         rows = (table.index_select(0, ids) * first[:, None]).to(self.comm_dtype)
+        table.index_fill_(0, ids, 0.0)                                    # own rows come back inside the gathered block
+        pad = capacity - ids.numel()
+        if pad:                                                           # sentinel slots: row 0 with an all-zero contribution
+            ids = torch.cat([ids, ids.new_zeros(pad)])
+            rows = torch.cat([rows, rows.new_zeros(pad, row_len)])
         all_ids = [torch.empty_like(ids) for _ in range(self.world)]
         all_rows = [torch.empty_like(rows) for _ in range(self.world)]
-        if self.native is not None:
-            # two communicators (the library's and torch's) must not have collectives in flight at the same time: order
-            # torch's gathers after every bucket issued so far (NCCL/RCCL: concurrent communicators can deadlock)
-            self.native.wait()
         dist.all_gather(all_ids, ids, group=self.group)
         dist.all_gather(all_rows, rows, group=self.group)
-        table.index_fill_(0, ids, 0.0)                                    # own rows come back inside the gathered block
         inv = 1.0 / self.world
         table.index_add_(0, torch.cat(all_ids), torch.cat(all_rows).float() * inv)
 

@@ -36,6 +36,9 @@ class MlmStep:
             g = lambda k: float(c[k] if isinstance(c, dict) and k in c else getattr(c, k, 0.1))
             dropout = (g("hidden_dropout_prob"), g("attention_probs_dropout_prob"), g("pred_head_dropout_prob"), 0.0)
         self.dropout, self.drop_seed, self.step_no = dropout, int(drop_seed) & 0xFFFFFFFF, 0
+        # gradient accumulation (PretrainDriver): later micro-steps keep the arena (zero_grads False) and every micro-step's mean
+        # loss is scaled by 1 / accumulation steps (train_r2r.py:250-252)
+        self.zero_grads, self.loss_scale = True, 1.0
         B, Lt = batch["txt_ids"].shape
         Bp, V = batch["rgb_fts"].shape[:2]
         G = batch["gmap_step_ids"].shape[1]
@@ -106,7 +109,8 @@ class MlmStep:
         eng.set_dropout(None if self.dropout is None else
                         tuple(self.dropout) + ((self.drop_seed << 32) | (self.step_no & 0xFFFFFFFF),))
         check(L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
-        check(L.etp_planner_set_lazy_join(h, 0), "set_lazy_join")
+        check(L.etp_planner_set_aux2_stream(h, None), "set_aux2_stream")
+        check(L.etp_planner_set_lazy_join(h, 0), "set_lazy_join")      # (PlannerStep re-installs its own streams at every enqueue)
         # text weights first on the main stream; everything else (panorama / x-layer casts, the gradient memset) rides on the
         # panorama stream, whose join precedes the MLM forward and every backward kernel
         check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
@@ -114,7 +118,7 @@ class MlmStep:
         check(L.etp_stream_after(s, s2), "fork")
         check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
         check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
-        if backward:
+        if backward and self.zero_grads:
             check(L.etp_memset_async(ptr(eng.grads), 0, eng.grads.numel() * 4, s2), "memset grads")
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), Bp, V,
@@ -124,7 +128,7 @@ class MlmStep:
         check(L.etp_gather_sum(_lib.ETP_F32, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "aggregate")
         check(L.etp_mlm_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
                             ptr(i["gmask"]), ptr(self.sel[0]), ptr(self.sel[1]), ptr(self.sel[2]), ptr(self.labels), B, Lt, G,
-                            self.Nm, 1.0 / self.Nm, ptr(self.loss), ptr(self.st_mlm), s), "mlm_fwd")
+                            self.Nm, self.loss_scale / self.Nm, ptr(self.loss), ptr(self.st_mlm), s), "mlm_fwd")
         if not backward:
             return
         check(L.etp_mlm_bwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(i["pos"]), ptr(i["gmask"]),
@@ -203,11 +207,19 @@ class PretrainDriver:
 
     def __init__(self, model: GlocalTextPathNavCMT, loaders: Dict, learning_rate: float = 5e-5, warmup_steps: int = 10000,
                  num_train_steps: int = 100000, grad_norm: float = 5.0, accum_steps: int = 1, dropout="config", seed: int = 0,
-                 distributed: bool = False, max_cached_steps: int = 4, generator=None):
+                 distributed: bool = False, max_cached_steps: int = 4, generator=None, max_txt_len: int = 100):
+        """accum_steps = gradient_accumulation_steps of train_r2r.py:231-300: that many consecutive (task, batch) draws (the
+        MetaLoader keeps the task fixed over them, loader.py:61-63) each add the gradient of mean-loss / accum_steps to the
+        arena, then ONE reduction / clipping / optimizer step follows.  max_txt_len = the dataset's truncation length
+        (run_pt/r2r_pretrain_habitat.json: 100): with several ranks the row-sparse word-embedding exchange uses the
+        rank-independent capacity B * max_txt_len (the collate pads to the per-batch maximum, so L differs across ranks)."""
         from .optim import FusedAdamW, WarmupLinearLR
         from . import dp
-        if accum_steps != 1:
-            raise NotImplementedError("gradient_accumulation_steps > 1 (the reference's configs use 1: run_pt/*.json)")
+        if accum_steps < 1:
+            raise ValueError("accum_steps must be >= 1")
+        self.accum_steps, self.max_txt_len = int(accum_steps), int(max_txt_len)
+        self._micro = 0                     # micro-steps since the last optimizer step
+        self._touched = []                  # word rows touched by the SAP micro-steps of the current accumulation window
         self.model, self.dropout, self.seed = model, dropout, int(seed)
         self.meta = MetaLoader(loaders, accum_steps=accum_steps, distributed=distributed, device=model._engine.device,
                                generator=generator)
@@ -241,42 +253,60 @@ class PretrainDriver:
         return st
 
     def train_step(self, name: str, batch) -> torch.Tensor:
-        """One optimizer step on `batch` of task `name` ('sap...' / 'mlm...': the part before '_' selects the task, as
-        train_r2r.py:235).  Returns the device loss tensor (no host sync)."""
+        """One micro-step on `batch` of task `name` ('sap...' / 'mlm...': the part before '_' selects the task, as
+        train_r2r.py:235); every accum_steps-th call closes the window with the gradient reduction and the optimizer step.
+        Returns the device loss tensor of this micro-step, already scaled by 1 / accum_steps as the reference logs it
+        (no host sync)."""
         task = name.split("_")[0]
+        first = self._micro == 0
+        A = self.accum_steps
         if task == "sap":
             st = self._sap_step(batch)
-            st.step_no = self.global_step
+            st.step_no = self.global_step * A + self._micro
+            st.zero_grads = first
+            st.loss_scale = 1.0 / (st.B * A)
             st.run_eager()
-            ids = st.inp["txt_ids"]
+            if st.Lt > self.max_txt_len and self.distributed:
+                raise ValueError(f"instruction length {st.Lt} exceeds max_txt_len={self.max_txt_len} (the exchange capacity)")
+            self._touched.append((st.inp["txt_ids"].reshape(-1).clone() if A > 1 else st.inp["txt_ids"].reshape(-1), st.B))
         elif task == "mlm":
             st = MlmStep(self.model, batch, dropout=self.dropout, drop_seed=self.seed)
-            st.step_no = self.global_step
+            st.step_no = self.global_step * A + self._micro
+            st.zero_grads = first
+            st.loss_scale = 1.0 / A
             st.run_eager()
-            ids = None
         else:
             raise ValueError(f"unknown task {task!r}: this fork pre-trains with 'mlm' and 'sap' (pretrain_cmt.py:141-163,223-283)")
         loss = st.loss.clone()
+        self._micro += 1
+        self.task_losses.setdefault(name, []).append(loss)
+        if self._micro < A:
+            if task == "mlm":
+                torch.cuda.current_stream().synchronize()
+                st.close()
+            return loss
         if self.distributed:
             red = self.reducers[task]
             for i in range(len(red.ranges)):
                 red.reduce_bucket(i)
-            if ids is not None:
-                red.reduce_sparse_rows(ids)
+            if task == "sap":
+                ids = torch.cat([t for t, _ in self._touched]) if len(self._touched) > 1 else self._touched[0][0]
+                red.reduce_sparse_rows(ids, capacity=sum(b for _, b in self._touched) * self.max_txt_len)
             red.finish()
+        self._micro = 0
+        self._touched = []
         self.global_step += 1
         self.lr_history.append(self.sched.step(self.global_step))
         self.opt.step()
         if task == "mlm":
             torch.cuda.current_stream().synchronize()      # the per-batch MLM step object is released: its buffers must be idle
             st.close()
-        self.task_losses.setdefault(name, []).append(loss)
         return loss
 
     def run(self, num_steps: int):
         it = iter(self.meta)
         out = []
-        for _ in range(num_steps):
+        for _ in range(num_steps * self.accum_steps):       # num_steps OPTIMIZER steps
             name, batch = next(it)
             out.append((name, self.train_step(name, batch)))
         return out

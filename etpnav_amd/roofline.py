@@ -119,3 +119,41 @@ def step_roofline(cfg, B: int, L: int, V: int, G: int, Bp: int = None, peak_flop
     return {"t_roof_ms": t * 1e3, "flops": flops, "hbm_bytes": by, "kernels": len(ks),
             "t_mfma_bound_ms": t_mfma * 1e3, "t_hbm_bound_ms": (t - t_mfma) * 1e3,
             "peak_flops": peak_flops, "peak_hbm_bytes_per_s": peak_bps}
+
+
+def fused_plan_roofline(cfg, B: int, L: int, V: int, G: int, Bp: int = None, peak_flops: float = PEAK_BF16_FLOPS,
+                        peak_bps: float = PEAK_HBM_BPS) -> Dict[str, float]:
+    """The byte model of SURVEY.md §8(d) ("fused-kernel plan"): what a fully fused implementation would have to move.
+    Per transformer layer and direction ONE fused kernel: forward reads the layer's bf16 weights (2 B / parameter) and writes
+    the saved activations once, (6H + I) * 2 B per token (x, q, k, v, ctx, LN-out, FFN pre-activation); backward reads the
+    weights again (2 B), writes fp32 weight gradients (4 B), reads the saved activations once and moves an equal volume of
+    gradient streams.  FLOPs as SURVEY Appendix C (2MNK, backward = 2x forward).  t_roof = sum over these fused kernels of
+    max(flops / peak_mfma, bytes / peak_hbm)."""
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    Fi, Fd = cfg.image_feat_size, cfg.depth_feat_size
+    Bp = B if Bp is None else Bp
+    Mt, Mp, Mg = B * L, Bp * V, B * G
+    act = (6 * H + I) * 2.0                                      # saved bytes per token-layer
+    ks = []
+
+    def layer(tokens, w_params, fwd_flops):
+        ks.append((fwd_flops, w_params * 2.0 + tokens * act))                          # forward
+        ks.append((2.0 * fwd_flops, w_params * 6.0 + tokens * act * 2.0))              # backward
+
+    lin = 8 * H * H + 4 * H * I                                  # per-token linear FLOPs of a BERT / pano layer
+    w_layer = 4 * H * H + 2 * H * I
+    for _ in range(cfg.num_l_layers):
+        layer(Mt, w_layer, Mt * lin + B * 4.0 * L * L * H)
+    ks.append((Mp * 2.0 * H * (Fi + Fd + 4), H * (Fi + Fd) * 2.0 + Mp * (Fi + Fd) * 4.0 + Mp * H * 2.0))
+    ks.append((2.0 * Mp * 2.0 * H * (Fi + Fd + 4), H * (Fi + Fd) * 6.0 + Mp * (Fi + Fd) * 2.0 + Mp * H * 4.0))
+    for _ in range(cfg.num_pano_layers):
+        layer(Mp, w_layer, Mp * lin + Bp * 4.0 * V * V * H)
+    for _ in range(cfg.num_x_layers):
+        fl = B * G * 4.0 * H * H + B * L * 4.0 * H * H + B * 4.0 * G * L * H + B * G * 8.0 * H * H + B * 4.0 * G * G * H \
+            + B * G * 4.0 * H * I
+        tokens = Mg * 1.7 + Mt * (2 * H * 2.0) / act             # node sub-blocks (~1.7 layer equivalents) + the text K/V rows
+        layer(tokens, 8 * H * H + 2 * H * I, fl)
+    ks.append((Mg * (2.0 * H * H + 2 * H), H * H * 2.0 + Mg * H * 4.0))
+    ks.append((2.0 * Mg * (2.0 * H * H + 2 * H), H * H * 6.0 + Mg * H * 6.0))
+    t = sum(max(f / peak_flops, by / peak_bps) for f, by in ks)
+    return {"t_roof_ms": t * 1e3, "flops": sum(f for f, _ in ks), "hbm_bytes": sum(b for _, b in ks), "kernels": len(ks)}

@@ -146,15 +146,23 @@ class PlannerStep:
             a2 = ctypes.c_void_p()
             check(self.L.etp_stream_create(ctypes.byref(a2)), "stream_create")
             self.aux2 = a2.value
-        check(self.L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
-        check(self.L.etp_planner_set_aux2_stream(h, self.aux2), "set_aux2_stream")
-        # navigation / panorama weight gradients keep running on the aux stream while the text backward starts; the text
-        # backward's own join (or the explicit one in enqueue_main) completes them
-        check(self.L.etp_planner_set_lazy_join(h, 1 if self.aux is not None else 0), "set_lazy_join")
+        self._lazy = 1 if self.aux is not None else 0
+        self._install_streams()
         self._pano_pending = False
         self.graph = None
         self.graphs = []
         self.stream = None
+
+    def _install_streams(self):
+        """The planner handle is shared by every step object of a model (PretrainDriver alternates MlmStep and several cached
+        PlannerSteps): its side streams and lazy-join level are (re)installed at every enqueue, so a step never runs on another
+        step's streams or silently loses its overlap schedule.  navigation / panorama weight gradients keep running on the aux
+        stream while the text backward starts; the text backward's own join (or the explicit one in enqueue_main) completes
+        them."""
+        h = self.eng.handle
+        check(self.L.etp_planner_set_aux_stream(h, self.aux), "set_aux_stream")
+        check(self.L.etp_planner_set_aux2_stream(h, self.aux2), "set_aux2_stream")
+        check(self.L.etp_planner_set_lazy_join(h, self._lazy), "set_lazy_join")
 
     def shape_key(self):
         return (self.B, self.Lt, self.Bp, self.V, self.G)
@@ -170,6 +178,9 @@ class PlannerStep:
         streams are reused; only the small CSR index arrays of the node aggregation are rebuilt)."""
         if self.batch_shape_key(batch) != self.shape_key():
             raise ValueError(f"batch shapes {self.batch_shape_key(batch)} differ from this step's {self.shape_key()}")
+        if self.graphs:
+            # the CSR index tensors below are re-allocated: kernel nodes of an existing graph would keep the old pointers
+            raise RuntimeError("load_batch() on a step with captured / recorded graphs: close() the graphs (or build a new step) first")
         names = {"txt_ids": "txt_ids", "txt_masks": "txt_masks", "rgb": "rgb_fts", "dep": "dep_fts", "loc": "loc_fts", "nav": "nav_types",
                  "view_lens": "view_lens", "step_ids": "gmap_step_ids", "pos": "gmap_pos_fts", "gmask": "gmap_masks",
                  "visited": "gmap_visited_masks", "dists": "gmap_pair_dists", "labels": "labels"}
@@ -190,6 +201,7 @@ class PlannerStep:
     def _enqueue_pano_bwd(self, s: int):
         L, h, i = self.L, self.eng.handle, self.inp
         s2 = self.s2 if self.s2 is not None else s
+        self._install_streams()
         self.eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
         check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), self.Bp, self.V, None,
@@ -212,6 +224,7 @@ class PlannerStep:
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
         dt = _lib.ETP_F32          # node assembly works on the fp32 API tensors
         self.step_no += 1
+        self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
         # weight-shadow refresh and gradient zeroing ride on the stream that first needs them: the text cast on the main
@@ -248,6 +261,7 @@ class PlannerStep:
         L, eng, h, i = self.L, self.eng, self.eng.handle, self.inp
         B, Lt, V, G, H = self.B, self.Lt, self.V, self.G, eng.cconf.hidden
         dt = _lib.ETP_F32
+        self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
         check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
@@ -275,6 +289,7 @@ class PlannerStep:
         L, eng, i = self.L, self.eng, self.inp
         if layer_hi is None:
             layer_hi = eng.cconf.n_l
+        self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(eng.handle, int(self.grad_overwrite)), "set_grad_overwrite")
         check(L.etp_txt_bwd_range(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
@@ -308,10 +323,10 @@ class PlannerStep:
         if head > 0:
             lazy = self.aux is not None
             if lazy:      # the top layers' weight gradients keep running while the chain continues (no join between the ranges)
-                check(self.L.etp_planner_set_lazy_join(self.eng.handle, 2), "set_lazy_join")
+                self._lazy = 2
             self.enqueue_txt_bwd(s, n_l - head, n_l)
             if lazy:
-                check(self.L.etp_planner_set_lazy_join(self.eng.handle, 1), "set_lazy_join")
+                self._lazy = 1
             self._enqueue_pano_bwd(s)
             self.enqueue_txt_bwd(s, 0, n_l - head)
         else:
@@ -420,16 +435,20 @@ class PlannerStep:
 
 class MicroBatchedStep:
     """The same training step (one gradient of the mean loss over the whole batch, ss_trainer_ETP.py:892,1055) issued as
-    `n_micro` micro-batches on INDEPENDENT stream sets.
+    `n_micro` micro-batches -- a GRADIENT-ACCUMULATION facility for a batch whose activations do not fit, not a
+    performance mode.
 
-    A planner step is a dependent chain of ~240 short kernels: each one ramps up, runs a few microseconds
-    at partial occupancy and drains before the next may start, and those fixed costs -- not bandwidth or MFMA rate -- bound
-    the step.  Two half-batch chains have no dependency on each other, so the hardware runs one chain's kernel in the other's
-    ramp / drain gaps; the per-kernel work halves while the fixed cost is hidden instead of paid twice.  Gradients: the first
-    micro-batch's weight-gradient GEMMs store (first touch), the others accumulate behind it on the shared weight-gradient
-    stream (in issue order, so no atomics are needed on the matrices); vector / table gradients are atomics as before.  The
-    loss of every micro-batch is scaled by 1/B of the WHOLE batch, so the arena ends up with exactly the full-batch gradient
-    (fp32 summation order aside).  Dropout draws an independent mask stream per micro-batch."""
+    Measured on MI355X (profiles/r02s_bench_micro*.json): 2 micro-batches 10.8-13.7 ms, 4 micro-batches
+    25.8 ms against 4.4 ms for the single chain.  The idea that one chain's kernels would fill the other's launch / drain
+    gaps does not hold on this chip: a half-batch chain takes as long as the full-batch one (its kernels are bound by the
+    per-launch latency, not by work), and the chains meet on the shared weight-gradient stream, where the later
+    micro-batches must accumulate behind the first one's stores in issue order.
+    Gradients: the first micro-batch's weight-gradient GEMMs store (first touch), the others accumulate behind it on the
+    shared weight-gradient stream (in issue order, so no atomics are needed on the matrices); vector / table gradients are
+    atomics as before.  The loss of every micro-batch is scaled by 1/B of the WHOLE batch, so the arena ends up with exactly
+    the full-batch gradient (fp32 summation order aside; tests/test_planner_gpu.py).  Dropout draws an independent mask
+    stream per micro-batch.  The pre-training loop's gradient_accumulation_steps (train_r2r.py:231-300) is implemented in
+    etpnav_amd.pretrain.PretrainDriver on whole task batches instead."""
 
     def __init__(self, model: GlocalTextPathNavCMT, batch: Dict[str, torch.Tensor], n_micro: int = 2, dropout=None,
                  drop_seed: int = 0):

@@ -107,7 +107,8 @@ typedef struct etp_attn_desc {
 } etp_attn_desc;
 int etp_attn_fwd(const etp_attn_desc* d, etp_stream_t stream);
 typedef struct etp_attn_bwd_desc {
-  etp_attn_desc f;              /* same as forward (ctx unused) */
+  etp_attn_desc f;              /* same as forward; ctx / ldc MUST be the forward's output: the bf16 kernels keep only lse in P and
+                                 * recompute from it (Lq or Lk > 128 also read ctx for D = rowsum(dO * O)) */
   const void* dctx; int64_t ldd;
   void* dP;                     /* scratch [B,heads,Lq,ldS] */
   void* dQ; int64_t lddq; void* dK; int64_t lddk; void* dV; int64_t lddv;
@@ -425,6 +426,16 @@ typedef struct etp_comm etp_comm;
 int etp_allreduce_unique_id(void* id_out_128_bytes);
 int etp_allreduce_init(etp_comm** out, const void* unique_id, int rank, int world, int comm_dtype, int64_t max_bucket_elems);
 int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_t producer);
+/* Row-sparse mean of a table gradient [n_rows, row_len] (the word-embedding table: a step touches <= B*L of its 30 522 /
+ * 250 002 rows; DDP would all-reduce the dense table, ss_trainer_ETP.py:208-212).  ids[0, n_ids) = rows this rank touched (any
+ * order, repeats allowed); `capacity` >= n_ids is the rank-INDEPENDENT block size (e.g. B * max_txt_len; the reference's collate
+ * pads to the per-batch maximum, pretrain_src/pretrain_src/data/tasks.py:322-364, so the token count differs across ranks --
+ * the capacity must not).  pack (repeats masked on the device) -> ncclAllGather of (ids, rows) -> scatter-add x 1/world, on the
+ * communicator's own stream after `producer`: the same communicator and stream as the dense buckets. */
+int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t row_len, const int64_t* ids, int64_t n_ids,
+                              int64_t capacity, etp_stream_t producer);
+/* 1 when librccl can be bound in this process (ranks agree on it before any of them enters etp_allreduce_init) */
+int etp_allreduce_available(void);
 int etp_allreduce_wait(etp_comm* c, etp_stream_t consumer);
 int etp_allreduce_destroy(etp_comm* c);
 int etp_allreduce_rank(const etp_comm* c);

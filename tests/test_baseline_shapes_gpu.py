@@ -11,7 +11,7 @@ surfaces that had no oracle check:
 
 All through the C ABI of libetpnav_hip.so.  Tolerances as tests/test_planner_gpu.py: fp32 2e-4 abs (+2e-3 relative on
 gradients; BASELINE.json asks 1e-3), bf16 5e-2 outputs / per-tensor RELATIVE gradient bounds (golden_util.compare_grads_bf16,
-compare_full_bf16: 6 % of the tensor's abs-max on samples, 5 % on its L2, cosine >= 0.995).
+compare_full_bf16: 10 % of the tensor's abs-max on samples, 5 % on its L2 norm, relative L2 error <= 12 %, cosine >= 0.99).
 """
 import os
 import tempfile
@@ -84,6 +84,31 @@ def test_benchmarked_shape_b32_bf16_train_mode_close_to_oracle():
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
     assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
     print("bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
+    step.close()
+
+
+@pytest.mark.parametrize("workload", ["c4", "c5"])
+def test_other_benchmarked_shapes_bf16_train_mode_close_to_oracle(workload):
+    """The per-GPU shapes of BASELINE.json configs[3] (RxR: XLM-R vocabulary, L = 512, B = 16) and configs[4] (64 graph
+    nodes, B = 8) exactly as `bench.py --workload c4 / c5` runs them (bf16, dropout on) against the oracle applying the
+    same masks: until round 3 these shapes had parity runs at B = 2 only (VERDICT r2 weak #3)."""
+    w = {"c4": dict(task="rxr", B=16, L=512, V=36, G=16), "c5": dict(task="r2r", B=8, L=80, V=36, G=64)}[workload]
+    cfg = (po.PlannerConfig.rxr if w["task"] == "rxr" else po.PlannerConfig.r2r)(image_feat_size=768)
+    P = po.init_params(cfg, seed=0)
+    batch = po.make_batch(cfg, B=w["B"], L=w["L"], V=w["V"], G=w["G"], seed=1234, ragged=False)
+    rates = (0.1, 0.1, 0.1, 0.4)
+    outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*rates, seed=(4 << 32) | 1))
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch, dropout=rates, drop_seed=4)
+    step.run_eager()
+    got = step_outputs(step)
+    for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
+        assert (got[k].float().cpu() - outs[k]).abs().max().item() < 8e-2, k
+    fin = torch.isfinite(outs["global_logits"])
+    assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
+    assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
+    assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
+    print(workload, "bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
     step.close()
 
 

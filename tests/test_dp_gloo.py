@@ -15,7 +15,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, comm_dtype, q):
+def _ids_of(r, ragged):
+    # ragged: the ranks touch DIFFERENT numbers of rows (the reference's collate pads to the per-batch maximum, so B*L differs
+    # across ranks: ADVICE r2) -- the exchange must use a rank-independent capacity, not len(row_ids)
+    return torch.tensor([3 + r, 7, 7, 20 + 2 * r] + ([31, 7, 40] if (ragged and r == 1) else []))
+
+
+def _worker(rank, world, port, comm_dtype, q, ragged=False, capacity=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -27,15 +33,15 @@ def _worker(rank, world, port, comm_dtype, q):
             g = torch.Generator().manual_seed(100 + r)
             grads[r] = torch.randn(n, generator=g)
             table = grads[r][1000:].view(n_rows, row_len)
-            ids_r = torch.tensor([3 + r, 7, 7, 20 + 2 * r])
+            ids_r = _ids_of(r, ragged)
             mask = torch.zeros(n_rows, dtype=torch.bool); mask[ids_r] = True
             table[~mask] = 0                                     # row-sparse, as an embedding gradient is
         mine = grads[rank].clone()
-        ids = torch.tensor([3 + rank, 7, 7, 20 + 2 * rank])
+        ids = _ids_of(rank, ragged)
         red = dp.GradReducer(mine, [(600, 1000), (0, 600)], comm_dtype=comm_dtype, sparse_rows=(1000, n_rows, row_len))
         red.reduce_bucket(0)
         red.reduce_bucket(1)
-        red.reduce_sparse_rows(ids)
+        red.reduce_sparse_rows(ids, capacity=capacity)
         red.finish()
         if comm_dtype == torch.float32:
             expect = sum(grads) / world
@@ -49,12 +55,15 @@ def _worker(rank, world, port, comm_dtype, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
-def test_grad_reducer_world2_gloo(comm_dtype):
+@pytest.mark.parametrize("comm_dtype,ragged,capacity", [(torch.float32, False, None), (torch.bfloat16, False, None),
+                                                        (torch.float32, True, 12), (torch.float32, True, None)])
+def test_grad_reducer_world2_gloo(comm_dtype, ragged, capacity):
+    """ragged + capacity=12: fixed rank-independent block size; ragged + capacity=None: the maximum length is agreed with
+    one scalar all-reduce.  Both must give the dense mean although rank 1 touches 7 rows and rank 0 four."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_dtype, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_dtype, q, ragged, capacity)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

