@@ -213,8 +213,8 @@ __device__ __forceinline__ void frag_load(Frag<T>& f, const char* lds, int row16
 // profiles/r02_gemm_sweep.json).  Larger tiles keep the fetch in the epilogue (too many registers).
 // (No arrays in these structs on purpose: a runtime-indexed member array keeps the whole object in scratch memory.)
 struct EpiChunk { uint4 r0, r1, c0, c1, z0, z1; };
-template <typename T, typename TC, int BM, int BN> struct EpiPre {
-  static constexpr int NCHUNK = BM * (BN / 8) / 256;
+template <typename T, typename TC, int BM, int BN, int NTH = 256> struct EpiPre {
+  static constexpr int NCHUNK = BM * (BN / 8) / NTH;
   static constexpr bool ON = NCHUNK <= 2;
   EpiChunk k0, k1;
   bool valid;
@@ -223,11 +223,40 @@ template <typename T, typename TC, int BM, int BN> struct EpiPre {
   float4 b0, b1;
   bool bias_valid;
 };
-template <typename T, typename TC, int BN>
+// The activation-backward operand Z (bf16, one 16-byte vector per chunk) of tiles whose other epilogue operands are NOT
+// prefetched (128x128: 8 chunks per thread): the GELU-backward dgrad of the FFN spent 11 us of its 25 in the epilogue, two
+// dependent global round trips behind the reduction (profiles/r03_gemm_phases.txt); fetched before the reduction instead.
+// Indexed only with compile-time constants (fully unrolled loops), so it stays in registers.
+// Named members + a select chain instead of an array: a member array indexed by a loop variable lands in scratch memory
+// whenever the loop is not fully unrolled (the epilogue's chunk loops carry an early exit).
+template <int N> struct ZPre {
+  uint4 z0, z1, z2, z3, z4, z5, z6, z7;
+  bool valid;
+  __device__ __forceinline__ uint4 get(int i) const {
+    return i == 0 ? z0 : i == 1 ? z1 : i == 2 ? z2 : i == 3 ? z3 : i == 4 ? z4 : i == 5 ? z5 : i == 6 ? z6 : z7;
+  }
+};
+template <typename T, typename TC, int BM, int BN, int NTH>
+__device__ __forceinline__ void z_prefetch(ZPre<BM * (BN / 8) / NTH>& zp, const GemmArgs& g, int m0, int n0, int tid) {
+  constexpr int N = BM * (BN / 8) / NTH, CPRW = BN / 8;
+  zp.valid = false;
+  if constexpr (sizeof(T) == 2 && (N == 4 || N == 8)) {
+    if (!g.vec_epilogue || !(g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD)) return;
+    zp.valid = true;
+#define ETP_ZFETCH(j)                                                                                             \
+  (*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.Z) + (long)min(m0 + (tid + (j) * NTH) / CPRW, g.M - 1) * g.ldz + \
+                                   min(n0 + ((tid + (j) * NTH) % CPRW) * 8, (g.N - 1) / 8 * 8)))
+    zp.z0 = ETP_ZFETCH(0); zp.z1 = ETP_ZFETCH(1); zp.z2 = ETP_ZFETCH(2); zp.z3 = ETP_ZFETCH(3);
+    if constexpr (N > 4) { zp.z4 = ETP_ZFETCH(4); zp.z5 = ETP_ZFETCH(5); zp.z6 = ETP_ZFETCH(6); zp.z7 = ETP_ZFETCH(7); }
+#undef ETP_ZFETCH
+  }
+}
+
+template <typename T, typename TC, int BN, int NTH = 256>
 __device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmArgs& g, const TC* C, int m0, int n0, int ks, int tid) {
   constexpr int CPRW = BN / 8;
   constexpr int VPC = 8 * (int)sizeof(TC) / 16, VPT = 8 * (int)sizeof(T) / 16;
-  const int q = tid + j * 256;
+  const int q = tid + j * NTH;
   const int lr = q / CPRW, lc = (q % CPRW) * 8;
   const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, (g.N - 1) / 8 * 8);
   if (g.R != nullptr) {
@@ -246,11 +275,11 @@ __device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmAr
     if constexpr (VPT == 2) k.z1 = p[1];
   }
 }
-template <typename T, typename TC, int BM, int BN>
-__device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN>& pre, const GemmArgs& g, const TC* C, int m0, int n0, int ks,
+template <typename T, typename TC, int BM, int BN, int NTH = 256>
+__device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN, NTH>& pre, const GemmArgs& g, const TC* C, int m0, int n0, int ks,
                                              int tid) {
-  using E = EpiPre<T, TC, BM, BN>;
-  static_assert(256 % (BN / 8) == 0, "a thread's chunks must share their columns");
+  using E = EpiPre<T, TC, BM, BN, NTH>;
+  static_assert(NTH % (BN / 8) == 0, "a thread's chunks must share their columns");
   pre.valid = false;
   pre.bias_valid = false;
   if (!g.vec_epilogue) return;
@@ -262,15 +291,18 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN>& pre, const G
   }
   if constexpr (E::ON) {
     pre.valid = true;
-    epi_fetch_chunk<T, TC, BN>(pre.k0, 0, g, C, m0, n0, ks, tid);
-    if constexpr (E::NCHUNK == 2) epi_fetch_chunk<T, TC, BN>(pre.k1, 1, g, C, m0, n0, ks, tid);
+    epi_fetch_chunk<T, TC, BN, NTH>(pre.k0, 0, g, C, m0, n0, ks, tid);
+    if constexpr (E::NCHUNK == 2) epi_fetch_chunk<T, TC, BN, NTH>(pre.k1, 1, g, C, m0, n0, ks, tid);
   }
 }
 
 // Epilogue shared by both GEMM kernels (register-staged and LDS-DMA main loops).
-template <typename T, typename TC, int BM, int BN>
+// NTH threads run the store phase; the accumulators belong to the first four wavefronts (the warp-specialised kernel's loader
+// wavefronts 4..7 own none and skip the staging writes).
+template <typename T, typename TC, int BM, int BN, int NTH = 256>
 __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], char* smem, const GemmArgs& g, TC* C, int m0,
-                                              int n0, int ks, int tid, const EpiPre<T, TC, BM, BN>& pre) {
+                                              int n0, int ks, int tid, const EpiPre<T, TC, BM, BN, NTH>& pre,
+                                              const ZPre<BM * (BN / 8) / NTH> zp) {
   constexpr int MT = BM / 32, NT = BN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -281,18 +313,20 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
   const int i = lane & 15, gq = lane >> 4;
   constexpr int CP = BN + 4;
   float* ct = reinterpret_cast<float*>(smem);
+  if (NTH == 256 || wave < 4) {
 #pragma unroll
-  for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+      for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r)
+          ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
+  }
   __syncthreads();
   const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
   T* Z = reinterpret_cast<T*>(g.Z);
   constexpr int CPRW = BN / 8;                     // 8-column chunks per tile row
-  constexpr int NCHUNK = BM * CPRW / 256;
+  constexpr int NCHUNK = BM * CPRW / NTH;
   if (g.vec_epilogue) {
     // Phase A: issue every global read of the epilogue (residual / activation operand / old C) up front from
     // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
@@ -310,7 +344,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
     uint4 rr[HC][VPC], cc[HC][VPC], zz[HC][VPT];
     const bool use_pre = pre.valid;
     if (use_pre) {
-      if constexpr (EpiPre<T, TC, BM, BN>::ON) {      // fetched before the main loop (these tiles have HC == NCHUNK <= 2: one pass)
+      if constexpr (EpiPre<T, TC, BM, BN, NTH>::ON) {      // fetched before the main loop (these tiles have HC == NCHUNK <= 2: one pass)
         rr[0][0] = pre.k0.r0; cc[0][0] = pre.k0.c0; zz[0][0] = pre.k0.z0;
         if constexpr (VPC == 2) { rr[0][1] = pre.k0.r1; cc[0][1] = pre.k0.c1; }
         if constexpr (VPT == 2) zz[0][1] = pre.k0.z1;
@@ -324,7 +358,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
 #pragma unroll
     for (int jh = 0; jh < HC; ++jh) {
       if (use_pre) break;
-      const int jj = jh, q = tid + (h0 + jh) * 256;
+      const int jj = jh, q = tid + (h0 + jh) * NTH;
       const int lr = q / CPRW, lc = (q % CPRW) * 8;
       const int rowc = min(m0 + lr, g.M - 1), colc = min(n0 + lc, col_last);
       if (has_r) {
@@ -338,15 +372,19 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
         for (int u = 0; u < VPC; ++u) cc[jj][u] = p[u];
       }
       if (has_zr) {
-        const uint4* p = reinterpret_cast<const uint4*>(Z + (long)rowc * g.ldz + colc);
+        if (zp.valid) {
+          if constexpr (VPT == 1) zz[jj][0] = zp.get(h0 + jh);
+        } else {
+          const uint4* p = reinterpret_cast<const uint4*>(Z + (long)rowc * g.ldz + colc);
 #pragma unroll
-        for (int u = 0; u < VPT; ++u) zz[jj][u] = p[u];
+          for (int u = 0; u < VPT; ++u) zz[jj][u] = p[u];
+        }
       }
     }
     // Phase B: combine and store
 #pragma unroll
     for (int jh = 0; jh < HC; ++jh) {
-      const int jj = jh, q = tid + (h0 + jh) * 256;
+      const int jj = jh, q = tid + (h0 + jh) * NTH;
       const int lr = q / CPRW, lc = (q % CPRW) * 8;
       const int row = m0 + lr, col = n0 + lc;
       const bool ok = row < g.M && col < g.N;
@@ -422,7 +460,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
     return;
   }
   // scalar fallback (odd leading dimensions / unaligned bases): one element per thread-iteration, row-major
-  for (int q = tid; q < BM * BN; q += 256) {
+  for (int q = tid; q < BM * BN; q += NTH) {
     const int lr = q / BN, lc = q % BN;
     const int row = m0 + lr, col = n0 + lc;
     if (row >= g.M || col >= g.N) continue;
@@ -548,7 +586,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   EpiPre<T, TC, BM, BN> pre;
   pre.valid = false;
   pre.bias_valid = false;
-  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
+  ZPre<BM * (BN / 8) / 256> zp;
+  zp.valid = false;
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
 }
 
 // =========================================================================================================
@@ -572,7 +612,7 @@ template <typename T, bool TR, int ROWS>
 __device__ __forceinline__ void dma_plan(DmaPlan<T, TR, ROWS>& p, const T* base, long ld, int row0, int rows_total, int k0,
                                          int tid) {
   using G = TileGeom<T, TR, ROWS, 0>;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = (tid >> 6) & 3;      // (loader wavefronts 4..7 of the warp-specialised kernel map to 0..3)
 #pragma unroll
   for (int j = 0; j < DmaPlan<T, TR, ROWS>::PER_WAVE; ++j) {
     const int piece = j * 4 + wave;
@@ -720,6 +760,8 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
 
   EpiPre<T, TC, BM, BN> pre;
   epi_prefetch<T, TC, BM, BN>(pre, g, C, m0, n0, ks, tid);     // epilogue operands travel while the reduction runs
+  ZPre<BM * (BN / 8) / 256> zp;
+  z_prefetch<T, TC, BM, BN, 256>(zp, g, m0, n0, tid);
 
   const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
   float colsum_acc = 0.f;
@@ -830,8 +872,143 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     if (do_colsum && m0 + (tid % BM) < g.M) atomicAdd(g.a_colsum + m0 + (tid % BM), colsum_acc);
   }
   __syncthreads();
-  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre);
+  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
   probe_end(probe, g, rec, nk);
+}
+
+// =========================================================================================================
+// Warp-specialised variant (round 3): 512 threads = 4 COMPUTE wavefronts (2x2 over the tile, fragments + MFMA, as above)
+// + 4 LOADER wavefronts that do nothing but issue the LDS-DMA pieces and wait for them.
+//
+// Why: the phase probe (profiles/r03_gemm_phases.txt) shows 930 cycles per slab on a 128x64 tile with one workgroup per CU
+// for 256 cycles of MFMA work, whatever the ring depth (sweep: ring 3 = ring 4), and the builds that run only one half of
+// the loop (ETP_GEMM_EXPT) put the DMA half at ... cycles and the MFMA half at ... : a global_load_lds piece occupies its
+// wavefront for 60-185 cycles of issue (MI355X_MICROARCH.md "LDS-DMA piece issue cost"), six to eight pieces per slab,
+// and an in-order wavefront cannot issue its MFMAs meanwhile.  With one wavefront per SIMD nothing else owns the matrix
+// pipe during that time.  Here every SIMD hosts one loader and one compute wavefront: the vector-memory issue of the one
+// runs beside the MFMA stream of the other (separate issue ports), and a slab costs max(DMA issue, MFMA) instead of
+// their sum.  One s_barrier per slab for all eight wavefronts:
+//
+//     compute:  frags(t,1) <- LDS || MFMA(t,0);  [lgkmcnt(0)]  s_barrier;  frags(t+1,0) <- LDS || MFMA(t,1)
+//     loader :                        [slab t+1 landed: vmcnt]  s_barrier;  issue slab t+STAGES into slab t's buffer
+//
+// Used for the tile classes that run ONE workgroup per CU (128x64 on the M = 2560, N = 768 products, 64x64 on the
+// M = 512 node products); the 128x128 class keeps two 256-thread workgroups per CU (its registers do not allow four
+// wavefronts per SIMD).
+// =========================================================================================================
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__device__ __forceinline__ void ws_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem, int rec) {
+  using GA = TileGeom<T, TA, BM, 0>;
+  using GB = TileGeom<T, TB, BN, 0>;
+  constexpr int BK = MmaTraits<T>::BK;
+  constexpr int KS = BK / 32;
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int STAGE = GA::BYTES + GB::BYTES;
+  constexpr int PER_SLAB = DmaPlan<T, TA, BM>::PER_WAVE + DmaPlan<T, TB, BN>::PER_WAVE;
+  static_assert(KS == 2, "the warp-specialised kernel is built for bf16 operands (two MFMA k-steps per slab)");
+  static_assert(!TA, "weight-gradient (TN) products use the grouped kernel");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int wr = (wave & 3) >> 1, wc = wave & 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+  PhaseProbe probe;
+  probe_begin(probe, g);
+
+  int kbeg = 0, kend = g.K;
+  if (g.ksplit > 1) {
+    const int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
+    kbeg = ks * per;
+    kend = min(g.K, kbeg + per);
+  }
+  const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  EpiPre<T, TC, BM, BN, 512> pre;
+
+  if (loader) {
+    // ---------------- loader wavefronts ----------------
+    DmaPlan<T, TA, BM> pa;
+    DmaPlan<T, TB, BN> pb;
+    dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
+    dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+      if (s < nk) {
+        dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
+        dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
+      }
+    epi_prefetch<T, TC, BM, BN, 512>(pre, g, C, m0, n0, ks, tid);
+    if (nk > 0) {
+      wait_slabs<PER_SLAB, STAGES - 1>(min(STAGES - 1, nk - 1));
+      __builtin_amdgcn_s_barrier();
+    }
+    for (int t = 0; t + 1 < nk; ++t) {
+      wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 2 - t));   // slab t+1 landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();                                     // compute waves hold slab t in registers: its buffer is free
+      if (t + STAGES < nk) {
+        const unsigned dst = lds0 + (t % STAGES) * STAGE;
+        dma_issue<T, TA, BM>(pa, dst, g.lda);
+        dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);
+      }
+    }
+    wait_vmcnt<0>();
+  } else {
+    // ---------------- compute wavefronts ----------------
+    epi_prefetch<T, TC, BM, BN, 512>(pre, g, C, m0, n0, ks, tid);
+    Frag<T> fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    if (nk > 0) {
+      __builtin_amdgcn_s_barrier();
+      load_frags<T, TA, TB, BM, BN>(fa0, fb0, smem, smem + GA::BYTES, 0, wr, wc, lane);
+    }
+    if (probe.on) probe.mt1 = __builtin_amdgcn_s_memtime();
+#define ETP_MMA_SET(FA, FB)                                            \
+  _Pragma("unroll") for (int a = 0; a < MT; ++a)                       \
+      _Pragma("unroll") for (int b = 0; b < NT; ++b) mma_step(acc[a][b], FA[a], FB[b]);
+    int t = 0;
+    for (; t + 1 < nk; ++t) {
+      const char* sa = smem + (t % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // all of slab t is in this wave's registers
+      __builtin_amdgcn_s_barrier();
+      const char* sn = smem + ((t + 1) % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa0, fb0, sn, sn + GA::BYTES, 0, wr, wc, lane);
+      ETP_MMA_SET(fa1, fb1)
+    }
+    if (t < nk) {
+      const char* sa = smem + (t % STAGES) * STAGE;
+      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
+      ETP_MMA_SET(fa0, fb0)
+      ETP_MMA_SET(fa1, fb1)
+    }
+#undef ETP_MMA_SET
+    if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();
+  }
+  __syncthreads();
+  ZPre<BM * (BN / 8) / 512> zp;
+  zp.valid = false;                       // (these tiles have <= 2 chunks per thread: Z travels with EpiPre)
+  gemm_epilogue<T, TC, BM, BN, 512>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
+  probe_end(probe, g, rec, nk);
+}
+
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
+  const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
+  const int zo = z / g.nb_inner, zi = z % g.nb_inner;
+  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  ws_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // __launch_bounds__(256, w): w = wavefronts per SIMD the grid needs (2 for the 128-row tiles, 3 for 64x64).  Without it
@@ -989,6 +1166,47 @@ static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
   return ETP_OK;
 }
 
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+static int launch_ws_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
+  using GA = TileGeom<T, TA, BM, 0>;
+  using GB = TileGeom<T, TB, BN, 0>;
+  constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
+  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
+  static_assert(smem <= 160 * 1024, "ring exceeds the CU's LDS");
+  static bool attr_set = false;
+  void (*kern)(const GemmArgs) = gemm_ws_kernel<T, TC, TA, TB, BM, BN, STAGES>;
+  if (!attr_set) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = ((g_in.M + BM - 1) / BM) * ((g_in.N + BN - 1) / BN);
+  dim3 grid(tiles, nbatch * g_in.ksplit, 1);
+  GemmArgs g = g_in;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "gemm_ws<%s,%s,%s%s,%dx%d,s%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
+           TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);
+  g.dbg = g_probe_buf ? probe_slot(nm, (long)tiles * nbatch * g_in.ksplit, g.M, g.N, g.K) : nullptr;
+  ProfRec rec;
+  const bool prof = g_prof_on && !rec_active();
+  if (prof) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    rec.id = prof_id(nm);
+    rec.flops = 2.0 * g.M * g.N * g.K * nbatch;
+    rec.bytes = ((double)g.M * g.K + (double)g.N * g.K) * nbatch * sizeof(T) + (double)g.M * g.N * nbatch * sizeof(TC);
+    ETP_CHECK_HIP(hipEventCreate(&rec.a));
+    ETP_CHECK_HIP(hipEventCreate(&rec.b));
+    ETP_CHECK_HIP(hipEventRecord(rec.a, st));
+  }
+  ETP_LAUNCH(kern, grid, dim3(512), smem, st, g);
+  ETP_CHECK_LAUNCH("gemm_ws");
+  if (prof) {
+    ETP_CHECK_HIP(hipEventRecord(rec.b, st));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(rec);
+  }
+  return ETP_OK;
+}
+
 static bool dma_ok(int bk, int K, int ksplit) {
   // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
   bool dma = (K % bk == 0) && (K >= 2 * bk);
@@ -1031,6 +1249,36 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   if (!dma) {
     if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 64, 64, 0>(g, nbatch, st);
+  }
+  // warp-specialised classes (bf16 NT / NN, unbatched): whenever the tile class runs at most ~one workgroup per CU
+  if constexpr (sizeof(T) == 2 && !TA) {
+    static const int ws_on = [] { const char* e = getenv("ETP_GEMM_WS"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool forced = force && strstr(force, "spec") != nullptr;    // "wspec[r4|r5|r6]", "64spec[r4|r6|r8]"
+    const bool deny = force && force[0] && !forced;
+    if (ws_on && !deny && nbatch == 1 && g.ksplit == 1) {
+      int wst = 0;                                   // 1: 128x64, 2: 64x64
+      if (wide && tw <= 288) wst = 1;
+      else if (!big && !wide && t64 <= 288) wst = 2;
+      int ring = wst == 1 ? 5 : 6;
+      if (forced) {
+        wst = force[0] == 'w' ? 1 : (force[0] == '6' ? 2 : wst);
+        ring = wst == 1 ? 5 : 6;
+        if (strstr(force, "r4")) ring = 4;
+        if (strstr(force, "r5")) ring = 5;
+        if (strstr(force, "r6")) ring = 6;
+        if (strstr(force, "r8")) ring = 8;
+      }
+      if (wst == 1) {
+        if (ring == 4) return launch_ws_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
+        if (ring == 6) return launch_ws_one<T, TC, TA, TB, 128, 64, 6>(g, nbatch, st);
+        return launch_ws_one<T, TC, TA, TB, 128, 64, 5>(g, nbatch, st);
+      }
+      if (wst == 2) {
+        if (ring == 4) return launch_ws_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
+        if (ring == 8) return launch_ws_one<T, TC, TA, TB, 64, 64, 8>(g, nbatch, st);
+        return launch_ws_one<T, TC, TA, TB, 64, 64, 6>(g, nbatch, st);
+      }
+    }
   }
   if (big) {
     if (stages == 3) return launch_one<T, TC, TA, TB, 128, 128, 3>(g, nbatch, st);

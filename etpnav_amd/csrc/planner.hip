@@ -64,6 +64,10 @@ struct etp_planner {
   // optional third stream: the d(txt_embeds) contributions of the x-layers' text K/V projections (M = B*L rows, the largest
   // GEMMs of the navigation backward) form a serial accumulate chain of their own that nothing on the node chain reads
   hipStream_t aux2 = nullptr;
+  // etp_planner_refresh_text_split: event after which the bf16 shadow of text layers >= 1 is valid (consumed once by the next
+  // etp_txt_fwd, after it has enqueued layer 0)
+  hipEvent_t txt_w_ready = nullptr;
+  bool txt_w_pending = false;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   hipEvent_t next_event() {
@@ -760,6 +764,25 @@ int etp_planner_refresh_part(etp_planner* p, int part, etp_stream_t stream) {
   return cast_f32_to_bf16(p->P + lo, reinterpret_cast<uint16_t*>(p->S) + lo, hi - lo, (hipStream_t)stream);
 }
 
+// bf16 shadow of the text encoder with only layer 0 on the dependent chain: layer 0's matrices are cast on `main`, layers
+// 1.. on `side` (bandwidth-bound, ~40 us for BERT-base, which used to sit in front of the first text GEMM of every step);
+// the next etp_txt_fwd on `main` waits for the side cast right after it has enqueued layer 0.
+int etp_planner_refresh_text_split(etp_planner* p, etp_stream_t main, etp_stream_t side) {
+  ETP_REQUIRE(p && p->P, "planner not bound");
+  if (p->cfg.dtype != ETP_BF16) return ETP_OK;
+  const long txt_end = p->off(p->img_w);
+  hipStream_t sm = (hipStream_t)main, ss = (hipStream_t)side;
+  if (p->cfg.n_l < 2 || ss == nullptr || ss == sm) return cast_f32_to_bf16(p->P, p->S, txt_end, sm);
+  const long l1 = p->off(p->txt[1].att.qkv_w);
+  ETP_TRY(cast_f32_to_bf16(p->P, p->S, l1, sm));
+  ETP_TRY(stream_after(p, sm, ss));                     // the side stream starts no earlier than this step (ordering with the optimizer)
+  ETP_TRY(cast_f32_to_bf16(p->P + l1, reinterpret_cast<uint16_t*>(p->S) + l1, txt_end - l1, ss));
+  if (!p->txt_w_ready) ETP_CHECK_HIP(hipEventCreateWithFlags(&p->txt_w_ready, hipEventDisableTiming));
+  ETP_CHECK_HIP(event_record(p->txt_w_ready, ss));
+  p->txt_w_pending = true;
+  return ETP_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 int64_t etp_txt_stash_bytes(const etp_planner* p, int B, int L) {
   if (!p) return 0;
@@ -792,6 +815,10 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
     if (l == p->cfg.n_l - 1) t.ffn[l].y.f = out;      // the last LayerNorm writes the API tensor itself (backward never reads it)
     ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps, MODE_TXT, l));
     x = t.ffn[l].y;
+    if (l == 0 && p->txt_w_pending) {                    // layers >= 1 read weights cast on the side stream
+      ETP_CHECK_HIP(stream_wait_event(c.st, p->txt_w_ready));
+      p->txt_w_pending = false;
+    }
   }
   if (p->cfg.n_l == 0) ETP_TRY(copy_f32(x.f, out, (long)M * H, c.st));
   return ETP_OK;

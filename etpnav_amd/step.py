@@ -231,7 +231,12 @@ class PlannerStep:
         # stream, the panorama/navigation casts and the (bandwidth-bound) gradient memset on the panorama stream, whose
         # join below precedes forward_navigation and every backward kernel
         if self.refresh_weights:
-            check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
+            # only layer 0's cast stays in front of the first text GEMM; layers 1.. are cast on the panorama stream and
+            # etp_txt_fwd waits for them after its layer 0 (ETP_TXT_CAST_SPLIT=0: the whole text cast on the main stream)
+            if self.s2 is not None and os.environ.get("ETP_TXT_CAST_SPLIT", "1") != "0":
+                check(L.etp_planner_refresh_text_split(h, s, s2), "refresh text weights")
+            else:
+                check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
         check(L.etp_stream_after(s, s2), "fork")
         if self.refresh_weights:
             check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")

@@ -294,6 +294,9 @@ int etp_planner_refresh_weights(etp_planner* p, etp_stream_t stream);
  * part 0 = text encoder (forward_txt), 1 = view projections + panorama encoder (forward_panorama), 2 = x-layers + SAP
  * head (forward_navigation).  The three parts tile the matrix region exactly. */
 int etp_planner_refresh_part(etp_planner* p, int part, etp_stream_t stream);
+/* bf16 shadow of the text encoder, layer 0 on `main` and layers >= 1 on `side`; the next etp_txt_fwd issued on `main` waits for
+ * the side cast after its layer 0 (takes ~40 us of weight casting off the head of the dependent chain of a training step). */
+int etp_planner_refresh_text_split(etp_planner* p, etp_stream_t main, etp_stream_t side);
 
 /* Activations that cross these entry points (txt_embeds, pano_embeds, gmap_img_fts, gmap_embeds and their gradients) are
  * fp32 in BOTH modes, as they are under the reference's autocast (outputs of fp32 LayerNorms); `dtype` only selects the

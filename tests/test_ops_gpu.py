@@ -121,6 +121,38 @@ def test_gemm_epilogues(dtype):
     assert (C.float() - (C0.float() + raw)).abs().max().item() <= tol(dtype, 4)
 
 
+@pytest.mark.parametrize("tile", ["wspecr4", "wspecr5", "wspecr6", "64specr4", "64specr6", "64specr8", "128s2", "ws4", "64s3"])
+@pytest.mark.parametrize("tb", [0, 1])
+def test_gemm_tile_classes_with_epilogues(tile, tb, monkeypatch):
+    """Every LDS-DMA tile class of round 3 -- the warp-specialised kernels (4 loader + 4 compute wavefronts, rings of 4..8
+    slabs) and the pipelined 256-thread kernels -- forced through ETP_GEMM_TILE on ragged shapes (partial tiles in both
+    directions, reductions shorter and longer than the ring), NT and NN storage, with the epilogues the planner uses:
+    bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU backward, dropout."""
+    monkeypatch.setenv("ETP_GEMM_TILE", tile)
+    dtype, t = _lib.ETP_BF16, torch.bfloat16
+    for (M, N, K) in [(300, 200, 128), (130, 72, 192), (257, 136, 768), (64, 64, 1024)]:
+        torch.manual_seed(M + N + K + tb)
+        A = torch.randn(M, K, device=DEV).to(t)
+        B = (torch.randn(N, K, device=DEV) * 0.1).to(t)
+        Bs = B.t().contiguous() if tb else B                       # NN: B stored [K][N]
+        bias = torch.randn(N, device=DEV)
+        raw = A.float() @ B.float().t()
+        # fp32 stream output with bias + fp32 residual (out-proj / FFN-down / dgrad_s of the planner)
+        R = torch.randn(M, N, device=DEV)
+        C = torch.full((M, N), float("nan"), device=DEV)
+        run_gemm(A, Bs, C, M, N, K, 0, tb, dtype, c_dtype=_lib.ETP_F32, bias=bias, R=R)
+        assert (C - (raw + bias + R)).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K, "stream")
+        # bf16 output, bias + GELU, pre-activation saved
+        Cb = torch.full((M, N), float("nan"), device=DEV, dtype=t); Z = torch.empty(M, N, device=DEV, dtype=t)
+        run_gemm(A, Bs, Cb, M, N, K, 0, tb, dtype, bias=bias, Z=Z, act=_lib.ACT_GELU)
+        assert (Z.float() - (raw + bias)).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K, "z")
+        assert (Cb.float() - gelu(raw + bias)).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K, "gelu")
+        # GELU backward reads Z
+        Zin = torch.randn(M, N, device=DEV).to(t)
+        run_gemm(A, Bs, Cb, M, N, K, 0, tb, dtype, Z=Zin, act=_lib.ACT_GELU_BWD)
+        assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K, "dgelu")
+
+
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
 def test_gemm_wgrad_splitk_fp32_out(dtype):
     """dW[N,K] += dY[M,N]^T X[M,K]: TN storage, fp32 output, RMW and atomic split-K."""

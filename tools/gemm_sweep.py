@@ -49,7 +49,7 @@ def make(kind, M, N, K):
 
 
 def time_variant(kind, M, N, K, variant, iters=24):
-    os.environ["ETP_GEMM_TILE"] = variant
+    os.environ["ETP_GEMM_TILE"] = "" if variant == "auto" else variant
     sets = [make(kind, M, N, K) for _ in range(NSETS)]
     s = torch.cuda.current_stream().cuda_stream
     for d, _ in sets:
@@ -88,6 +88,8 @@ def main():
     shapes += [("fwd", 2560, 2 * H, H), ("dg_s", 2560, H, 2 * H), ("fwd", 512, H, H), ("dg_s", 512, H, H),
                ("fwd", 8192, 3 * H, H), ("fwd_s", 8192, H, H), ("fwd_g", 8192, I, H), ("fwd_s", 8192, H, I)]
     variants = ["64s3", "64s4", "ws3", "ws4", "128s2", "128s3"]
+    if os.environ.get("SWEEP_SPEC"):               # round 3: the warp-specialised classes (4 loader + 4 compute wavefronts)
+        variants = ["auto", "64s4", "ws4", "128s2", "64specr4", "64specr6", "64specr8", "wspecr4", "wspecr5", "wspecr6"]
     out = {"variants": variants, "shapes": {}, "ksweep": {}}
     for kind, M, N, K in shapes:
         key = f"{kind}:{M}x{N}x{K}"
@@ -103,7 +105,8 @@ def main():
         out["shapes"][key] = {"us": row, "best": best, "best_tflops": round(fl / row[best] / 1e6, 1)}
         print(key, row, "->", best, file=sys.stderr, flush=True)
     for K in (128, 256, 512, 768, 1536, 3072):
-        out["ksweep"][str(K)] = {v: round(time_variant("fwd_s", 2560, 768, K, v), 2) for v in ("64s3", "ws3", "128s2")}
+        kv = ("64s3", "ws3", "128s2") + (("wspecr5",) if os.environ.get("SWEEP_SPEC") else ())
+        out["ksweep"][str(K)] = {v: round(time_variant("fwd_s", 2560, 768, K, v), 2) for v in kv}
         print("ksweep", K, out["ksweep"][str(K)], file=sys.stderr, flush=True)
     os.environ["ETP_GEMM_TILE"] = ""
     print(json.dumps(out, indent=1))
