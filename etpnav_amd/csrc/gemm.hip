@@ -297,13 +297,13 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN, NTH>& pre, co
 }
 
 // Epilogue shared by both GEMM kernels (register-staged and LDS-DMA main loops).
-// NTH threads run the store phase; the accumulators belong to the first four wavefronts (the warp-specialised kernel's loader
-// wavefronts 4..7 own none and skip the staging writes).
+// NTH threads = NTH / 64 wavefronts in a (NTH / 128) x 2 grid over the tile.
 template <typename T, typename TC, int BM, int BN, int NTH = 256>
-__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], char* smem, const GemmArgs& g, TC* C, int m0,
-                                              int n0, int ks, int tid, const EpiPre<T, TC, BM, BN, NTH>& pre,
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / (NTH / 128) / 16][BN / 32], char* smem, const GemmArgs& g, TC* C,
+                                              int m0, int n0, int ks, int tid, const EpiPre<T, TC, BM, BN, NTH>& pre,
                                               const ZPre<BM * (BN / 8) / NTH> zp) {
-  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int WM = NTH / 128;                      // wavefront rows of the (WM x 2) grid
+  constexpr int MT = BM / WM / 16, NT = BN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   // ---- epilogue ----------------------------------------------------------------------------------------
@@ -313,15 +313,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[BM / 32][BN / 32], 
   const int i = lane & 15, gq = lane >> 4;
   constexpr int CP = BN + 4;
   float* ct = reinterpret_cast<float*>(smem);
-  if (NTH == 256 || wave < 4) {
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ct[(wr * (BM / 2) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
-  }
+      for (int r = 0; r < 4; ++r)
+        ct[(wr * (BM / WM) + a * 16 + gq * 4 + r) * CP + wc * (BN / 2) + b * 16 + i] = acc[a][b][r];
   __syncthreads();
   const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
   T* Z = reinterpret_cast<T*>(g.Z);
@@ -601,21 +599,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 //   * out-of-range rows/columns are clamped to valid addresses (their products are never stored);
 //   * one barrier per slab; `s_waitcnt vmcnt(N)` leaves the younger slabs' DMA in flight across it.
 // =========================================================================================================
-template <typename T, bool TR, int ROWS>
+template <typename T, bool TR, int ROWS, int NW = 4>
 struct DmaPlan {
-  static constexpr int PER_WAVE = ROWS / 32;          // 1-KiB pieces per wave per slab
+  static_assert(ROWS % (8 * NW) == 0, "tile rows must split into whole 1-KiB pieces per wavefront");
+  static constexpr int PER_WAVE = ROWS / (8 * NW);    // 1-KiB pieces per wave per slab (ROWS / 8 pieces per tile)
   const T* src[PER_WAVE];                             // per-lane source address of piece j (advanced per slab)
   int lds_off[PER_WAVE];                              // wave-uniform LDS byte offset of piece j within the tile
 };
 
-template <typename T, bool TR, int ROWS>
-__device__ __forceinline__ void dma_plan(DmaPlan<T, TR, ROWS>& p, const T* base, long ld, int row0, int rows_total, int k0,
+template <typename T, bool TR, int ROWS, int NW>
+__device__ __forceinline__ void dma_plan(DmaPlan<T, TR, ROWS, NW>& p, const T* base, long ld, int row0, int rows_total, int k0,
                                          int tid) {
   using G = TileGeom<T, TR, ROWS, 0>;
-  const int lane = tid & 63, wave = (tid >> 6) & 3;      // (loader wavefronts 4..7 of the warp-specialised kernel map to 0..3)
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-  for (int j = 0; j < DmaPlan<T, TR, ROWS>::PER_WAVE; ++j) {
-    const int piece = j * 4 + wave;
+  for (int j = 0; j < DmaPlan<T, TR, ROWS, NW>::PER_WAVE; ++j) {
+    const int piece = j * NW + wave;
     const int idx = piece * 64 + lane;               // 16-byte chunk index inside the tile == LDS position
     p.lds_off[j] = __builtin_amdgcn_readfirstlane(piece * 1024);
     if constexpr (!TR) {
@@ -649,11 +648,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
       : "memory");
 }
 
-template <typename T, bool TR, int ROWS>
-__device__ __forceinline__ void dma_issue(DmaPlan<T, TR, ROWS>& p, unsigned lds_tile_addr, long ld) {
+template <typename T, bool TR, int ROWS, int NW>
+__device__ __forceinline__ void dma_issue(DmaPlan<T, TR, ROWS, NW>& p, unsigned lds_tile_addr, long ld) {
   constexpr int BK = MmaTraits<T>::BK;
 #pragma unroll
-  for (int j = 0; j < DmaPlan<T, TR, ROWS>::PER_WAVE; ++j) {
+  for (int j = 0; j < DmaPlan<T, TR, ROWS, NW>::PER_WAVE; ++j) {
     glds16(p.src[j], lds_tile_addr + (unsigned)p.lds_off[j]);
     if constexpr (!TR) p.src[j] += BK;
     else p.src[j] += (long)BK * ld;
@@ -691,11 +690,11 @@ __device__ __forceinline__ void probe_end(const PhaseProbe& p, const GemmArgs& g
   d[7] = (unsigned long long)nk;
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN>
-__device__ __forceinline__ void load_frags(Frag<T> (&fa)[BM / 32], Frag<T> (&fb)[BN / 32], const char* sa, const char* sb, int s,
-                                           int wr, int wc, int lane) {
+template <typename T, bool TA, bool TB, int BM, int BN, int NW>
+__device__ __forceinline__ void load_frags(Frag<T> (&fa)[BM / (NW / 2) / 16], Frag<T> (&fb)[BN / 32], const char* sa, const char* sb,
+                                           int s, int wr, int wc, int lane) {
 #pragma unroll
-  for (int a = 0; a < BM / 32; ++a) frag_load<T, TA, BM, 0>(fa[a], sa, wr * (BM / 2) + a * 16, s, lane);
+  for (int a = 0; a < BM / (NW / 2) / 16; ++a) frag_load<T, TA, BM, 0>(fa[a], sa, wr * (BM / (NW / 2)) + a * 16, s, lane);
 #pragma unroll
   for (int b = 0; b < BN / 32; ++b) frag_load<T, TB, BN, 0>(fb[b], sb, wc * (BN / 2) + b * 16, s, lane);
 }
@@ -713,16 +712,19 @@ __device__ __forceinline__ void load_frags(Frag<T> (&fa)[BM / 32], Frag<T> (&fb)
 //     frags(t+1, 0) <- LDS   ||  MFMA(t, last)                        slabs in flight and one landed
 //
 // so each ds_read batch is covered by the previous sub-step's MFMAs and a DMA piece has STAGES-1 slab times to land.
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+// NW wavefronts (4 or 8) form a (NW / 2) x 2 grid over the tile: 4 for the 64- / 128-row tiles, 8 for the 256 x 128 tile (each
+// wavefront keeps a 64 x 64 sub-tile; twice the FLOPs of 128 x 128 per byte that crosses the CU's LDS-DMA path).
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES, int NW>
 __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem,
                                          int rec) {
   using GA = TileGeom<T, TA, BM, 0>;
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int BK = MmaTraits<T>::BK;
   constexpr int KS = BK / 32;
-  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int NTH = 64 * NW;
+  constexpr int MT = BM / (NW / 2) / 16, NT = BN / 32;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
-  constexpr int PER_SLAB = DmaPlan<T, TA, BM>::PER_WAVE + DmaPlan<T, TB, BN>::PER_WAVE;   // DMA instrs per wave per slab
+  constexpr int PER_SLAB = DmaPlan<T, TA, BM, NW>::PER_WAVE + DmaPlan<T, TB, BN, NW>::PER_WAVE;   // DMA instrs per wave per slab
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -738,18 +740,18 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
   }
   const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;     // host guarantees BK | (kend-kbeg)
 
-  DmaPlan<T, TA, BM> pa;
-  DmaPlan<T, TB, BN> pb;
-  dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
-  dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+  DmaPlan<T, TA, BM, NW> pa;
+  DmaPlan<T, TB, BN, NW> pb;
+  dma_plan<T, TA, BM, NW>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  dma_plan<T, TB, BN, NW>(pb, B, g.ldb, n0, g.N, kbeg, tid);
 
   // the whole ring goes in flight before anything else
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the ring
 #pragma unroll
   for (int s = 0; s < STAGES; ++s)
     if (s < nk) {
-      dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
-      dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
+      dma_issue<T, TA, BM, NW>(pa, lds0 + s * STAGE, g.lda);
+      dma_issue<T, TB, BN, NW>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
     }
 
   f32x4_t acc[MT][NT];
@@ -758,10 +760,10 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  EpiPre<T, TC, BM, BN> pre;
-  epi_prefetch<T, TC, BM, BN>(pre, g, C, m0, n0, ks, tid);     // epilogue operands travel while the reduction runs
-  ZPre<BM * (BN / 8) / 256> zp;
-  z_prefetch<T, TC, BM, BN, 256>(zp, g, m0, n0, tid);
+  EpiPre<T, TC, BM, BN, NTH> pre;
+  epi_prefetch<T, TC, BM, BN, NTH>(pre, g, C, m0, n0, ks, tid);     // epilogue operands travel while the reduction runs
+  ZPre<BM * (BN / 8) / NTH> zp;
+  z_prefetch<T, TC, BM, BN, NTH>(zp, g, m0, n0, tid);
 
   const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
   float colsum_acc = 0.f;
@@ -770,7 +772,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
   if (nk > 0) {
     wait_slabs<PER_SLAB, STAGES - 1>(min(STAGES - 1, nk - 1));   // slab 0 landed, the rest of the ring stays in flight
     __builtin_amdgcn_s_barrier();
-    load_frags<T, TA, TB, BM, BN>(fa0, fb0, smem, smem + GA::BYTES, 0, wr, wc, lane);
+    load_frags<T, TA, TB, BM, BN, NW>(fa0, fb0, smem, smem + GA::BYTES, 0, wr, wc, lane);
   }
   if (probe.on) probe.mt1 = __builtin_amdgcn_s_memtime();
 
@@ -779,7 +781,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
       // fused bias gradient: blocks of the first tile column also sum the A tile ([k][rows]) over k
       if (do_colsum) {
         const char* sa = smem + (t % STAGES) * STAGE;
-        constexpr int KQ = 256 / BM, RPT = BK / KQ;
+        constexpr int KQ = NTH / BM, RPT = BK / KQ;
         const int col = tid % BM, kq = tid / BM;
         const int chunk = col / GA::EPC, within = (col % GA::EPC) * (int)sizeof(T);
 #pragma unroll 4
@@ -803,7 +805,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
 #define ETP_MMA_SET(FA, FB)                                            \
   _Pragma("unroll") for (int a = 0; a < MT; ++a)                       \
       _Pragma("unroll") for (int b = 0; b < NT; ++b) mma_step(acc[a][b], FA[a], FB[b]);
-#define ETP_LOAD_FRAGS(...) load_frags<T, TA, TB, BM, BN>(__VA_ARGS__)
+#define ETP_LOAD_FRAGS(...) load_frags<T, TA, TB, BM, BN, NW>(__VA_ARGS__)
 #endif
   // hand-over between slabs: slab t+1 landed, every wave's reads of slab t retired, next DMA into the freed buffer
 #define ETP_SLAB_HANDOVER(t)                                                                             \
@@ -812,8 +814,8 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
   __builtin_amdgcn_s_barrier();                                                                          \
   if (ETP_GEMM_EXPT != 2 && (t) + STAGES < nk) {                                                         \
     const unsigned dst = lds0 + ((t) % STAGES) * STAGE;                                                  \
-    dma_issue<T, TA, BM>(pa, dst, g.lda);                                                                \
-    dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);                                                    \
+    dma_issue<T, TA, BM, NW>(pa, dst, g.lda);                                                                \
+    dma_issue<T, TB, BN, NW>(pb, dst + GA::BYTES, g.ldb);                                                    \
   }
 
   if constexpr (KS == 2) {                // bf16: two sub-steps per slab, set 0 then set 1
@@ -872,152 +874,20 @@ __device__ __forceinline__ void dma_tile(const GemmArgs& g, const T* A, const T*
     if (do_colsum && m0 + (tid % BM) < g.M) atomicAdd(g.a_colsum + m0 + (tid % BM), colsum_acc);
   }
   __syncthreads();
-  gemm_epilogue<T, TC, BM, BN>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
+  gemm_epilogue<T, TC, BM, BN, NTH>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
   probe_end(probe, g, rec, nk);
-}
-
-// =========================================================================================================
-// Warp-specialised variant (round 3): 512 threads = 4 COMPUTE wavefronts (2x2 over the tile, fragments + MFMA, as above)
-// + 4 LOADER wavefronts that do nothing but issue the LDS-DMA pieces and wait for them.
-//
-// Why: the phase probe (profiles/r03_gemm_phases.txt) shows 930 cycles per slab on a 128x64 tile with one workgroup per CU
-// for 256 cycles of MFMA work, whatever the ring depth (sweep: ring 3 = ring 4), and the builds that run only one half of
-// the loop (ETP_GEMM_EXPT) put the DMA half at ... cycles and the MFMA half at ... : a global_load_lds piece occupies its
-// wavefront for 60-185 cycles of issue (MI355X_MICROARCH.md "LDS-DMA piece issue cost"), six to eight pieces per slab,
-// and an in-order wavefront cannot issue its MFMAs meanwhile.  With one wavefront per SIMD nothing else owns the matrix
-// pipe during that time.  Here every SIMD hosts one loader and one compute wavefront: the vector-memory issue of the one
-// runs beside the MFMA stream of the other (separate issue ports), and a slab costs max(DMA issue, MFMA) instead of
-// their sum.  One s_barrier per slab for all eight wavefronts:
-//
-//     compute:  frags(t,1) <- LDS || MFMA(t,0);  [lgkmcnt(0)]  s_barrier;  frags(t+1,0) <- LDS || MFMA(t,1)
-//     loader :                        [slab t+1 landed: vmcnt]  s_barrier;  issue slab t+STAGES into slab t's buffer
-//
-// Used for the tile classes that run ONE workgroup per CU (128x64 on the M = 2560, N = 768 products, 64x64 on the
-// M = 512 node products); the 128x128 class keeps two 256-thread workgroups per CU (its registers do not allow four
-// wavefronts per SIMD).
-// =========================================================================================================
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__device__ __forceinline__ void ws_tile(const GemmArgs& g, const T* A, const T* B, TC* C, int tm, int tn, int ks, char* smem, int rec) {
-  using GA = TileGeom<T, TA, BM, 0>;
-  using GB = TileGeom<T, TB, BN, 0>;
-  constexpr int BK = MmaTraits<T>::BK;
-  constexpr int KS = BK / 32;
-  constexpr int MT = BM / 32, NT = BN / 32;
-  constexpr int STAGE = GA::BYTES + GB::BYTES;
-  constexpr int PER_SLAB = DmaPlan<T, TA, BM>::PER_WAVE + DmaPlan<T, TB, BN>::PER_WAVE;
-  static_assert(KS == 2, "the warp-specialised kernel is built for bf16 operands (two MFMA k-steps per slab)");
-  static_assert(!TA, "weight-gradient (TN) products use the grouped kernel");
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool loader = wave >= 4;
-  const int wr = (wave & 3) >> 1, wc = wave & 1;
-  const int m0 = tm * BM, n0 = tn * BN;
-  PhaseProbe probe;
-  probe_begin(probe, g);
-
-  int kbeg = 0, kend = g.K;
-  if (g.ksplit > 1) {
-    const int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
-    kbeg = ks * per;
-    kend = min(g.K, kbeg + per);
-  }
-  const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;
-  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  EpiPre<T, TC, BM, BN, 512> pre;
-
-  if (loader) {
-    // ---------------- loader wavefronts ----------------
-    DmaPlan<T, TA, BM> pa;
-    DmaPlan<T, TB, BN> pb;
-    dma_plan<T, TA, BM>(pa, A, g.lda, m0, g.M, kbeg, tid);
-    dma_plan<T, TB, BN>(pb, B, g.ldb, n0, g.N, kbeg, tid);
-#pragma unroll
-    for (int s = 0; s < STAGES; ++s)
-      if (s < nk) {
-        dma_issue<T, TA, BM>(pa, lds0 + s * STAGE, g.lda);
-        dma_issue<T, TB, BN>(pb, lds0 + s * STAGE + GA::BYTES, g.ldb);
-      }
-    epi_prefetch<T, TC, BM, BN, 512>(pre, g, C, m0, n0, ks, tid);
-    if (nk > 0) {
-      wait_slabs<PER_SLAB, STAGES - 1>(min(STAGES - 1, nk - 1));
-      __builtin_amdgcn_s_barrier();
-    }
-    for (int t = 0; t + 1 < nk; ++t) {
-      wait_slabs<PER_SLAB, STAGES - 2>(min(STAGES - 2, nk - 2 - t));   // slab t+1 landed (this wave's pieces)
-      __builtin_amdgcn_s_barrier();                                     // compute waves hold slab t in registers: its buffer is free
-      if (t + STAGES < nk) {
-        const unsigned dst = lds0 + (t % STAGES) * STAGE;
-        dma_issue<T, TA, BM>(pa, dst, g.lda);
-        dma_issue<T, TB, BN>(pb, dst + GA::BYTES, g.ldb);
-      }
-    }
-    wait_vmcnt<0>();
-  } else {
-    // ---------------- compute wavefronts ----------------
-    epi_prefetch<T, TC, BM, BN, 512>(pre, g, C, m0, n0, ks, tid);
-    Frag<T> fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-    if (nk > 0) {
-      __builtin_amdgcn_s_barrier();
-      load_frags<T, TA, TB, BM, BN>(fa0, fb0, smem, smem + GA::BYTES, 0, wr, wc, lane);
-    }
-    if (probe.on) probe.mt1 = __builtin_amdgcn_s_memtime();
-#define ETP_MMA_SET(FA, FB)                                            \
-  _Pragma("unroll") for (int a = 0; a < MT; ++a)                       \
-      _Pragma("unroll") for (int b = 0; b < NT; ++b) mma_step(acc[a][b], FA[a], FB[b]);
-    int t = 0;
-    for (; t + 1 < nk; ++t) {
-      const char* sa = smem + (t % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
-      ETP_MMA_SET(fa0, fb0)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // all of slab t is in this wave's registers
-      __builtin_amdgcn_s_barrier();
-      const char* sn = smem + ((t + 1) % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa0, fb0, sn, sn + GA::BYTES, 0, wr, wc, lane);
-      ETP_MMA_SET(fa1, fb1)
-    }
-    if (t < nk) {
-      const char* sa = smem + (t % STAGES) * STAGE;
-      load_frags<T, TA, TB, BM, BN>(fa1, fb1, sa, sa + GA::BYTES, 1, wr, wc, lane);
-      ETP_MMA_SET(fa0, fb0)
-      ETP_MMA_SET(fa1, fb1)
-    }
-#undef ETP_MMA_SET
-    if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();
-  }
-  __syncthreads();
-  ZPre<BM * (BN / 8) / 512> zp;
-  zp.valid = false;                       // (these tiles have <= 2 chunks per thread: Z travels with EpiPre)
-  gemm_epilogue<T, TC, BM, BN, 512>(acc, smem, g, C, m0, n0, ks, tid, pre, zp);
-  probe_end(probe, g, rec, nk);
-}
-
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (g.N + BN - 1) / BN;
-  int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, (g.M + BM - 1) / BM, tiles_n, g.xcd_map, tm, tn);
-  const int z = blockIdx.y / g.ksplit, ks = blockIdx.y % g.ksplit;
-  const int zo = z / g.nb_inner, zi = z % g.nb_inner;
-  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
-  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
-  TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  ws_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // __launch_bounds__(256, w): w = wavefronts per SIMD the grid needs (2 for the 128-row tiles, 3 for 64x64).  Without it
 // hipcc (ROCm 7.2) assumes a 512-register budget, splits it into VGPRs + AGPRs and then shuttles accumulators and
 // fragments between the two files (~290 v_accvgpr_* moves per kernel, ~150 inside the reduction loop); with the bound
 // every MFMA takes the VGPR form and accumulates in place.
-template <int BM, int BN> struct TileWaves { static constexpr int MIN = (BM * BN <= 64 * 64) ? 3 : 2; };
+template <int BM, int BN> struct TileWaves {
+  static constexpr int MIN = (BM * BN <= 64 * 64) ? 3 : 2;
+  static constexpr int NW = BM >= 256 ? 8 : 4;       // wavefronts per workgroup
+};
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_dma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::MIN)) void gemm_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (g.N + BN - 1) / BN;
   int tm, tn;
@@ -1027,7 +897,7 @@ __global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_dma_kernel
   const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
   const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* C = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES, TileWaves<BM, BN>::NW>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Grouped launch: up to ETP_GEMM_GROUP_MAX independent products of one storage/dtype/tile class in ONE grid (the four
@@ -1035,7 +905,7 @@ __global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_dma_kernel
 // into 8 contiguous chunks, one per XCD (workgroup i runs on XCD i % 8), so every private L2 sees a compact slab of one or
 // two problems; inside a problem tiles run along the longer tile axis first (same order as tile_of_block).
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_group_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::MIN)) void gemm_group_kernel(const GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x, nwg = gridDim.x;
   int id = bid;
@@ -1053,7 +923,7 @@ __global__ __launch_bounds__(256, (TileWaves<BM, BN>::MIN)) void gemm_group_kern
   int tm, tn;
   if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
   else { tn = local / tiles_m; tm = local % tiles_m; }
-  dma_tile<T, TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES, TileWaves<BM, BN>::NW>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
                                           reinterpret_cast<TC*>(g.C), tm, tn, 0, smem, bid);
 }
 
@@ -1156,49 +1026,8 @@ static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
     ETP_CHECK_HIP(hipEventCreate(&rec.b));
     ETP_CHECK_HIP(hipEventRecord(rec.a, st));
   }
-  ETP_LAUNCH(kern, grid, dim3(256), smem, st, g);
+  ETP_LAUNCH(kern, grid, dim3(STAGES == 0 ? 256 : 64 * TileWaves<BM, BN>::NW), smem, st, g);
   ETP_CHECK_LAUNCH("gemm");
-  if (prof) {
-    ETP_CHECK_HIP(hipEventRecord(rec.b, st));
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_recs.push_back(rec);
-  }
-  return ETP_OK;
-}
-
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-static int launch_ws_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
-  using GA = TileGeom<T, TA, BM, 0>;
-  using GB = TileGeom<T, TB, BN, 0>;
-  constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
-  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
-  static_assert(smem <= 160 * 1024, "ring exceeds the CU's LDS");
-  static bool attr_set = false;
-  void (*kern)(const GemmArgs) = gemm_ws_kernel<T, TC, TA, TB, BM, BN, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
-  const int tiles = ((g_in.M + BM - 1) / BM) * ((g_in.N + BN - 1) / BN);
-  dim3 grid(tiles, nbatch * g_in.ksplit, 1);
-  GemmArgs g = g_in;
-  char nm[96];
-  snprintf(nm, sizeof(nm), "gemm_ws<%s,%s,%s%s,%dx%d,s%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
-           TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);
-  g.dbg = g_probe_buf ? probe_slot(nm, (long)tiles * nbatch * g_in.ksplit, g.M, g.N, g.K) : nullptr;
-  ProfRec rec;
-  const bool prof = g_prof_on && !rec_active();
-  if (prof) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    rec.id = prof_id(nm);
-    rec.flops = 2.0 * g.M * g.N * g.K * nbatch;
-    rec.bytes = ((double)g.M * g.K + (double)g.N * g.K) * nbatch * sizeof(T) + (double)g.M * g.N * nbatch * sizeof(TC);
-    ETP_CHECK_HIP(hipEventCreate(&rec.a));
-    ETP_CHECK_HIP(hipEventCreate(&rec.b));
-    ETP_CHECK_HIP(hipEventRecord(rec.a, st));
-  }
-  ETP_LAUNCH(kern, grid, dim3(512), smem, st, g);
-  ETP_CHECK_LAUNCH("gemm_ws");
   if (prof) {
     ETP_CHECK_HIP(hipEventRecord(rec.b, st));
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -1230,54 +1059,41 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
   const long tw = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * nbatch * g.ksplit;
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch * g.ksplit;
-  bool big = (g.M >= 128 && g.N >= 128 && t128 >= 360);
-  bool wide = !big && g.M >= 128 && g.N >= 64 && tw >= 200 && tw <= 520 && nbatch == 1;
+  const long t256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * nbatch * g.ksplit;
+  // 256x128 (8 wavefronts, one workgroup per CU): 48 KiB per slab for 64 MFMAs per SIMD pair -- the only class whose MFMA time
+  // matches the CU's LDS-DMA feed (~40 B/clk, profiles/r03b_gemm_sweep_dma_only.json); taken when it gives most CUs a tile
+  bool huge = g.M >= 256 && g.N >= 128 && nbatch == 1 && t256 >= 160;
+  static const int huge_on = [] { const char* e = getenv("ETP_GEMM_256"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!huge_on) huge = false;
+  bool big = !huge && (g.M >= 128 && g.N >= 128 && t128 >= 360);
+  bool wide = !huge && !big && g.M >= 128 && g.N >= 64 && tw >= 200 && tw <= 520 && nbatch == 1;
   static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!wide_on) wide = false;
   const bool dma = dma_ok(BK, g.K, g.ksplit);
-  int stages = big ? 2 : (wide ? 4 : 3);
-  if (!big && !wide && t64 <= 320 && g.K >= 4 * BK) stages = 4;
+  int stages = (big || huge) ? 2 : (wide ? 4 : 3);
+  if (!huge && !big && !wide && t64 <= 320 && g.K >= 4 * BK) stages = 4;
   const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_sweep.py): "128", "64", "w" + optional "s2".."s4", "64r"
   if (force && force[0]) {
+    huge = force[0] == '2';                        // "256", "256s3"
     if (force[0] == '1' || force[0] == '6') { big = force[0] == '1'; wide = false; }
     if (force[0] == 'w') { wide = true; big = false; }
-    stages = big ? 2 : (wide ? 4 : 3);
+    if (huge) { big = false; wide = false; }
+    stages = (big || huge) ? 2 : (wide ? 4 : 3);
     if (strstr(force, "s2")) stages = 2;
     if (strstr(force, "s3")) stages = 3;
     if (strstr(force, "s4")) stages = 4;
   }
   if (!dma) {
-    if (big) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
+    if (big || huge) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 64, 64, 0>(g, nbatch, st);
   }
-  // warp-specialised classes (bf16 NT / NN, unbatched): whenever the tile class runs at most ~one workgroup per CU
-  if constexpr (sizeof(T) == 2 && !TA) {
-    static const int ws_on = [] { const char* e = getenv("ETP_GEMM_WS"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool forced = force && strstr(force, "spec") != nullptr;    // "wspec[r4|r5|r6]", "64spec[r4|r6|r8]"
-    const bool deny = force && force[0] && !forced;
-    if (ws_on && !deny && nbatch == 1 && g.ksplit == 1) {
-      int wst = 0;                                   // 1: 128x64, 2: 64x64
-      if (wide && tw <= 288) wst = 1;
-      else if (!big && !wide && t64 <= 288) wst = 2;
-      int ring = wst == 1 ? 5 : 6;
-      if (forced) {
-        wst = force[0] == 'w' ? 1 : (force[0] == '6' ? 2 : wst);
-        ring = wst == 1 ? 5 : 6;
-        if (strstr(force, "r4")) ring = 4;
-        if (strstr(force, "r5")) ring = 5;
-        if (strstr(force, "r6")) ring = 6;
-        if (strstr(force, "r8")) ring = 8;
-      }
-      if (wst == 1) {
-        if (ring == 4) return launch_ws_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
-        if (ring == 6) return launch_ws_one<T, TC, TA, TB, 128, 64, 6>(g, nbatch, st);
-        return launch_ws_one<T, TC, TA, TB, 128, 64, 5>(g, nbatch, st);
-      }
-      if (wst == 2) {
-        if (ring == 4) return launch_ws_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
-        if (ring == 8) return launch_ws_one<T, TC, TA, TB, 64, 64, 8>(g, nbatch, st);
-        return launch_ws_one<T, TC, TA, TB, 64, 64, 6>(g, nbatch, st);
-      }
+  if (huge) {
+    if constexpr (sizeof(T) == 2) {                  // bf16 only: the fp32 parity mode keeps the four-wavefront tiles
+      if (stages == 3) return launch_one<T, TC, TA, TB, 256, 128, 3>(g, nbatch, st);
+      return launch_one<T, TC, TA, TB, 256, 128, 2>(g, nbatch, st);
+    } else {
+      if (stages == 3) return launch_one<T, TC, TA, TB, 128, 128, 3>(g, nbatch, st);
+      return launch_one<T, TC, TA, TB, 128, 128, 2>(g, nbatch, st);
     }
   }
   if (big) {
@@ -1348,7 +1164,11 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
   using GA = TileGeom<T, TA, BM, 0>;
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
-  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
+  // ETP_GROUP_WG_PER_CU=1: request more than half of the CU's LDS so that only ONE workgroup of this (leaf) kernel fits on a CU;
+  // the other half of the CU's registers / LDS then stays free for the dependent chain's workgroups while the group runs
+  static const int one_per_cu = [] { const char* e = getenv("ETP_GROUP_WG_PER_CU"); return (e && e[0] == '1') ? 1 : 0; }();
+  constexpr int smem_tile = smem_loop > smem_c ? smem_loop : smem_c;
+  const int smem = (one_per_cu && smem_tile < 84 * 1024) ? 84 * 1024 : smem_tile;
   static bool attr_set = false;
   void (*kern)(const GemmGroup) = gemm_group_kernel<T, TC, TA, TB, BM, BN, STAGES>;
   if (!attr_set) {
@@ -1382,7 +1202,7 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
     ETP_CHECK_HIP(hipEventCreate(&rec.b));
     ETP_CHECK_HIP(hipEventRecord(rec.a, st));
   }
-  ETP_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, grp);
+  ETP_LAUNCH(kern, dim3(tiles), dim3(64 * TileWaves<BM, BN>::NW), smem, st, grp);
   ETP_CHECK_LAUNCH("gemm_group");
   if (prof) {
     ETP_CHECK_HIP(hipEventRecord(rec.b, st));
@@ -1402,14 +1222,31 @@ static int launch_group_tiles(GemmGroup& grp, hipStream_t st) {
   }
   // 128x128 tiles halve the L2->LDS bytes per FLOP; they pay once the group still gives most CUs a tile
   bool big = all_big && t128 >= 160;
-  int stages = big ? 2 : 3;
-  const char* force = getenv("ETP_GROUP_TILE");          // tuning aid: "128s2", "128s3", "64s3", "64s4"
+  // 256x128 (8 wavefronts, one workgroup per CU) halves them again: a text layer's four weight gradients are 216 such tiles
+  long t256 = 0;
+  bool all_huge = sizeof(T) == 2;
+  for (int i = 0; i < grp.n; ++i) {
+    t256 += (long)((grp.g[i].M + 255) / 256) * ((grp.g[i].N + 127) / 128);
+    all_huge = all_huge && grp.g[i].M >= 256 && grp.g[i].N >= 128;
+  }
+  bool huge = all_huge && t256 >= 128;
+  static const int huge_on = [] { const char* e = getenv("ETP_GEMM_256"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!huge_on) huge = false;
+  int stages = (big || huge) ? 2 : 3;
+  const char* force = getenv("ETP_GROUP_TILE");          // tuning aid: "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"
   if (force && force[0]) {
+    huge = force[0] == '2' && all_huge;
     big = force[0] == '1' && all_big;
-    stages = big ? 2 : 3;
+    stages = (big || huge) ? 2 : 3;
     if (strstr(force, "s2")) stages = 2;
     if (strstr(force, "s3")) stages = 3;
     if (strstr(force, "s4")) stages = 4;
+  }
+  if (huge) {
+    if constexpr (sizeof(T) == 2) {
+      if (stages == 3) return launch_group_one<T, TC, TA, TB, 256, 128, 3>(grp, st);
+      return launch_group_one<T, TC, TA, TB, 256, 128, 2>(grp, st);
+    }
   }
   if (big) {
     if (stages == 3) return launch_group_one<T, TC, TA, TB, 128, 128, 3>(grp, st);

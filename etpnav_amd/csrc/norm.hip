@@ -203,68 +203,49 @@ __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
-  // Two rows per wave iteration (round 3): a wave owns rows row, row + stride, ...; the loads of BOTH rows of a pair (x, dy,
-  // the optional gradient to add) are issued before either row's reductions, so the second row's memory round trip runs under
-  // the first row's arithmetic instead of after it (the kernel is latency-bound: 27.5 MB in 9.5 us at M = 2560).
-  const int stride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
-    const int row1 = row0 + stride;
-    const bool two = row1 < M;
-    const int rows[2] = {row0, two ? row1 : row0};
-    float xv[2][NCH][4], dv[2][NCH][4], av[2][NCH][4];
-    float mean[2], rstd[2];
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[NCH][4], gy[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      mean[r] = stats[2 * rows[r]]; rstd[r] = stats[2 * rows[r] + 1];
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      float xv[4], dv[4];
+      load4(x + (long)row * H + col, xv);
+      load4(dy + (long)row * H + col, dv);
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
+      const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        load4(x + (long)rows[r] * H + col, xv[r][c]);
-        load4(dy + (long)rows[r] * H + col, dv[r][c]);
-        if (add != nullptr) load4(add + (long)rows[r] * H + col, av[r][c]);
+      for (int e = 0; e < 4; ++e) {
+        xh[c][e] = (xv[e] - mean) * rstd;
+        gy[c][e] = dv[e] * gmv[e];
+        s1 += gy[c][e];
+        s2 += gy[c][e] * xh[c][e];
+        ag[c][e] += dv[e] * xh[c][e];
+        ab[c][e] += dv[e];
       }
     }
+    s1 = wave_sum(s1) * (1.0f / H);
+    s2 = wave_sum(s2) * (1.0f / H);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (r == 1 && !two) break;
-      const int row = rows[r];
-      float xh[NCH][4], gy[NCH][4];
-      float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      float o[4];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
-        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - s1 - xh[c][e] * s2);
+      if (add != nullptr) {
+        float av[4];
+        load4(add + (long)row * H + col, av);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[c][e] = (xv[r][c][e] - mean[r]) * rstd[r];
-          gy[c][e] = dv[r][c][e] * gmv[e];
-          s1 += gy[c][e];
-          s2 += gy[c][e] * xh[c][e];
-          ag[c][e] += dv[r][c][e] * xh[c][e];
-          ab[c][e] += dv[r][c][e];
-        }
+        for (int e = 0; e < 4; ++e) o[e] += av[e];
       }
-      s1 = wave_sum(s1) * (1.0f / H);
-      s2 = wave_sum(s2) * (1.0f / H);
+      if (dx != nullptr) store4(dx + (long)row * H + col, o);
+      if (dxt != nullptr) {
+        if (drop.p > 0.f) {   // the operand copy is the gradient of a dropped dense output: d(dense) = dx * mask / (1-p)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (gy[c][e] - s1 - xh[c][e] * s2);
-        if (add != nullptr) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += av[r][c][e];
+          for (int e = 0; e < 4; ++e) o[e] *= drop_mult(drop.seed, (uint32_t)row * H + col + e, drop.p, drop.inv_keep);
         }
-        if (dx != nullptr) store4(dx + (long)row * H + col, o);
-        if (dxt != nullptr) {
-          if (drop.p > 0.f) {   // the operand copy is the gradient of a dropped dense output: d(dense) = dx * mask / (1-p)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= drop_mult(drop.seed, (uint32_t)row * H + col + e, drop.p, drop.inv_keep);
-          }
-          store4(dxt + (long)row * H + col, o);
-        }
+        store4(dxt + (long)row * H + col, o);
       }
     }
   }

@@ -121,16 +121,16 @@ def test_gemm_epilogues(dtype):
     assert (C.float() - (C0.float() + raw)).abs().max().item() <= tol(dtype, 4)
 
 
-@pytest.mark.parametrize("tile", ["wspecr4", "wspecr5", "wspecr6", "64specr4", "64specr6", "64specr8", "128s2", "ws4", "64s3"])
+@pytest.mark.parametrize("tile", ["256s2", "256s3", "128s2", "128s3", "ws4", "ws3", "64s3", "64s4"])
 @pytest.mark.parametrize("tb", [0, 1])
 def test_gemm_tile_classes_with_epilogues(tile, tb, monkeypatch):
-    """Every LDS-DMA tile class of round 3 -- the warp-specialised kernels (4 loader + 4 compute wavefronts, rings of 4..8
-    slabs) and the pipelined 256-thread kernels -- forced through ETP_GEMM_TILE on ragged shapes (partial tiles in both
-    directions, reductions shorter and longer than the ring), NT and NN storage, with the epilogues the planner uses:
+    """Every LDS-DMA tile class of round 3 -- 256x128 (eight wavefronts), 128x128, 128x64 and 64x64 (four), each with its ring
+    depths -- forced through ETP_GEMM_TILE on ragged shapes (partial tiles in both directions, reductions shorter and longer
+    than the ring), NT and NN storage, with the epilogues the planner uses:
     bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU backward, dropout."""
     monkeypatch.setenv("ETP_GEMM_TILE", tile)
     dtype, t = _lib.ETP_BF16, torch.bfloat16
-    for (M, N, K) in [(300, 200, 128), (130, 72, 192), (257, 136, 768), (64, 64, 1024)]:
+    for (M, N, K) in [(300, 200, 128), (130, 72, 192), (257, 136, 768), (64, 64, 1024), (520, 392, 256)]:
         torch.manual_seed(M + N + K + tb)
         A = torch.randn(M, K, device=DEV).to(t)
         B = (torch.randn(N, K, device=DEV) * 0.1).to(t)
@@ -439,7 +439,7 @@ def _desc(A, B, C, M, N, K, ta, tb, dtype, c_dtype, out_mode=0):
 
 
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
-@pytest.mark.parametrize("tile", ["", "128s2", "128s3", "64s3", "64s4"])
+@pytest.mark.parametrize("tile", ["", "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"])
 def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
     """Seven TN products of different shapes / reduction lengths (an x-layer's weight gradients: token counts 512 and 2560,
     ragged 200-wide output) in ONE grid == the same products one by one; store and accumulate modes; every tile class."""
@@ -465,6 +465,29 @@ def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
     for (n, k, m), W, ref in zip(shapes, outs, refs):
         err = (W - ref).abs().max().item()
         assert err <= tol(dtype, math.sqrt(m) / 4), f"{(n, k, m)}: {err}"
+
+
+@pytest.mark.parametrize("tile", ["", "256s2", "256s3", "128s2"])
+def test_gemm_group_text_layer_weight_gradients_large_tiles(tile, monkeypatch):
+    """The four weight gradients of a text layer (the dominant launch of a step) as ONE grouped grid with every tile class
+    that fits them -- 256x128 tiles make it 216 workgroups, one per CU -- against fp32 matmuls; tokens = 640 (10 slabs)."""
+    monkeypatch.setenv("ETP_GROUP_TILE", tile)
+    torch.manual_seed(5)
+    dtype, t = _lib.ETP_BF16, torch.bfloat16
+    shapes = [(2304, 768, 640), (768, 768, 640), (3072, 768, 640), (768, 3072, 640)]
+    descs, refs, outs, keep = (GemmDesc * len(shapes))(), [], [], []
+    for i, (n, k, m) in enumerate(shapes):
+        dY = (torch.randn(m, n, device=DEV) * 0.5).to(t)
+        X = (torch.randn(m, k, device=DEV) * 0.5 + 0.05).to(t)
+        W = torch.full((n, k), float("nan"), device=DEV)
+        descs[i] = _desc(dY, X, W, n, k, m, 1, 1, dtype, _lib.ETP_F32, out_mode=0)
+        keep += [dY, X]
+        refs.append(dY.float().t() @ X.float()); outs.append(W)
+    check(L().etp_gemm_group(descs, len(shapes), stream()), "etp_gemm_group")
+    torch.cuda.synchronize()
+    for (n, k, m), W, ref in zip(shapes, outs, refs):
+        err = (W - ref).abs().max().item()
+        assert err <= tol(dtype, math.sqrt(m) / 4), f"{tile} {(n, k, m)}: {err}"
 
 
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])

@@ -1,7 +1,7 @@
 """Time the REAL reference planner (vlnce_baselines/models/etp/vilmodel_cmt.py, imported through oracle/ref_harness.py) on the
 host cores of the BUILD container, BASELINE.json configs[1] (B=32, L=80, V=36x768, G=16), fp32, fwd+bwd.
 
-    python tools/cpu_reference_timing.py > profiles/r02_cpu_reference.json
+    python tools/cpu_reference_timing.py > profiles/r03_cpu_reference.json
 
 /root/reference does not exist on the GPU box, so bench.py's `cpu_baseline` there times the oracle port; this file is the
 `kind: "reference"` counterpart measured where the reference can be imported (all physical cores, stated).

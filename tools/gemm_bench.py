@@ -117,7 +117,7 @@ def group_table():
               "x-layer node side (512 tok)": (512, [(768, 768), (768, 768), (2304, 768), (768, 768), (3072, 768), (768, 3072)]),
               "x-layer text K/V (2560 tok)": (2560, [(1536, 768)]),
               "RxR text layer (8192 tok)": (8192, [(2304, 768), (768, 768), (3072, 768), (768, 3072)])}
-    tiles = ["128s2", "128s3", "64s3", "64s4"]
+    tiles = ["256s2", "256s3", "128s2", "128s3", "64s3"]
     print(f"{'grouped weight gradients':34} " + " ".join(f"{t + ':us':>10} {'TF':>7}" for t in tiles))
     for name, (tok, shapes) in layers.items():
         row = f"{name:34} "

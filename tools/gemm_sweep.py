@@ -88,8 +88,8 @@ def main():
     shapes += [("fwd", 2560, 2 * H, H), ("dg_s", 2560, H, 2 * H), ("fwd", 512, H, H), ("dg_s", 512, H, H),
                ("fwd", 8192, 3 * H, H), ("fwd_s", 8192, H, H), ("fwd_g", 8192, I, H), ("fwd_s", 8192, H, I)]
     variants = ["64s3", "64s4", "ws3", "ws4", "128s2", "128s3"]
-    if os.environ.get("SWEEP_SPEC"):               # round 3: the warp-specialised classes (4 loader + 4 compute wavefronts)
-        variants = ["auto", "64s4", "ws4", "128s2", "64specr4", "64specr6", "64specr8", "wspecr4", "wspecr5", "wspecr6"]
+    if os.environ.get("SWEEP_256"):                # round 3: the eight-wavefront 256x128 class beside the four-wavefront ones
+        variants = ["auto", "64s4", "ws4", "128s2", "256s2", "256s3"]
     out = {"variants": variants, "shapes": {}, "ksweep": {}}
     for kind, M, N, K in shapes:
         key = f"{kind}:{M}x{N}x{K}"
@@ -97,7 +97,7 @@ def main():
             continue
         row = {}
         for v in variants:
-            if v.startswith("128") and (M < 128 or N < 128):
+            if (v.startswith("128") and (M < 128 or N < 128)) or (v.startswith("256") and (M < 256 or N < 128)):
                 continue
             row[v] = round(time_variant(kind, M, N, K, v), 2)
         best = min(row, key=row.get)
@@ -105,7 +105,7 @@ def main():
         out["shapes"][key] = {"us": row, "best": best, "best_tflops": round(fl / row[best] / 1e6, 1)}
         print(key, row, "->", best, file=sys.stderr, flush=True)
     for K in (128, 256, 512, 768, 1536, 3072):
-        kv = ("64s3", "ws3", "128s2") + (("wspecr5",) if os.environ.get("SWEEP_SPEC") else ())
+        kv = ("64s3", "ws3", "128s2") + (("256s2",) if os.environ.get("SWEEP_256") else ())
         out["ksweep"][str(K)] = {v: round(time_variant("fwd_s", 2560, 768, K, v), 2) for v in kv}
         print("ksweep", K, out["ksweep"][str(K)], file=sys.stderr, flush=True)
     os.environ["ETP_GEMM_TILE"] = ""

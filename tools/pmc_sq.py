@@ -8,13 +8,21 @@
 (8 SQ slots + 2 GRBM slots per pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots"; never combined with other trace
 domains.)  Kernels are grouped by (short name, grid); counters are means per launch.  Derived columns:
 
-    mfma_util   SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024)      matrix-pipe busy cycles summed over the chip's
-                                                                          1024 SIMDs / cycles the kernel was resident
+    mfma_util   SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  matrix-pipe busy cycles summed over the chip's
+                                                                          1024 SIMDs / cycles the kernel was resident.
+                                                                          GRBM_GUI_ACTIVE arrives summed over the 8 XCDs
+                                                                          (it reads 8 x duration x clock), hence the / 8;
+                                                                          check: the grouped weight-gradient GEMM's 2.2 M
+                                                                          MFMAs x ~14.4 busy cycles = 31.9 M = the counter
+    mfma_time   SQ_VALU_MFMA_BUSY_CYCLES / (duration * 2.4 GHz * 1024)   the same against the kernel's own duration at the
+                                                                          maximum clock: GRBM_GUI_ACTIVE also counts a window
+                                                                          around short kernels (it implies > 2.4 GHz for
+                                                                          kernels under ~20 us), which deflates mfma_util
     wait_frac   SQ_WAIT_ANY / SQ_WAVE_CYCLES                              wave parked on s_waitcnt / s_barrier
     stall_frac  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                         issue stalls
     issue_frac  SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
     lds_conf    SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE                  extra LDS cycles per LDS cycle
-    ghz         GRBM_GUI_ACTIVE / duration                                effective clock
+    ghz         GRBM_GUI_ACTIVE / 8 / duration                            effective clock
 
 The reference has no counterpart (host time.time() counters only: pretrain_src/pretrain_src/train_r2r.py:227,299-317).
 """
@@ -25,6 +33,7 @@ import re
 from collections import defaultdict
 
 csv.field_size_limit(1 << 30)
+XCDS = 8          # GRBM_GUI_ACTIVE is reported summed over the XCDs on gfx950
 
 
 def short(kernel: str) -> str:
@@ -67,7 +76,9 @@ def main():
         g = lambda c: e.get(c)
         ent = {"launches": n, "workgroups": k[1], "avg_us_under_pmc": round(d, 2), "counters": {c: round(v, 1) for c, v in e.items()}}
         if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and g("GRBM_GUI_ACTIVE"):
-            ent["mfma_util"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") * 1024.0), 4)
+            ent["mfma_util"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / XCDS * 1024.0), 4)
+            if d > 0:
+                ent["mfma_time"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (d * 2400.0 * 1024.0), 4)
         if g("SQ_WAVE_CYCLES"):
             for name, c in (("wait_frac", "SQ_WAIT_ANY"), ("stall_frac", "SQ_WAIT_INST_ANY"), ("issue_frac", "SQ_ACTIVE_INST_ANY")):
                 if g(c) is not None:
@@ -75,13 +86,13 @@ def main():
         if g("SQ_LDS_IDX_ACTIVE"):
             ent["lds_conf"] = round((g("SQ_LDS_BANK_CONFLICT") or 0.0) / g("SQ_LDS_IDX_ACTIVE"), 4)
         if g("GRBM_GUI_ACTIVE") and d > 0:
-            ent["ghz"] = round(g("GRBM_GUI_ACTIVE") / d * 1e-3, 3)
+            ent["ghz"] = round(g("GRBM_GUI_ACTIVE") / XCDS / d * 1e-3, 3)
         out[f"{k[0]} grid {k[1]}"] = ent
     rows = sorted(out.items(), key=lambda kv: -kv[1]["avg_us_under_pmc"] * kv[1]["launches"])
-    print(f"{'total us':>9} {'n':>4} {'avg us':>8} {'mfma':>6} {'wait':>6} {'stall':>6} {'issue':>6} {'ldsconf':>7} {'GHz':>5}  kernel")
+    print(f"{'total us':>9} {'n':>4} {'avg us':>8} {'mfma':>6} {'mfma_t':>6} {'wait':>6} {'stall':>6} {'issue':>6} {'ldsconf':>7} {'GHz':>5}  kernel")
     for name, e in rows[:a.top]:
         f = lambda x: f"{e[x]:6.3f}" if x in e else "     -"
-        print(f"{e['avg_us_under_pmc'] * e['launches']:9.0f} {e['launches']:4d} {e['avg_us_under_pmc']:8.2f} {f('mfma_util')} {f('wait_frac')} "
+        print(f"{e['avg_us_under_pmc'] * e['launches']:9.0f} {e['launches']:4d} {e['avg_us_under_pmc']:8.2f} {f('mfma_util')} {f('mfma_time')} {f('wait_frac')} "
               f"{f('stall_frac')} {f('issue_frac')} {f('lds_conf'):>7} {e.get('ghz', 0):5.2f}  {name}")
     if a.out:
         json.dump({"source": "rocprofv3 --pmc (one pass, 8 SQ + 1 GRBM counters) -- tools/pmc_sq.py", "kernels": dict(rows)},
