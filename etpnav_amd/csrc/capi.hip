@@ -234,15 +234,6 @@ int etp_stream_create_prio(etp_stream_t* out, int level) {
   *out = (etp_stream_t)s;
   return ETP_OK;
 }
-int etp_stream_create_masked(etp_stream_t* out, const uint32_t* cu_mask, int n_words) {
-  // a stream whose kernels may only run on the CUs whose bit is set (bit i of word i / 32): confines leaf work (weight gradients,
-  // the panorama branch) to a slice of the chip so that the dependent chain always finds free CUs
-  ETP_REQUIRE(out && cu_mask && n_words > 0, "null pointer");
-  hipStream_t s;
-  ETP_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
-  *out = (etp_stream_t)s;
-  return ETP_OK;
-}
 int etp_stream_destroy(etp_stream_t s) { ETP_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return ETP_OK; }
 int etp_stream_sync(etp_stream_t s) { ETP_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return ETP_OK; }
 int etp_stream_after(etp_stream_t from, etp_stream_t to) {

@@ -166,7 +166,7 @@ int launch_gemm(int dtype, int c_dtype, int transA, int transB, const GemmArgs& 
 // Several independent, unbatched, unsplit products of ONE (dtype, c_dtype, transA, transB) class in a single grid (LDS-DMA
 // kernel only: every reduction length must pass gemm_uses_dma).  n <= ETP_GEMM_GROUP_MAX.
 constexpr int ETP_GEMM_GROUP_MAX = 8;
-struct GemmGroup { int n; int xcd_chunks; int total_tiles; int tile_start[ETP_GEMM_GROUP_MAX + 1]; GemmArgs g[ETP_GEMM_GROUP_MAX]; };
+struct GemmGroup { int n; int xcd_chunks; int tile_start[ETP_GEMM_GROUP_MAX + 1]; GemmArgs g[ETP_GEMM_GROUP_MAX]; };
 int launch_gemm_group(int dtype, int c_dtype, int transA, int transB, const GemmArgs* gs, int n, hipStream_t st);
 bool gemm_uses_dma(int dtype, int K, int ksplit);   // true when launch_gemm will take the LDS-DMA kernel for this reduction
 // graphrec.hip: explicit hipGraph recording of everything issued through launch.h

@@ -907,33 +907,27 @@ __global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::M
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::MIN)) void gemm_group_kernel(const GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // grp.total_tiles > gridDim.x: PERSISTENT form -- the grid is capped (one workgroup per CU) and every workgroup walks its
-  // share of the tile list.  The group is leaf work running beside the dependent chain: two of its 64-KiB workgroups on a CU
-  // leave no LDS for any chain GEMM workgroup until one of them retires (33-66 us); capped at one per CU, every CU keeps 96 KiB
-  // and half its registers for the chain.
-  const int nwg = gridDim.x, total = grp.total_tiles;
-  for (int vb = blockIdx.x; vb < total; vb += nwg) {
-    if (vb != (int)blockIdx.x) __syncthreads();     // the previous tile's epilogue still reads its staging buffer
-    int id = vb;
-    if (grp.xcd_chunks) {    // uniform reduction lengths: contiguous chunk of the tile list per XCD (L2 locality)
-      // workgroup b sits on XCD b % 8 (also in the persistent form: nwg is a multiple of 8 there), so virtual index vb keeps it
-      const int xcd = vb & 7, q = total >> 3, r = total & 7;
-      id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-      if (id >= total) continue;                    // (only when total % 8 != 0 in the persistent form)
-    }                        // mixed lengths: dispatch order = list order (longest reductions first, spread over all XCDs)
-    int p = 0;
+  // (A persistent form -- grid capped at one workgroup per CU, every workgroup walking several tiles, so that the dependent
+  // chain always keeps half of every CU -- was measured SLOWER: 4.53 ms per step with 256 workgroups, 4.90 ms with 192 or 128,
+  // against 4.38 ms; profiles/r03_ab_runs.json group c7.  The step is bound by the throughput of chain + leaf work together.)
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  int id = bid;
+  if (grp.xcd_chunks) {      // uniform reduction lengths: contiguous chunk of the tile list per XCD (L2 locality)
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }                          // mixed lengths: dispatch order = list order (longest reductions first, spread over all XCDs)
+  int p = 0;
 #pragma unroll
-    for (int i = 1; i < ETP_GEMM_GROUP_MAX; ++i)
-      if (i < grp.n && id >= grp.tile_start[i]) p = i;
-    const GemmArgs& g = grp.g[p];
-    const int local = id - grp.tile_start[p];
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    int tm, tn;
-    if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
-    else { tn = local / tiles_m; tm = local % tiles_m; }
-    dma_tile<T, TC, TA, TB, BM, BN, STAGES, TileWaves<BM, BN>::NW>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
-                                                                 reinterpret_cast<TC*>(g.C), tm, tn, 0, smem, vb);
-  }
+  for (int i = 1; i < ETP_GEMM_GROUP_MAX; ++i)
+    if (i < grp.n && id >= grp.tile_start[i]) p = i;
+  const GemmArgs& g = grp.g[p];
+  const int local = id - grp.tile_start[p];
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  int tm, tn;
+  if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
+  else { tn = local / tiles_m; tm = local % tiles_m; }
+  dma_tile<T, TC, TA, TB, BM, BN, STAGES, TileWaves<BM, BN>::NW>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
+                                                               reinterpret_cast<TC*>(g.C), tm, tn, 0, smem, bid);
 }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
@@ -1068,16 +1062,11 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch * g.ksplit;
   const long tw = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * nbatch * g.ksplit;
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch * g.ksplit;
-  const long t256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * nbatch * g.ksplit;
-  // 256x128 (8 wavefronts, one workgroup per CU): 48 KiB per slab for 64 MFMAs per SIMD pair -- the only class whose MFMA time
-  // matches the CU's LDS-DMA feed (~40 B/clk, profiles/r03b_gemm_sweep_dma_only.json); taken when it gives most CUs a tile
-  bool huge = g.M >= 256 && g.N >= 128 && nbatch == 1 && t256 >= 160;
-  // default OFF for the planner's shapes: measured on MI355X (profiles/r03d_*) the 256x128 loop runs at the SAME rate per CU as
-  // two co-resident 128x128 workgroups (1.0 us per 256x128x64 slab either way: both sit at ~50 % MFMA issue rate, 2 wavefronts
-  // per SIMD), while 180 / 216 / 240 tiles leave 6-30 % of the CUs idle and the epilogue per workgroup doubles:
-  // step 4.51 ms with it, 4.37 ms without.  ETP_GEMM_256=1 or a "256..." tile enables it (it wins from ~8192 rows).
-  static const int huge_on = [] { const char* e = getenv("ETP_GEMM_256"); return (e && e[0] == '1') ? 1 : 0; }();
-  if (!huge_on) huge = false;
+  // 256x128 (eight wavefronts, one workgroup per CU) exists as a FORCED tile class only ("256s2" / "256s3"): measured on
+  // MI355X (profiles/r03d_*, r03_ab_runs.json group c5) its loop runs at the same rate per CU as two co-resident 128x128
+  // workgroups (1.0 us per 256x128x64 slab of work either way, ~50 % MFMA issue rate at two wavefronts per SIMD) while its
+  // 180 / 216 / 240 tiles leave 6-30 % of the CUs idle: step 4.51 ms with it against 4.37 ms; no shape up to 8192 rows wins.
+  bool huge = false;
   bool big = !huge && (g.M >= 128 && g.N >= 128 && t128 >= 360);
   bool wide = !huge && !big && g.M >= 128 && g.N >= 64 && tw >= 200 && tw <= 520 && nbatch == 1;
   static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1177,11 +1166,7 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
   using GA = TileGeom<T, TA, BM, 0>;
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
-  // ETP_GROUP_WG_PER_CU=1: request more than half of the CU's LDS so that only ONE workgroup of this (leaf) kernel fits on a CU;
-  // the other half of the CU's registers / LDS then stays free for the dependent chain's workgroups while the group runs
-  static const int one_per_cu = [] { const char* e = getenv("ETP_GROUP_WG_PER_CU"); return (e && e[0] == '1') ? 1 : 0; }();
-  constexpr int smem_tile = smem_loop > smem_c ? smem_loop : smem_c;
-  const int smem = (one_per_cu && smem_tile < 84 * 1024) ? 84 * 1024 : smem_tile;
+  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
   static bool attr_set = false;
   void (*kern)(const GemmGroup) = gemm_group_kernel<T, TC, TA, TB, BM, BN, STAGES>;
   if (!attr_set) {
@@ -1198,10 +1183,7 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
     bytes += ((double)g.M * g.K + (double)g.N * g.K) * sizeof(T) + (double)g.M * g.N * sizeof(TC);
   }
   for (int i = grp.n; i <= ETP_GEMM_GROUP_MAX; ++i) grp.tile_start[i] = tiles;
-  grp.total_tiles = tiles;
-  // persistent form: at most `cap` workgroups (a multiple of 8, one per CU by default) walk the tile list
-  const int cap = [] { const char* e = getenv("ETP_GROUP_PERSIST"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
-  const int grid = (cap > 0 && tiles > cap) ? cap : tiles;
+  const int grid = tiles;
   char nm[96];
   snprintf(nm, sizeof(nm), "gemm_group<%s,%s,%s%s,%dx%d,s%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
            TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);
@@ -1239,16 +1221,10 @@ static int launch_group_tiles(GemmGroup& grp, hipStream_t st) {
   }
   // 128x128 tiles halve the L2->LDS bytes per FLOP; they pay once the group still gives most CUs a tile
   bool big = all_big && t128 >= 160;
-  // 256x128 (8 wavefronts, one workgroup per CU) halves them again: a text layer's four weight gradients are 216 such tiles
-  long t256 = 0;
+  // 256x128: forced only (see launch_tiles)
   bool all_huge = sizeof(T) == 2;
-  for (int i = 0; i < grp.n; ++i) {
-    t256 += (long)((grp.g[i].M + 255) / 256) * ((grp.g[i].N + 127) / 128);
-    all_huge = all_huge && grp.g[i].M >= 256 && grp.g[i].N >= 128;
-  }
-  bool huge = all_huge && t256 >= 128;
-  static const int huge_on = [] { const char* e = getenv("ETP_GEMM_256"); return (e && e[0] == '1') ? 1 : 0; }();   // see launch_tiles
-  if (!huge_on) huge = false;
+  for (int i = 0; i < grp.n; ++i) all_huge = all_huge && grp.g[i].M >= 256 && grp.g[i].N >= 128;
+  bool huge = false;
   int stages = (big || huge) ? 2 : 3;
   const char* force = getenv("ETP_GROUP_TILE");          // tuning aid: "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"
   if (force && force[0]) {

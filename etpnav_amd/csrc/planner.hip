@@ -853,13 +853,6 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     if (l >= layer_hi || l < layer_lo) continue;
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
-    {
-      // ETP_WGRAD_FLUSH=2: the two FFN weight gradients leave for the side stream as soon as the FFN backward is enqueued
-      // instead of waiting for the attention backward of the same layer: shorter leaf launches, and only the attention
-      // half of layer 0 is left as the tail of the step
-      static const int twice = [] { const char* e = getenv("ETP_WGRAD_FLUSH"); return (e && e[0] == '2') ? 1 : 0; }();
-      if (twice) ETP_TRY(flush_side(c));
-    }
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     ETP_TRY(flush_side(c));          // this layer's four weight gradients: one fork
   }

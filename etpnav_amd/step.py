@@ -50,26 +50,12 @@ def build_node_csr(view_lens: torch.Tensor, V: int, G: int):
     return (i32(ptr_f), i32(idx_f), f32(w_f)), (i32(ptr_b), i32(idx_b), f32(w_b))
 
 
-def _cu_mask(spec: str, n_cus: int = 256):
-    """'a/b' -> CUs i with (i mod b) < a as a uint32 mask array (a regular pattern: the same share of every XCD whatever the
-    CU numbering), e.g. '1/4' = 64 of 256 CUs."""
-    a, b = (int(x) for x in spec.split("/"))
-    words = (ctypes.c_uint32 * (n_cus // 32))()
-    for i in range(n_cus):
-        if i % b < a:
-            words[i // 32] |= 1 << (i % 32)
-    return words
-
-
-def _side_stream(L, level: int, mask_env: str):
-    """leaf stream: lowest priority by default; with ETP_<X>_CU_MASK='a/b' a CU-masked stream instead"""
-    spec = os.environ.get(mask_env, "")
+def _side_stream(L, level: int):
+    """leaf stream (weight gradients / the panorama branch) at the lowest priority.  (Confining these streams to a slice of the
+    chip with hipExtStreamCreateWithCUMask was measured 1.8x SLOWER -- 7.8 ms per step whatever the share,
+    profiles/r03_ab_runs.json group c4 -- and is not offered.)"""
     h = ctypes.c_void_p()
-    if spec:
-        m = _cu_mask(spec)
-        check(L.etp_stream_create_masked(ctypes.byref(h), m, len(m)), "stream_create_masked")
-    else:
-        check(L.etp_stream_create_prio(ctypes.byref(h), level), "stream_create")
+    check(L.etp_stream_create_prio(ctypes.byref(h), level), "stream_create")
     return h.value
 
 
@@ -155,9 +141,9 @@ class PlannerStep:
         if not self._own_aux:                  # MicroBatchedStep: one weight-gradient / d_txt stream for all micro-batches
             self.aux = share_side_streams.aux
         elif overlap in (True, "aux", "both"):
-            self.aux = _side_stream(self.L, low, "ETP_AUX_CU_MASK")
+            self.aux = _side_stream(self.L, low)
         if overlap in (True, "s2", "both"):
-            self.s2 = _side_stream(self.L, low, "ETP_S2_CU_MASK")
+            self.s2 = _side_stream(self.L, low)
         self.aux2 = None
         if not self._own_aux:
             self.aux2 = share_side_streams.aux2

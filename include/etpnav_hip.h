@@ -410,9 +410,6 @@ int etp_stream_create(etp_stream_t* out);
 /* level < 0: the lowest priority the device offers (for leaf work such as weight gradients, so that the dependent chain's
  * workgroups are dispatched first whenever both wait for a CU), 0: default, > 0: highest. */
 int etp_stream_create_prio(etp_stream_t* out, int level);
-/* a stream confined to the CUs whose bit is set in cu_mask (bit i of word i / 32; 256 CUs = 8 words on MI355X):
- * hipExtStreamCreateWithCUMask.  Used for leaf work so that the dependent chain always finds free CUs. */
-int etp_stream_create_masked(etp_stream_t* out, const uint32_t* cu_mask, int n_words);
 int etp_stream_destroy(etp_stream_t s);
 int etp_stream_sync(etp_stream_t s);
 /* make `to` wait for the work enqueued so far on `from` (fork / join of parallel branches; capturable) */

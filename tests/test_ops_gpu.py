@@ -467,13 +467,11 @@ def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
         assert err <= tol(dtype, math.sqrt(m) / 4), f"{(n, k, m)}: {err}"
 
 
-@pytest.mark.parametrize("persist", ["0", "256", "64"])
 @pytest.mark.parametrize("tile", ["", "256s2", "256s3", "128s2"])
-def test_gemm_group_text_layer_weight_gradients_large_tiles(tile, persist, monkeypatch):
+def test_gemm_group_text_layer_weight_gradients_large_tiles(tile, monkeypatch):
     """The four weight gradients of a text layer (the dominant launch of a step) as ONE grouped grid with every tile class
     that fits them -- 256x128 tiles make it 216 workgroups, one per CU -- against fp32 matmuls; tokens = 640 (10 slabs)."""
     monkeypatch.setenv("ETP_GROUP_TILE", tile)
-    monkeypatch.setenv("ETP_GROUP_PERSIST", persist)       # capped persistent grid: every workgroup walks several tiles
     torch.manual_seed(5)
     dtype, t = _lib.ETP_BF16, torch.bfloat16
     shapes = [(2304, 768, 640), (768, 768, 640), (3072, 768, 640), (768, 3072, 640)]
