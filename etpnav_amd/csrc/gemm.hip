@@ -1069,7 +1069,11 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   bool huge = false;
   bool big = !huge && (g.M >= 128 && g.N >= 128 && t128 >= 360);
   bool wide = !huge && !big && g.M >= 128 && g.N >= 64 && tw >= 200 && tw <= 520 && nbatch == 1;
-  static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+  // The 128x64 class is OFF by default: alone it is the faster kernel for the M = 2560, N = 768 products (25.1 vs 28.4 us at
+  // K = 3072 in a single-stream step), but in the real three-stream step the 64x64 class wins, 4.30 vs 4.35 ms per step in
+  // three same-box A/B pairs (profiles/r03_ab_runs.json groups c1, c8): its 48-KiB, ~130-register workgroups pack beside the
+  // leaf kernels' workgroups where one 96-KiB 128x64 workgroup per CU does not.  ETP_GEMM_WIDE=1 enables it.
+  static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();
   if (!wide_on) wide = false;
   const bool dma = dma_ok(BK, g.K, g.ksplit);
   int stages = (big || huge) ? 2 : (wide ? 4 : 3);
