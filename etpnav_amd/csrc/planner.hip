@@ -853,17 +853,6 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     if (l >= layer_hi || l < layer_lo) continue;
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
-    {
-      // EXPERIMENT (tools/r03_call9.sh) ETP_FLUSH_MID=1: one fork per layer as before, but placed after the FFN backward -- the
-      // group then holds [attention gradients of layer l+1, FFN gradients of layer l] and meets the attention half of the
-      // chain instead of the two large FFN products
-      static const int mid = [] { const char* e = getenv("ETP_FLUSH_MID"); return (e && e[0] == '1') ? 1 : 0; }();
-      if (mid) {
-        ETP_TRY(flush_side(c));
-        ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
-        continue;
-      }
-    }
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     ETP_TRY(flush_side(c));          // this layer's four weight gradients: one fork
   }
