@@ -536,6 +536,50 @@ class GlocalTextPathNavCMT(nn.Module):
                                       gmap_visited_masks.to(torch.bool).contiguous(), dists)
         return {"gmap_embeds": embeds, "global_logits": logits}
 
+    def forward_navigation_steps(self, txt_embeds, txt_masks, steps):
+        """T navigation steps of one rollout in ONE batched call (second half).
+
+        The trainer calls forward_navigation once per rollout step on the same instruction embeddings
+        (ss_trainer_ETP.py:819-822,878) and sums the step losses before a single backward (:1055).  A step's node axis holds
+        B * G = a few hundred rows -- every kernel of such a call is latency-bound on an MI355X, forward and
+        backward.  When the inputs of several steps are known together (teacher-forced training, or replaying a finished
+        rollout for its backward), the steps are independent given the text, so they run as one (T * B)-episode batch: the
+        per-step graphs are padded to the largest node count (padded nodes are masked: no attention weight, -inf logit),
+        stacked along the batch axis, and the text is repeated T times -- autograd's repeat backward is the sum over the steps
+        that the reference's shared txt_embeds tensor produces.  One launch sequence with T times the rows instead of T
+        sequences; results and gradients equal the per-step calls (tests/test_baseline_shapes_gpu.py).
+
+        steps: list of dicts with gmap_step_ids [B,G_t], gmap_img_fts [B,G_t,H], gmap_pos_fts [B,G_t,7], gmap_masks [B,G_t],
+        gmap_visited_masks [B,G_t], gmap_pair_dists [B,G_t,G_t].  Returns a list of {'gmap_embeds', 'global_logits'} per step,
+        sliced back to G_t.  (The text K/V projections are recomputed for the T * B * L stacked rows: large, efficient GEMMs,
+        like the reference's own per-step re-projection; cache_text_kv does not apply to this call.)"""
+        T = len(steps)
+        if T == 0:
+            return []
+        B = txt_embeds.shape[0]
+        Gs = [int(st["gmap_step_ids"].shape[1]) for st in steps]
+        Gm = max(Gs)
+
+        def pad(x, dims, value=0):          # pad the node axes `dims` of x to Gm
+            for d in dims:
+                g = x.shape[d]
+                if g < Gm:
+                    shape = list(x.shape)
+                    shape[d] = Gm - g
+                    x = torch.cat([x, x.new_full(shape, value)], dim=d)
+            return x
+
+        cat = lambda key, dims, value=0: torch.cat([pad(st[key], dims, value) for st in steps], dim=0)
+        out = self.forward_navigation(txt_embeds.repeat(T, 1, 1), txt_masks.repeat(T, 1), None,
+                                      cat("gmap_step_ids", (1,)), cat("gmap_img_fts", (1,)), cat("gmap_pos_fts", (1,)),
+                                      cat("gmap_masks", (1,), False), cat("gmap_visited_masks", (1,), False),
+                                      cat("gmap_pair_dists", (1, 2)))
+        res = []
+        for t, g in enumerate(Gs):
+            res.append({"gmap_embeds": out["gmap_embeds"][t * B:(t + 1) * B, :g],
+                        "global_logits": out["global_logits"][t * B:(t + 1) * B, :g]})
+        return res
+
     def forward(self, mode, batch, **kwargs):
         # the reference's own forward (vilmodel_cmt.py:752-771) is dead code calling non-existent methods
         raise NotImplementedError("use forward_txt / forward_panorama / forward_navigation")

@@ -146,6 +146,65 @@ def test_rollout_matches_reference_golden_with_and_without_text_kv_cache(cached,
         print("rollout bf16", compare_grads_bf16(z, grads_of(model)))
 
 
+def _hip_rollout_batched(model, ids, masks, steps):
+    model.zero_grad()
+    txt = model.forward_txt(ids, masks)
+    outs = model.forward_navigation_steps(txt, masks, steps)
+    loss = 0.0
+    for o, st in zip(outs, steps):
+        loss = loss + F.cross_entropy(o["global_logits"], st["labels"], reduction="sum", ignore_index=-100) / ids.shape[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    return {"txt_embeds": txt.detach(), "loss": loss.detach(), "steps": [{k: v.detach() for k, v in o.items()} for o in outs]}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_rollout_steps_match_reference_golden(dtype):
+    """forward_navigation_steps (second half): the T = 3 steps of the REAL reference's rollout fixture as ONE
+    (T * B)-episode navigation call -- outputs of every step and all parameter gradients (text encoder included: the sum over
+    the steps) against the reference."""
+    z, cfg, P, ids, masks, steps = load_rollout()
+    model = build_model(cfg, P, dtype)
+    dsteps = [{k: v.cuda() for k, v in st.items()} for st in steps]
+    outs = _hip_rollout_batched(model, ids.cuda(), masks.cuda(), dsteps)
+    if dtype == torch.float32:
+        compare_rollout(z, outs, atol=2e-4)
+        compare_grads(z, grads_of(model), atol=2e-4, rel=2e-3, rel_sample=2e-3)
+    else:
+        compare_rollout(z, outs, atol=5e-2)
+        print("batched rollout bf16", compare_grads_bf16(z, grads_of(model)))
+
+
+def test_batched_rollout_with_growing_graphs_equals_per_step_calls():
+    """Steps whose graphs have DIFFERENT node counts (the topological map grows during an episode): the batched call pads
+    them to the largest count; every step's outputs on its own nodes and every gradient must equal the per-step calls."""
+    cfg = po.PlannerConfig.r2r(vocab_size=2048)
+    P = po.init_params(cfg, seed=21)
+    B, L = 3, 18
+    base = po.make_batch(cfg, B=B, L=L, V=8, G=6, seed=60, ragged=True)
+    ids, masks = base["txt_ids"].cuda(), base["txt_masks"].cuda()
+    steps = []
+    for t, G in enumerate((5, 8, 11)):
+        bt = po.make_batch(cfg, B=B, L=L, V=8, G=G, seed=61 + t, ragged=True)
+        gen = torch.Generator().manual_seed(200 + t)
+        bt["gmap_img_fts"] = torch.randn(B, G, cfg.hidden_size, generator=gen) * 0.5
+        steps.append({k: v.cuda() for k, v in bt.items() if k.startswith("gmap_") or k == "labels"})
+    model = build_model(cfg, P, torch.float32)
+    a = _hip_rollout(model, ids, masks, steps)
+    ga = grads_of(model)
+    b = _hip_rollout_batched(model, ids, masks, steps)
+    gb = grads_of(model)
+    assert abs(a["loss"].item() - b["loss"].item()) < 2e-5
+    for sa, sb in zip(a["steps"], b["steps"]):
+        fin = torch.isfinite(sa["global_logits"])
+        assert torch.equal(fin, torch.isfinite(sb["global_logits"]))
+        assert (sa["global_logits"][fin] - sb["global_logits"][fin]).abs().max().item() < 2e-5
+        assert (sa["gmap_embeds"] - sb["gmap_embeds"]).abs().max().item() < 2e-5
+    for k in ga:
+        err = (ga[k] - gb[k]).abs().max().item()
+        assert err < 2e-5 + 2e-4 * ga[k].abs().max().item(), f"{k}: {err}"
+
+
 def test_rollout_train_mode_matches_oracle_with_same_masks():
     """Train-mode rollout through the module API (every entry-point call draws its own mask stream): cached and uncached
     runs must both match the oracle given the same per-call seeds."""

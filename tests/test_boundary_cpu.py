@@ -144,3 +144,32 @@ def test_dropout_mask_generator_is_pinned_and_calibrated():
     assert a[:4] == (0.1, 0.1, 0.1, 0.0) and a[4] == (3 << 32) | 1 and b[4] == (3 << 32) | 2
     m.eval()
     assert m._dropout() is None
+
+
+def test_dropout_generator_statistics_match_nn_dropout():
+    """the train-mode parity tests compare the HIP masks with the oracle's restatement of the SAME hash, which
+    says nothing about the hash being a fair Bernoulli(1-p) source.  Here the library's masks (host view, etp_dropout_multipliers)
+    are held against torch.nn.Dropout(p) itself: keep rate within 4 binomial sigmas of 1-p (as nn.Dropout's own draw is), the
+    multiplier's mean within 4 sigmas of 1 (unbiasedness, what makes dropout a no-op in expectation), lag-1 .. lag-64 serial
+    correlation of the keep bits below 4 sigmas (consecutive elements of a row are independent, as with Philox), and per-column
+    keep rates of a [rows, 768] activation flat (no column is favoured: element index = row * H + col)."""
+    import numpy as np
+    L = _lib.lib()
+    n = 768 * 512
+    for p in (0.1, 0.4):
+        out = np.empty(n, np.float32)
+        assert L.etp_dropout_multipliers(p, (5 << 32) | 17, 1, 2, 3, n, out.ctypes.data) == 0
+        torch.manual_seed(0)
+        ref = torch.nn.functional.dropout(torch.ones(n), p, training=True).numpy()
+        sig = np.sqrt(p * (1 - p) / n)
+        for name, x in (("etp", out), ("nn.Dropout", ref)):
+            kept = (x != 0).astype(np.float64)
+            assert abs(kept.mean() - (1 - p)) < 4 * sig, (name, p, kept.mean())
+            assert abs(x.mean() - 1.0) < 4 * sig / (1 - p), (name, p, x.mean())
+        kept = (out != 0).astype(np.float64) - (1 - p)
+        var = p * (1 - p)
+        for lag in (1, 2, 3, 7, 8, 16, 64, 768):
+            r = float((kept[:-lag] * kept[lag:]).mean() / var)
+            assert abs(r) < 4 / np.sqrt(n - lag), (p, lag, r)
+        cols = (out.reshape(512, 768) != 0).mean(0)
+        assert abs(cols - (1 - p)).max() < 5 * np.sqrt(p * (1 - p) / 512), (p, cols.min(), cols.max())

@@ -73,6 +73,35 @@ def test_grad_reducer_world2_gloo(comm_dtype, ragged, capacity):
         assert ok, f"rank {rank}: max err {err}"
 
 
+def _native_decision_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            comm = dp.NativeComm.create(torch.device("cpu"), torch.float32, 1024)
+        q.put((rank, comm is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_communicator_decision_is_collective():
+    """a rank that cannot set up the library's RCCL communicator must not leave the others inside
+    ncclCommInitRank.  On CPU ranks the initialisation cannot succeed; NativeComm.create must come back None on EVERY rank
+    (availability and outcome are min-reduced over the group) without hanging, and the reducer then uses torch.distributed."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_decision_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(none for _, none in res), res
+
+
 def test_planner_bucket_ranges_cover_the_arena_once():
     from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
     m = GlocalTextPathNavCMT(default_config(vocab_size=1024), dtype=torch.float32, device="cpu")

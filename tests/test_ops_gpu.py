@@ -153,6 +153,40 @@ def test_gemm_tile_classes_with_epilogues(tile, tb, monkeypatch):
         assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K, "dgelu")
 
 
+@pytest.mark.parametrize("tile", ["64s2", "64s3", "64s4", "ws2", "ws3", "ws4", "128s2", "128s3", "256s2", "256s3"])
+def test_gemm_race_screen_under_uneven_load(tile, monkeypatch):
+    """The round-3 main loop changed the synchronisation structure (one barrier BETWEEN a slab's k-steps, the whole ring in
+    flight, counted vmcnt): cdna_hip_programming.md asks for a multi-run race screen of such edits, under UNEVEN load.  Every
+    tile class / ring depth runs the same products 12 times while a bandwidth-heavy copy loop on a second stream perturbs the
+    DMA timing; a stale or early LDS read would show as a run that differs from the others.  Outputs must be bit-identical
+    across runs and match the fp32 reference; reductions of 2, 3, 5 and 24 slabs cover the ring's fill / drain paths."""
+    monkeypatch.setenv("ETP_GEMM_TILE", tile)
+    dtype, t = _lib.ETP_BF16, torch.bfloat16
+    side = torch.cuda.Stream()
+    noise_a = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
+    noise_b = torch.empty_like(noise_a)
+    for (M, N, K, tb) in [(512, 384, 128, 0), (384, 256, 192, 1), (640, 768, 320, 0), (768, 512, 1536, 1)]:
+        torch.manual_seed(M + K)
+        A = torch.randn(M, K, device=DEV).to(t)
+        B = (torch.randn(N, K, device=DEV) * 0.1).to(t)
+        Bs = B.t().contiguous() if tb else B
+        ref = A.float() @ B.float().t()
+        first = None
+        for it in range(12):
+            C = torch.full((M, N), float("nan"), device=DEV)
+            if it % 2 == 1:                      # every other run competes with a streaming copy (uneven load)
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        noise_b.copy_(noise_a, non_blocking=True)
+            run_gemm(A, Bs, C, M, N, K, 0, tb, dtype, c_dtype=_lib.ETP_F32)
+            side.synchronize()
+            if first is None:
+                first = C.clone()
+                assert (C - ref).abs().max().item() <= tol(dtype, math.sqrt(K) / 4), (tile, M, N, K)
+            else:
+                assert torch.equal(C, first), (tile, M, N, K, it, (C - first).abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
 def test_gemm_wgrad_splitk_fp32_out(dtype):
     """dW[N,K] += dY[M,N]^T X[M,K]: TN storage, fp32 output, RMW and atomic split-K."""
