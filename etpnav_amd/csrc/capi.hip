@@ -327,6 +327,7 @@ int64_t etp_gemm_probe_count(void) { return gemm_probe_count(); }
 int etp_gemm_probe_meta(int64_t i, char* name, int cap, int32_t* dims) { return gemm_probe_meta((long)i, name, cap, dims); }
 int etp_prof_enable(int on) { prof_enable(on != 0); return ETP_OK; }
 int etp_prof_reset(void) { prof_reset(); return ETP_OK; }
+int etp_prof_filter(const char* name_part) { prof_filter(name_part); return ETP_OK; }
 int etp_prof_report(etp_prof_entry* out, int cap) {
   if (!out || cap <= 0) return 0;
   return prof_report(out, cap);

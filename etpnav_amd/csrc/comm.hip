@@ -31,6 +31,7 @@ struct Rccl {
   int (*GetUniqueId)(rcclUniqueId*) = nullptr;
   int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int) = nullptr;
   int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*CommAbort)(rcclComm_t) = nullptr;             // optional: only used to get out of a collective that never completes
   const char* (*GetErrorString)(int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
   int (*ReduceScatter)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
@@ -59,6 +60,7 @@ int load_rccl() {
   ETP_RCCL_SYM(ReduceScatter, "ncclReduceScatter")
   ETP_RCCL_SYM(AllGather, "ncclAllGather")
 #undef ETP_RCCL_SYM
+  g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
   g_rccl.lib = h;
   return ETP_OK;
 }
@@ -267,9 +269,27 @@ int etp_allreduce_wait(etp_comm* c, etp_stream_t consumer) {
   return ETP_OK;
 }
 
+// 1 when everything issued on the communicator's stream so far has completed, 0 while work is in flight (host-side poll for
+// the first-contact self-test, etpnav_amd/dp.py: a collective that never completes must not block the caller)
+int etp_allreduce_idle(etp_comm* c) {
+  if (!c || !c->stream) return 1;
+  return hipStreamQuery(c->stream) == hipSuccess ? 1 : 0;
+}
+
+// Give up on the communicator without waiting for work in flight (ncclCommAbort): after a timed-out self-test every rank
+// aborts, destroys the handle and falls back to torch.distributed.  The handle stays valid for etp_allreduce_destroy only.
+int etp_allreduce_abort(etp_comm* c) {
+  ETP_REQUIRE(c, "null communicator");
+  if (c->comm) {
+    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+    c->comm = nullptr;                                  // never ncclCommDestroy an aborted communicator
+  }
+  return ETP_OK;
+}
+
 int etp_allreduce_destroy(etp_comm* c) {
   if (!c) return ETP_OK;
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream && c->comm) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   for (auto& e : c->events) (void)hipEventDestroy(e);
   if (c->staging) (void)hipFree(c->staging);

@@ -180,6 +180,7 @@ void gemm_probe_set(unsigned long long* buf, long launches);
 long gemm_probe_count();
 int gemm_probe_meta(long i, char* name, int cap, int* dims);
 void prof_enable(bool on);
+void prof_filter(const char* name_part);
 void prof_reset();
 int prof_report(etp_prof_entry* out, int cap);
 

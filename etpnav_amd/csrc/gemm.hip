@@ -933,11 +933,14 @@ __global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::M
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ---------------------------------------
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static bool g_prof_on = false;
+static std::string g_prof_only;          // when set, only launches whose name contains it are bracketed (fewer event packets)
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::string> g_prof_names;
 static std::mutex g_prof_mu;
 
 void prof_enable(bool on) { g_prof_on = on; }
+void prof_filter(const char* name_part) { g_prof_only = name_part ? name_part : ""; }
+static bool prof_wanted(const char* nm) { return g_prof_only.empty() || strstr(nm, g_prof_only.c_str()) != nullptr; }
 void prof_reset() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1019,7 +1022,7 @@ static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
            sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN, STAGES);   // BLAS-style opA,opB
   g.dbg = (STAGES > 0 && g_probe_buf) ? probe_slot(nm, (long)tiles * nbatch * g_in.ksplit, g.M, g.N, g.K) : nullptr;
   ProfRec rec;
-  const bool prof = g_prof_on && !rec_active();
+  const bool prof = g_prof_on && !rec_active() && prof_wanted(nm);
   if (prof) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     rec.id = prof_id(nm);
@@ -1196,7 +1199,7 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
     for (int i = 0; i < grp.n; ++i) grp.g[i].dbg = slot;
   }
   ProfRec rec;
-  const bool prof = g_prof_on && !rec_active();
+  const bool prof = g_prof_on && !rec_active() && prof_wanted(nm);
   if (prof) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     rec.id = prof_id(nm);

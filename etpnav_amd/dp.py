@@ -66,12 +66,27 @@ class NativeComm:
                 comm.close()
             warnings.warn(f"etp_allreduce_init failed on some rank ({err}); all ranks use torch.distributed collectives")
             return None
+        # first contact: a small dense bucket and a small row-sparse exchange with known answers, polled from the host with a
+        # deadline -- a communicator that returns wrong values or never completes is aborted on EVERY rank (collective
+        # decision again) before any gradient goes through it
+        why = None
+        if os.environ.get("ETP_DP_SELFTEST", "1") != "0":
+            try:
+                why = comm.self_test(float(os.environ.get("ETP_DP_SELFTEST_TIMEOUT", "60")))
+            except Exception as e:           # noqa: BLE001
+                why = f"{type(e).__name__}: {e}"
+        if not cls._all_ok(why is None, device, group):
+            comm.abort()
+            warnings.warn(f"etp_allreduce_* self-test failed on some rank ({why or 'another rank'}); all ranks use "
+                          "torch.distributed collectives")
+            return None
         return comm
 
     def __init__(self, device: torch.device, comm_dtype=torch.float32, max_bucket_elems: int = 0, group=None):
         from . import _lib
         self._lib, self.L = _lib, _lib.lib()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.comm_dtype = comm_dtype
         ident = (ctypes.c_ubyte * 128)()
         if self.rank == 0:
             _lib.check(self.L.etp_allreduce_unique_id(ident), "allreduce_unique_id")
@@ -100,6 +115,53 @@ class NativeComm:
 
     def wait(self):
         self._lib.check(self.L.etp_allreduce_wait(self.handle, torch.cuda.current_stream().cuda_stream), "allreduce_wait")
+
+    def _drain(self, timeout_s: float) -> bool:
+        """Poll the communicator's stream from the host until it is idle; False when the deadline passes first."""
+        import time
+        t_end = time.monotonic() + timeout_s
+        while not self.L.etp_allreduce_idle(self.handle):
+            if time.monotonic() > t_end:
+                return False
+            time.sleep(0.002)
+        return True
+
+    def self_test(self, timeout_s: float = 60.0) -> Optional[str]:
+        """Known-answer run of both collectives on this communicator.  Returns None when they completed within the deadline
+        with the right values, else a description.  Dense: every rank contributes (rank + 1) -> mean (world + 1) / 2, on a
+        length that exercises the reduce-scatter body AND the all-reduce tail of etp_allreduce_bucket_ready.  Row-sparse:
+        rank r owns row r (value r + 1), all ranks share row `world` (value 10 * (rank + 1)), one id repeated."""
+        W, r = self.world, self.rank
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n = W * 64 * 3 + 17
+        dense = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
+        table = torch.zeros(W + 2, 64, dtype=torch.float32, device=dev)
+        table[r] = float(r + 1)
+        table[W] = 10.0 * (r + 1)
+        ids = torch.tensor([r, W, r], dtype=torch.int64, device=dev)
+        torch.cuda.current_stream().synchronize()
+        self.bucket_ready(dense, 0, n)
+        self.gather_rows(table, ids, 4)
+        if not self._drain(timeout_s):
+            return f"collectives did not complete within {timeout_s:.0f} s"
+        tol = 2e-2 if self.comm_dtype == torch.bfloat16 else 1e-6
+        want = (W + 1) / 2.0
+        bad = (dense - want).abs().max().item()
+        if not bad <= tol * want:
+            return f"dense mean off by {bad:.3g} (expected {want})"
+        exp = torch.zeros_like(table)
+        for k in range(W):
+            exp[k] = (k + 1) / W
+        exp[W] = 10.0 * want
+        bad = (table - exp).abs().max().item()
+        if not bad <= tol * 10.0 * want:
+            return f"row-sparse mean off by {bad:.3g}"
+        return None
+
+    def abort(self):
+        if getattr(self, "handle", None):
+            self.L.etp_allreduce_abort(self.handle)
+            self.close()
 
     def close(self):
         if getattr(self, "handle", None):

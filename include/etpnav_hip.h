@@ -440,6 +440,12 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
 /* 1 when librccl can be bound in this process (ranks agree on it before any of them enters etp_allreduce_init) */
 int etp_allreduce_available(void);
 int etp_allreduce_wait(etp_comm* c, etp_stream_t consumer);
+/* Host-side poll: 1 when everything issued on the communicator's stream has completed, 0 while work is in flight.  With
+ * etp_allreduce_abort (ncclCommAbort; afterwards only etp_allreduce_destroy is valid) this lets a first-contact self-test give
+ * up on a collective that never completes instead of blocking the job: etpnav_amd/dp.py NativeComm.self_test.  (DDP has no
+ * counterpart; its watchdog is NCCL_ASYNC_ERROR_HANDLING inside torch.distributed, ss_trainer_ETP.py:208-212.) */
+int etp_allreduce_idle(etp_comm* c);
+int etp_allreduce_abort(etp_comm* c);
 int etp_allreduce_destroy(etp_comm* c);
 int etp_allreduce_rank(const etp_comm* c);
 int etp_allreduce_world(const etp_comm* c);
@@ -475,6 +481,9 @@ int etp_ktime_reset(void);
 int64_t etp_ktime_report(char* buf, int64_t cap);
 int etp_prof_enable(int on);
 int etp_prof_reset(void);
+/* Bracket only launches whose name contains `name_part` (NULL / "" = all): with the step on its three streams every event pair is
+ * a barrier packet the queues must process, so timing one kernel class in-step should not bracket the other 150 launches. */
+int etp_prof_filter(const char* name_part);
 /* Phase probe of the LDS-DMA GEMM kernels (measurement aid, tools/gemm_phase_probe.py; the reference has only host
  * time.time() counters, pretrain_src/pretrain_src/train_r2r.py:227,299-317).  With a device buffer of
  * max_launches x 4096 x 8 uint64 installed, every following eager GEMM launch of <= 4096 workgroups records per workgroup

@@ -102,6 +102,63 @@ def test_native_communicator_decision_is_collective():
     assert all(none for _, none in res), res
 
 
+def _selftest_decision_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from etpnav_amd import _lib
+        log = []
+
+        class FakeComm(dp.NativeComm):                       # initialises fine everywhere; the self-test fails on rank 1 only
+            def __init__(self, device, comm_dtype=torch.float32, max_bucket_elems=0, group=None):
+                self.rank, self.world, self.handle = dist.get_rank(group), dist.get_world_size(group), None
+
+            def self_test(self, timeout_s=60.0):
+                log.append(("self_test", timeout_s))
+                return "collectives did not complete within 1 s" if self.rank == 1 else None
+
+            def abort(self):
+                log.append(("abort",))
+
+            def close(self):
+                log.append(("close",))
+
+        class FakeLib:
+            @staticmethod
+            def etp_allreduce_available():
+                return 1
+
+        real = _lib.lib
+        _lib.lib = lambda: FakeLib
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                comm = FakeComm.create(torch.device("cpu"), torch.float32, 1024)
+        finally:
+            _lib.lib = real
+        q.put((rank, comm is None, [e[0] for e in log], any("self-test failed" in str(x.message) for x in w)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_first_contact_self_test_disables_the_native_path_on_every_rank():
+    """The known-answer / deadline self-test of a freshly initialised communicator (NativeComm.self_test) fails on ONE rank:
+    every rank must abort its communicator and come back with None (-> torch.distributed collectives), the healthy rank too."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_selftest_decision_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, none, calls, warned in res:
+        assert none and warned, res
+        assert calls[:2] == ["self_test", "abort"], res
+
+
 def test_planner_bucket_ranges_cover_the_arena_once():
     from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
     m = GlocalTextPathNavCMT(default_config(vocab_size=1024), dtype=torch.float32, device="cpu")

@@ -89,6 +89,32 @@ def test_native_gather_rows_world1_restores_the_table(comm_dtype):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_native_communicator_first_contact_self_test_world1(comm_dtype):
+    """NativeComm.create runs the known-answer self-test (dense bucket with a tail + row-sparse exchange with a repeated id)
+    through the real RCCL communicator and polls it from the host; a communicator whose collectives do not drain within the
+    deadline is aborted (ncclCommAbort) and create() returns None."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = dp.NativeComm.create(torch.device("cuda", 0), comm_dtype, 4096)
+        assert comm is not None and comm.self_test(30.0) is None
+        assert comm.L.etp_allreduce_idle(comm.handle) == 1
+        comm._drain = lambda timeout_s: False                 # "never completes"
+        assert "did not complete" in comm.self_test(0.01)
+        comm.abort()
+        assert comm.handle is None
+        real = dp.NativeComm.self_test
+        dp.NativeComm.self_test = lambda self, timeout_s=60.0: "forced failure"
+        try:
+            with pytest.warns(UserWarning, match="self-test failed"):
+                assert dp.NativeComm.create(torch.device("cuda", 0), comm_dtype, 4096) is None
+        finally:
+            dp.NativeComm.self_test = real
+    finally:
+        dist.destroy_process_group()
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
