@@ -179,6 +179,65 @@ def test_two_rank_planner_step_mean_equals_full_batch_gradient():
         assert ok, f"rank {rank}: max err {err}"
 
 
+def _native_worker(rank, world, port, comm_dtype, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        n_rows, row_len = 300, 768
+        n_dense = 64 * 4000 + 37
+        n = (n_dense + 63) // 64 * 64 + n_rows * row_len
+        off = n - n_rows * row_len
+        grads, idsets = [], []
+        for r in range(world):                                   # every rank can rebuild all ranks' gradients
+            g = torch.Generator().manual_seed(100 + r)
+            x = torch.randn(n, generator=g)
+            ids_r = torch.tensor([3 + r, 7, 7, 20 + 2 * r, 299] + ([31, 7] if r == 1 else []))
+            table = x[off:].view(n_rows, row_len)
+            mask = torch.zeros(n_rows, dtype=torch.bool); mask[ids_r] = True
+            table[~mask] = 0
+            grads.append(x); idsets.append(ids_r)
+        mine = grads[rank].clone().cuda()
+        red = dp.GradReducer(mine, [(1024, n_dense), (0, 1024)], comm_dtype=comm_dtype, sparse_rows=(off, n_rows, row_len))
+        native = red.native is not None
+        seen = red.native.ranks_seen() if native else 0
+        red.reduce_bucket(0)
+        red.reduce_bucket(1)
+        red.reduce_sparse_rows(idsets[rank].cuda(), capacity=16)
+        red.finish()
+        torch.cuda.synchronize()
+        if comm_dtype == torch.float32:
+            expect, tol = sum(grads) / world, 1e-5
+        else:
+            expect, tol = sum(g.to(torch.bfloat16).float() for g in grads) / world, 5e-2
+        expect[n_dense:off] = grads[rank][n_dense:off]           # alignment gap between the buckets: not reduced
+        err = (mine.cpu() - expect).abs().max().item()
+        red.close()
+        q.put((rank, native, seen, err <= tol, err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_native_communicator_two_gpus_dense_and_row_sparse_mean(comm_dtype):
+    """the multi-rank path of etp_allreduce_* (in-place reduce-scatter -> scale -> all-gather, the all-reduce tail,
+    bf16 staging, gather_rows with ragged id counts) on TWO devices, one process per GPU over RCCL, against the analytic mean.
+    Skipped on one-GPU boxes; NativeComm.create's first-contact self-test covers the same collectives at start-up there."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, comm_dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, native, seen, ok, err in res:
+        assert native and seen == 2, res
+        assert ok, f"rank {rank}: max err {err}"
+
+
 def test_bench_self_launches_two_ranks_on_one_device():
     """`python bench.py --gpus 2` started WITHOUT torchrun must spawn its own ranks (VERDICT r2 missing #1; the reference's
     run script launches with torch.distributed.launch, run_r2r/main.bash:53).  Two ranks on one MI355X need the gloo backend
