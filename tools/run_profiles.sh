@@ -30,6 +30,9 @@ rm -rf $O/pmc_*/*kernel_trace* $O/pmc_*/p_counter_collection.csv
 # 4. per-kernel budget and the in-kernel phase probe
 $T python tools/chain_budget.py --seq > $O/chain_budget.txt 2>&1
 $T python tools/gemm_phase_probe.py > $O/gemm_phases.txt 2>&1
+# 4b. rollout episode: per-step calls vs text K/V cache vs one batched call
+$T python tools/rollout_bench.py > $O/rollout_bench.json 2> $O/rollout_bench.err
+$T python tools/rollout_bench.py --B 32 --T 5,15 > $O/rollout_bench_b32.json 2> $O/rollout_bench_b32.err
 # 5. parity + smoke on the same build
 timeout 1500 python -m pytest tests -m gpu -q --tb=short > $O/gpu_tests.log 2>&1; echo "rc tests $?"; tail -3 $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc smoke $?"; tail -2 $O/smoke.log
