@@ -854,7 +854,10 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
-    ETP_TRY(flush_side(c));          // this layer's four weight gradients: one fork
+    // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
+    // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work
+    static const int every = [] { const char* e = getenv("ETP_FLUSH_EVERY"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+    if (every == 1 || (layer_hi - 1 - l) % every == every - 1 || l == layer_lo) ETP_TRY(flush_side(c));
   }
   if (layer_lo == 0)
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
