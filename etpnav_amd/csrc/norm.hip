@@ -8,6 +8,7 @@
 // Both are HBM-bound row kernels: one 64-lane wavefront owns one row, statistics are reduced with
 // wave shuffles in fp32, I/O is 8/16-byte vectors per lane (coalesced 512 B / 1 KiB per wave instruction).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -305,9 +306,18 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
   }
 
 // yt / dxt: copy in the operand dtype `dtype` (ignored when NULL; pass NULL in fp32 mode where y itself is the operand)
+// MEASUREMENT ONLY (tools/r03_call19.sh): ETP_SKIP_LN names launches to drop -- "fwd" (ln_fwd_s), "bwd" (ln_bwd_s), "red"
+// (ln_part_reduce) -- so that the step time shows what fusing them away could buy at most (results are wrong in that mode),
+// like ETP_SKIP_WGRAD in planner.hip.
+static bool skip_ln(const char* what) {
+  static const char* e = getenv("ETP_SKIP_LN");
+  return e && strstr(e, what) != nullptr;
+}
+
 int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,
              float eps, hipStream_t st) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (y || yt), "bad arguments");
+  if (skip_ln("fwd")) return ETP_OK;
   const int grid = (int)std::min<long>((M + 3) / 4, 4096);
   if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_fwd_s_kernel, bf16_t, grid, x, gamma, beta, y, (bf16_t*)yt, stats, M, eps) }
   else { ETP_LN_DISPATCH(ln_fwd_s_kernel, float, grid, x, gamma, beta, y, (float*)yt, stats, M, eps) }
@@ -328,6 +338,7 @@ int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, con
              void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop, float* part) {
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (dx || dxt), "bad arguments");
   ETP_REQUIRE(drop.p == 0.f || (dxt != nullptr && dxt != (void*)dx), "dropout needs a separate operand copy");
+  if (skip_ln("bwd")) return ETP_OK;
   // without a slab buffer the blocks flush 2*H atomics each: keep their number low (128, the round-1 setting)
   const int grid = part ? ln_bwd_blocks(M) : (int)std::min<long>((M + 3) / 4, 128);
   if (dgamma == nullptr) part = nullptr;
@@ -338,6 +349,7 @@ int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, con
 }
 int ln_part_reduce(const float* part, int M, int H, float* dgamma, float* dbeta, hipStream_t st) {
   ETP_REQUIRE(part && dgamma && dbeta && M > 0 && H % 256 == 0, "bad arguments");
+  if (skip_ln("red")) return ETP_OK;
   const int nblk = ln_bwd_blocks(M);
   ETP_LAUNCH(ln_part_reduce_kernel, dim3((2 * H + 255) / 256, (nblk + LN_PART_CHUNK - 1) / LN_PART_CHUNK), dim3(256), 0, st, part, nblk, H,
              dgamma, dbeta);
