@@ -452,8 +452,16 @@ bool attn_rows_ok(int dt, const AttnBuf& a, long ldc) {
   return true;
 }
 
+// MEASUREMENT ONLY (tools/r03_call20.sh): ETP_SKIP_ATTN = "fwd" / "bwd" drops the launches so that the step time shows what
+// the attention kernels cost in the step (results are wrong in that mode); see ETP_SKIP_LN in norm.hip.
+static bool skip_attn(const char* what) {
+  static const char* e = getenv("ETP_SKIP_ATTN");
+  return e && strstr(e, what) != nullptr;
+}
+
 int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
   ETP_REQUIRE((uintptr_t)ctx % 16 == 0, "ctx must be 16-byte aligned");
+  if (skip_attn("fwd")) return ETP_OK;
   RowArgs k = make_row_args(nh, a, P, alpha, drop);
   k.ctx = (bf16_t*)ctx; k.ldc = ldc;
   const int nqt = (a.Lq + 15) / 16, nkt = (a.Lk + 15) / 16;
@@ -466,6 +474,7 @@ int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, lon
   ETP_REQUIRE(ldd % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 &&
                   ((uintptr_t)dctx | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) % 16 == 0,
               "gradient operands of the register-resident attention must be 16-byte aligned");
+  if (skip_attn("bwd")) return ETP_OK;
   RowArgs k = make_row_args(nh, a, const_cast<void*>(P), alpha, drop);
   k.dO = (const bf16_t*)dctx; k.ldd = ldd;
   k.dQ = (bf16_t*)dQ; k.dK = (bf16_t*)dK; k.dV = (bf16_t*)dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv;
