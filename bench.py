@@ -140,6 +140,11 @@ def main():
                     help="weak (default): every rank runs the full per-GPU batch of the workload (the reference's per-rank batch "
                          "semantics, pretrain_src/pretrain_src/data/loader.py:127-164); strong: the workload's batch is the GLOBAL "
                          "batch, split evenly over the ranks (SURVEY.md §8d C3: global 32 -> 4 per GPU at 8 GPUs)")
+    ap.add_argument("--dp-schedule", nargs="?", const="overlapped", default=None, choices=["overlapped", "joined"],
+                    help="single GPU only: issue the step the way the multi-rank path does (PlannerStep.run_data_parallel: "
+                         "text backward in layer groups, buckets announced in between) but without collectives -- what the "
+                         "data-parallel issue order itself costs against the free-running single-GPU schedule.  'overlapped' "
+                         "(library communicator) or 'joined' (torch.distributed collectives)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -218,23 +223,27 @@ def main():
             print(f"[bench] graph recording failed ({e}); falling back to eager issue", file=sys.stderr)
             use_graph = False
 
+    dp_groups = dp.planner_buckets_layered(model, text_groups=3)[2] if (args.dp_schedule and world == 1) else None
+    dp_overlapped = args.dp_schedule != "joined"
+
     def one_step():
+        if world == 1 and dp_groups is not None:
+            step.run_data_parallel(dp_groups, lambda i, side: None, overlapped=dp_overlapped)
+            return
         if world == 1:
             step.replay() if use_graph else step.run_eager()
             return
         if use_graph:
             step.replay(part=0)
-        else:
-            step.enqueue_main(model._engine.stream(), True, join_pano=True)
-        reducer.reduce_bucket(0)                                 # non-text matrices: overlaps the text backward
-        if use_graph:
+            reducer.reduce_bucket(0)
             step.replay(part=1)
             nxt = 1
         else:
-            # text backward in layer groups (last layers first); each group's gradients are reduced while the next runs
-            for k, (lo, hi) in enumerate(txt_groups):
-                step.enqueue_txt_bwd(model._engine.stream(), lo, hi)
-                reducer.reduce_bucket(1 + k)
+            # everything outside the text encoder first, then the text backward in layer groups (last layers first); each
+            # bucket's reduction starts as soon as its producers are enqueued and runs beside the rest of the backward.  With the
+            # library communicator the step keeps its free-running schedule (side streams are waited for by the communication
+            # stream, not by the chain); torch.distributed collectives get the joined order.
+            step.run_data_parallel(txt_groups, lambda i, side: reducer.reduce_bucket(i, also=side), overlapped=reducer.overlapped)
             nxt = 1 + len(txt_groups)
         for i in range(nxt, len(reducer.ranges)):
             reducer.reduce_bucket(i)

@@ -107,6 +107,13 @@ class NativeComm:
         self._lib.check(self.L.etp_allreduce_bucket_ready(self.handle, grads.data_ptr() + 4 * start, end - start,
                                                           torch.cuda.current_stream().cuda_stream), "allreduce_bucket_ready")
 
+    def after(self, streams: Sequence[int]):
+        """Order the communication stream after everything enqueued so far on the given raw stream handles."""
+        cs = self.L.etp_allreduce_stream(self.handle)
+        for st in streams:
+            if st:
+                self._lib.check(self.L.etp_stream_after(st, cs), "stream_after")
+
     def gather_rows(self, table: torch.Tensor, ids: torch.Tensor, capacity: int):
         """table [n_rows, row_len] fp32 view of the gradient arena; ids int64 on the device (this rank's touched rows)."""
         self._lib.check(self.L.etp_allreduce_gather_rows(self.handle, table.data_ptr(), table.shape[0], table.shape[1],
@@ -200,14 +207,26 @@ class GradReducer:
                       for s, e in self.ranges]
         self._pending: List = []
 
-    def reduce_bucket(self, i: int, async_op: bool = True):
-        """Start the mean-reduction of dense bucket i (call when its gradients are complete)."""
+    @property
+    def overlapped(self) -> bool:
+        """True when reduce_bucket can order the communication after SIDE streams (the library communicator owns its stream);
+        torch.distributed collectives only see the current stream, so their producers must be joined into it first."""
+        return self.native is not None
+
+    def reduce_bucket(self, i: int, async_op: bool = True, also: Sequence[int] = ()):
+        """Start the mean-reduction of dense bucket i (call when its gradients are complete in stream order).  `also`: raw
+        stream handles that hold producers of the bucket besides the current stream (weight-gradient / panorama streams of
+        PlannerStep.run_data_parallel); only the library communicator can wait for them without stalling the current stream."""
         if self.world == 1:
             return
         s, e = self.ranges[i]
         if self.native is not None:
+            self.native.after(also)
             self.native.bucket_ready(self.g, s, e)
             return
+        if also:
+            raise RuntimeError("torch.distributed collectives cannot wait for side streams: join them into the current stream "
+                               "(PlannerStep.run_data_parallel(overlapped=False))")
         view = self.g[s:e]
         if self.comm_dtype == torch.float32:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

@@ -45,6 +45,10 @@ def test_native_communicator_world1_in_place_mean(comm_dtype):
         g = torch.randn(n, device="cuda")
         ref = g.clone()
         comm = dp.NativeComm(g.device, comm_dtype, max_bucket_elems=n)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            g[:128].mul_(1.0)                                 # a producer on a side stream ...
+        comm.after([side.cuda_stream, 0])                     # ... the communication stream is ordered after it (0 = absent stream)
         comm.bucket_ready(g, 128, n)                          # a sub-range, as the arena buckets are
         comm.wait()
         torch.cuda.synchronize()

@@ -11,6 +11,8 @@ bound the reference itself shows between its bf16-autocast and fp32 runs (SURVEY
 on the fixture samples, 5 % on its L2 norm, and on full tensors relative L2 error <= 12 % with cosine >= 0.99
 (tests/golden_util.py: compare_grads_bf16 / compare_full_bf16; tests/test_bf16_bounds_cpu.py shows the bounds can fail).
 """
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -162,6 +164,57 @@ def test_text_backward_in_layer_ranges_equals_single_call():
     torch.cuda.synchronize()
     bad = schedule_mismatches(model, ref, rel=2e-5)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("overlapped", [True, False])
+@pytest.mark.parametrize("B,L", [(3, 24), (32, 80)])
+def test_data_parallel_issue_order_gives_the_single_gpu_gradients(overlapped, B, L):
+    """PlannerStep.run_data_parallel (what bench.py's multi-rank path issues): text backward in layer groups with the bucket
+    callbacks in between, free-running (side streams handed to the reducer) or joined -- after the last group everything is
+    joined, and every gradient equals the plain step's.  The callbacks see bucket 0 (non-text) and one bucket per group, and in
+    the overlapped form the side streams that hold their producers; a consumer that waits for exactly those streams (as
+    dp.NativeComm.after does for the communication stream) must see complete gradients for the announced bucket."""
+    from etpnav_amd import dp, _lib
+    cfg = po.PlannerConfig.r2r(vocab_size=4096)
+    P = po.init_params(cfg, seed=2)
+    batch = po.make_batch(cfg, B=B, L=L, V=14 if B == 3 else 36, G=8 if B == 3 else 16, seed=5, ragged=True)
+    model = build_model(cfg, P, torch.bfloat16)
+    step = PlannerStep(model, batch)
+    step.run_eager(); torch.cuda.synchronize()
+    ref = model.flat_grads.clone()
+    ranges, sparse, groups = dp.planner_buckets_layered(model, text_groups=3)
+    Lb = _lib.lib()
+    watcher = ctypes.c_void_p()
+    _lib.check(Lb.etp_stream_create(ctypes.byref(watcher)), "stream_create")
+    s = model._engine.stream()
+    seen, snaps = [], []
+
+    def bucket_ready(i, side):
+        seen.append((i, tuple(side)))
+        # a consumer stream ordered after the main stream and the announced side streams copies the bucket: what a
+        # communication stream would read
+        for st in (s,) + tuple(side):
+            _lib.check(Lb.etp_stream_after(st, watcher.value), "stream_after")
+        lo, hi = ranges[i]
+        snap = torch.empty(hi - lo, device="cuda")
+        with torch.cuda.stream(torch.cuda.ExternalStream(watcher.value)):
+            snap.copy_(model.flat_grads[lo:hi], non_blocking=True)
+        snaps.append((i, snap))
+
+    for rep in range(2):
+        seen.clear(); snaps.clear()
+        step.run_data_parallel(groups, bucket_ready, stream=s, overlapped=overlapped)
+        torch.cuda.synchronize()
+        assert [i for i, _ in seen] == [0, 1, 2, 3]
+        assert all((len(side) > 0) == overlapped for _, side in seen)
+        bad = schedule_mismatches(model, ref, rel=2e-5)
+        assert not bad, bad
+        for i, snap in snaps:                       # the bucket was complete when its consumer read it
+            lo, hi = ranges[i]
+            d = (snap - ref[lo:hi]).abs().max().item()
+            assert d <= 2e-5 * max(1.0, ref[lo:hi].abs().max().item()), (rep, i, d)
+    _lib.check(Lb.etp_stream_destroy(watcher), "stream_destroy")
+    step.close()
 
 
 @pytest.mark.parametrize("dtype,rel", [(torch.float32, 2e-5), (torch.bfloat16, 2e-4)])
