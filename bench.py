@@ -145,6 +145,10 @@ def main():
                          "text backward in layer groups, buckets announced in between) but without collectives -- what the "
                          "data-parallel issue order itself costs against the free-running single-GPU schedule.  'overlapped' "
                          "(library communicator) or 'joined' (torch.distributed collectives)")
+    ap.add_argument("--text-groups", type=int, default=9,
+                    help="data-parallel path: the text encoder's weight gradients are reduced in this many layer groups (last "
+                         "layers first), each as soon as its backward is enqueued (9 = one ~28 MB bucket per layer, DDP's bucket size class; the count "
+                         "costs the chain nothing: 3 / 5 / 9 groups all run at 4.29-4.31 ms on one GPU, profiles/r03_ab_runs.json c25)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -206,7 +210,7 @@ def main():
                            dropout="config" if args.mode == "train" else None, drop_seed=rank)
     reducer, ranks_seen, comm_kind = None, 1, None
     if world > 1:
-        ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=3)
+        ranges, sparse, txt_groups = dp.planner_buckets_layered(model, text_groups=args.text_groups)
         reducer = dp.GradReducer(model.flat_grads, ranges,
                                  comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32,
                                  sparse_rows=sparse)
@@ -223,7 +227,7 @@ def main():
             print(f"[bench] graph recording failed ({e}); falling back to eager issue", file=sys.stderr)
             use_graph = False
 
-    dp_groups = dp.planner_buckets_layered(model, text_groups=3)[2] if (args.dp_schedule and world == 1) else None
+    dp_groups = dp.planner_buckets_layered(model, text_groups=args.text_groups)[2] if (args.dp_schedule and world == 1) else None
     dp_overlapped = args.dp_schedule != "joined"
 
     def one_step():
