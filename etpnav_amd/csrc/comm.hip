@@ -174,6 +174,7 @@ etp_stream_t etp_allreduce_stream(const etp_comm* c) { return c ? (etp_stream_t)
 // grads[0, n) <- mean over ranks, in place.  Everything enqueued on `producer` so far completes before the bucket is read.
 int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_t producer) {
   ETP_REQUIRE(c && grads && n >= 0 && ((uintptr_t)grads % 16 == 0), "bad arguments");
+  ETP_REQUIRE(c->comm, "communicator was aborted (only etp_allreduce_destroy is valid now)");
   if (n == 0) return ETP_OK;
   hipStream_t prod = (hipStream_t)producer, cs = c->stream;
   hipEvent_t e = c->next_event();
@@ -217,6 +218,7 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
                               int64_t capacity, etp_stream_t producer) {
   ETP_REQUIRE(c && table && n_rows > 0 && row_len > 0 && capacity > 0 && n_ids >= 0 && n_ids <= capacity && (ids || n_ids == 0),
               "bad arguments (n_ids must not exceed the rank-independent capacity)");
+  ETP_REQUIRE(c->comm, "communicator was aborted (only etp_allreduce_destroy is valid now)");
   const int W = c->world;
   const size_t rs = c->comm_dtype == ETP_BF16 ? 2 : 4;
   if (c->rows_cap < capacity || c->rows_len != row_len) {          // (re)allocate the staging blocks: first call / larger batch
