@@ -23,6 +23,21 @@ using namespace etp;
 
 struct etp_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
+// etp_stamp: the stream's arrival time at this point, taken on the device (no host event, no profiler)
+__global__ void stamp_kernel(unsigned long long* slot) {
+  if (threadIdx.x == 0) *slot = __builtin_amdgcn_s_memrealtime();
+}
+namespace etp {
+static unsigned long long* g_stamp_buf = nullptr;
+static long g_stamp_cap = 0;
+static std::vector<int> g_stamp_tags;
+void stamp_mark(hipStream_t st, int tag) {
+  if (!g_stamp_buf || rec_active() || (long)g_stamp_tags.size() >= g_stamp_cap) return;
+  ETP_LAUNCH(stamp_kernel, dim3(1), dim3(64), 0, st, g_stamp_buf + g_stamp_tags.size());
+  g_stamp_tags.push_back(tag);
+}
+}  // namespace etp
+
 extern "C" {
 
 const char* etp_version(void) { return "etpnav_hip 0.1.0 (gfx950)"; }
@@ -331,6 +346,22 @@ int etp_prof_filter(const char* name_part) { prof_filter(name_part); return ETP_
 int etp_prof_report(etp_prof_entry* out, int cap) {
   if (!out || cap <= 0) return 0;
   return prof_report(out, cap);
+}
+int etp_stamp_sink(uint64_t* dev_buf, int64_t cap) {
+  ETP_REQUIRE(dev_buf == nullptr || cap > 0, "cap must be positive");
+  g_stamp_buf = reinterpret_cast<unsigned long long*>(dev_buf);
+  g_stamp_cap = dev_buf ? (long)cap : 0;
+  g_stamp_tags.clear();
+  return ETP_OK;
+}
+int64_t etp_stamp_count(void) { return (int64_t)g_stamp_tags.size(); }
+int etp_stamp_tag(int64_t i) { return (i >= 0 && i < (int64_t)g_stamp_tags.size()) ? g_stamp_tags[(size_t)i] : -1; }
+int etp_stamp_mark(etp_stream_t s, int tag) { stamp_mark((hipStream_t)s, tag); return ETP_OK; }
+int etp_stamp(uint64_t* slot, etp_stream_t s) {
+  ETP_REQUIRE(slot, "null pointer");
+  ETP_LAUNCH(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, reinterpret_cast<unsigned long long*>(slot));
+  ETP_CHECK_LAUNCH("stamp");
+  return ETP_OK;
 }
 
 }  // extern "C"

@@ -183,5 +183,8 @@ void prof_enable(bool on);
 void prof_filter(const char* name_part);
 void prof_reset();
 int prof_report(etp_prof_entry* out, int cap);
+// capi.hip: with a stamp sink installed (etp_stamp_sink), records the stream's device-side arrival time at this point of the
+// planner's issue order under `tag`; a no-op otherwise (tools/chain_waits.py)
+void stamp_mark(hipStream_t st, int tag);
 
 }  // namespace etp

@@ -815,6 +815,7 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
                          lp(t.x0, c.dt), t.st0, B, L, H, eps, c.st, hid(c, MODE_TXT, 0, SITE_EMBED)));
   Act x = t.x0;
   for (int l = 0; l < p->cfg.n_l; ++l) {
+    stamp_mark(c.st, 1000 + l);
     ETP_TRY(self_att_fwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, eps, MODE_TXT, l));
     if (l == p->cfg.n_l - 1) t.ffn[l].y.f = out;      // the last LayerNorm writes the API tensor itself (backward never reads it)
     ETP_TRY(ffn_fwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, eps, MODE_TXT, l));
@@ -825,6 +826,7 @@ int etp_txt_fwd(etp_planner* p, const int64_t* ids, const uint8_t* mask, int B, 
     }
   }
   if (p->cfg.n_l == 0) ETP_TRY(copy_f32(x.f, out, (long)M * H, c.st));
+  stamp_mark(c.st, 1099);
   return ETP_OK;
 }
 
@@ -851,8 +853,10 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     BwdWs wf = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);   // same carving in every call
     BwdWs wa = plan_ws(wb, c.dt, M, B, c.nh, L, (int)round_up(L, 8), H, c.I);
     if (l >= layer_hi || l < layer_lo) continue;
+    stamp_mark(c.st, 2200 + 10 * l);
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
+    stamp_mark(c.st, 2200 + 10 * l + 1);
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
     // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work
@@ -863,6 +867,7 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
                            p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st,
                            hid(c, MODE_TXT, 0, SITE_EMBED)));
+  stamp_mark(c.st, 2299);
   // a range that stops above layer 0 is followed by another one: with lazy level 2 its weight gradients keep running on the
   // side stream (the final range, or etp_planner_join_aux, joins them)
   if (p->lazy_join >= 2 && layer_lo > 0) return flush_side(c);
@@ -984,6 +989,7 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
   PanoStash s = plan_pano(p, b, B, V);
   const etp_config& cf = p->cfg;
   const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
+  stamp_mark(c.st, 1100);
   ETP_LAUNCH(seq_mask_kernel, dim3((M + 255) / 256), dim3(256), 0, c.st, view_lens, s.mask, out_mask, B, V);
   ETP_CHECK_LAUNCH("seq_mask");
   const void* rgbT = rgb; const void* depT = dep;
@@ -1017,6 +1023,7 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
     x = t.x2;
   }
   if (cf.n_p > 0) ETP_TRY(ln_fwd_s(c.dt, x, p->pf(p->pn_g), p->pf(p->pn_b), out, nullptr, s.stn, M, H, 1e-12f, c.st));
+  stamp_mark(c.st, 1199);
   return ETP_OK;
 }
 
@@ -1034,6 +1041,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   const int H = c.H, I = c.I, M = B * V, ldS = (int)round_up(V, 8);
   Bump wb(ws);
   PanoWs w0 = plan_pano_ws(wb, c.dt, M, B, c.nh, V, ldS, H, I);
+  stamp_mark(c.st, 2100);
   Act g = w0.g;
   Drop gd = drop_none();
   if (cf.n_p > 0) {
@@ -1085,6 +1093,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
   ETP_TRY(linear_wgrad(c, w.t1, H, rgbT, cf.img_feat, p->img_w, p->img_b, M, H, cf.img_feat));
   if (cf.use_depth) ETP_TRY(linear_wgrad(c, w.dI, H, depT, cf.dep_feat, p->dep_w, p->dep_b, M, H, cf.dep_feat));
   if (d_rgb) ETP_TRY(linear_dgrad_s(c, w.t1, H, p->img_w, d_rgb, M, H, cf.img_feat, nullptr, 0, denv));
+  stamp_mark(c.st, 2199);
   return finish_wgrads(c);
 }
 
@@ -1279,6 +1288,7 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
   for (int l = 0; l < cf.n_x; ++l) {   // GraphLXRTXLayer.forward vilmodel_cmt.py:383-398
     const XLayerP& q = p->xl[l];
     XStash& t = s.layers[l];
+    stamp_mark(c.st, 1200 + l);
     // cross attention nodes -> text (BertXAttention :360-363)
     ETP_TRY(linear_fwd(c, x.t, H, q.q_w, q.q_b, t.cross.q, H, Mg, H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     if (kv_side) ETP_CHECK_HIP(stream_wait_event(c.st, kv_ready[l]));
@@ -1303,8 +1313,10 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
   if (cf.n_x == 0 || c.dt != ETP_BF16) ETP_TRY(copy_f32(x.f, out_embeds, (long)Mg * H, c.st));
   // SAP head: Linear -> ReLU (GEMM epilogue) -> LN -> Linear(H->1) -> masks
   ETP_TRY(linear_fwd(c, x.t, H, p->sap0_w, p->sap0_b, s.r, H, Mg, H, H, ETP_ACT_RELU, nullptr, nullptr, 0));
-  return sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
-                      out_logits, s.str, Mg, H, c.st, site(c, p->p_head, MODE_NAV, 0, SITE_HEAD));
+  ETP_TRY(sap_tail_fwd(c.dt, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), p->pf(p->sap4_b), visited, gmask,
+                       out_logits, s.str, Mg, H, c.st, site(c, p->p_head, MODE_NAV, 0, SITE_HEAD)));
+  stamp_mark(c.st, 1299);
+  return ETP_OK;
 }
 }  // namespace
 extern "C" {
@@ -1353,6 +1365,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
   if (cached) kc = plan_kv(p, const_cast<void*>(kvbuf), B, L);
   const Act xlast = cf.n_x == 0 ? s.x0 : s.layers[cf.n_x - 1].ffn.y;
   float* g = n.g;
+  stamp_mark(c.st, 2000);
   if (d_logits) {
     ETP_TRY(sap_tail_bwd(c.dt, d_logits, s.r, p->pf(p->sap2_g), p->pf(p->sap2_b), p->pf(p->sap4_w), s.str, visited, gmask,
                          n.head.t2, p->gf(p->sap2_g), p->gf(p->sap2_b), p->gf(p->sap4_w), p->gf(p->sap4_b), Mg, H, c.st,
@@ -1369,6 +1382,7 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     const Act x = l == 0 ? s.x0 : s.layers[l - 1].ffn.y;
     const NavCrossWs& xc = n.cross[l];
     const BwdWs& w = xc.w;
+    stamp_mark(c.st, 2010 + 10 * l);
     ETP_TRY(ffn_bwd(c, q.ffn, t.self.y, t.ffn, Mg, g, n.ffn[l], MODE_NAV, l));
     ETP_TRY(self_att_bwd(c, q.self, t.cross.y, t.self, B, G, gmask, cf.use_sprels ? dists : nullptr, spw, spb, dspw, dspb, g,
                          n.self[l], MODE_NAV, l));
@@ -1403,7 +1417,9 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(flush_side(c));          // this layer's weight gradients: one fork
   }
   if (cf.n_x == 0) ETP_TRY(copy_f32(g, d_img, (long)Mg * H, c.st));
+  stamp_mark(c.st, 2090);
   if (!cached && c.s3 != c.st) ETP_TRY(stream_after(p, c.s3, c.st));      // d_txt complete in `stream` order
+  stamp_mark(c.st, 2091);
   ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
                          p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
                          cf.ang_feat + 3, c.st));

@@ -232,6 +232,7 @@ class PlannerStep:
         self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
+        L.etp_stamp_mark(s, 1)                 # measurement aid: a no-op unless a stamp sink is installed (tools/chain_waits.py)
         # weight-shadow refresh and gradient zeroing ride on the stream that first needs them: the text cast on the main
         # stream, the panorama/navigation casts and the (bandwidth-bound) gradient memset on the panorama stream, whose
         # join below precedes forward_navigation and every backward kernel
@@ -257,12 +258,14 @@ class PlannerStep:
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
         check(L.etp_stream_after(s2, s), "join")
         pf, xf, wf = self.csr_f
+        L.etp_stamp_mark(s, 2)
         check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
         check(L.etp_nav_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
                             ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.gemb), ptr(self.logits),
                             ptr(self.st_nav), s), "nav_fwd")
         check(L.etp_sap_ce(ptr(self.logits), ptr(i["labels"]), ptr(self.loss), ptr(self.dlogits) if backward else None, B, G,
                            self.loss_scale, -100, s), "sap_ce")
+        L.etp_stamp_mark(s, 3)
         check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")     # the mode never leaks to other users of the planner
 
     def enqueue_bwd_main(self, s: int, join_pano: bool = True, defer_pano: bool = False):
@@ -278,8 +281,10 @@ class PlannerStep:
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
         pb, xb, wb = self.csr_b
+        L.etp_stamp_mark(s, 4)
         check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s),
               "node assembly bwd")
+        L.etp_stamp_mark(s, 5)
         if defer_pano:             # the caller enqueues the panorama backward later (run_eager: after the first text layers);
             check(L.etp_stream_after(s, s2), "fork")             # its stream is ordered after d_pano's producer already now
             check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
@@ -302,6 +307,7 @@ class PlannerStep:
         self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(eng.handle, int(self.grad_overwrite)), "set_grad_overwrite")
+        L.etp_stamp_mark(s, 6)
         check(L.etp_txt_bwd_range(eng.handle, ptr(self.d_txt), ptr(i["txt_ids"]), ptr(i["txt_masks"]), self.B, self.Lt,
                                   ptr(self.st_txt), ptr(self.ws_txt), layer_lo, layer_hi, s), "txt_bwd")
         check(L.etp_planner_set_grad_overwrite(eng.handle, 0), "set_grad_overwrite")
@@ -310,6 +316,7 @@ class PlannerStep:
         if self._pano_pending:
             check(L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
             self._pano_pending = False
+        L.etp_stamp_mark(s, 7)
 
     def _drop_state(self):
         if self.dropout is None:

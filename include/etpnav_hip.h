@@ -494,6 +494,17 @@ int etp_gemm_probe_enable(uint64_t* dev_buf, int64_t max_launches);
 int64_t etp_gemm_probe_count(void);
 int etp_gemm_probe_meta(int64_t i, char* name, int cap, int32_t* dims);
 int etp_prof_report(etp_prof_entry* out, int cap);
+/* Device-side time stamp (measurement aid, tools/chain_waits.py): a one-thread kernel on `stream` stores s_memrealtime (100 MHz,
+ * chip-wide) into *slot when the stream reaches it -- the un-profiled view of where a stream waits (the reference's single
+ * backward, ss_trainer_ETP.py:504, has no joins of its own: every wait found is ours). */
+int etp_stamp(uint64_t* slot, etp_stream_t stream);
+/* Stamp sink: with a device buffer of `cap` uint64 installed, the planner entry points (and etp_stamp_mark, for the caller's own
+ * points) append one such stamp per marked point of their issue order -- text / navigation / panorama layer boundaries, forks and
+ * joins -- in enqueue order; etp_stamp_tag(i) names stamp i (tags: tools/chain_waits.py).  dev_buf == NULL removes the sink. */
+int etp_stamp_sink(uint64_t* dev_buf, int64_t cap);
+int64_t etp_stamp_count(void);
+int etp_stamp_tag(int64_t i);
+int etp_stamp_mark(etp_stream_t stream, int tag);
 
 #ifdef __cplusplus
 }
