@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("ksplit", ctypes.c_int32), ("alpha", ctypes.c_float),
                 ("bias", ctypes.c_void_p), ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64),
                 ("Z", ctypes.c_void_p), ("ldz", ctypes.c_int64),
-                ("act", ctypes.c_int32), ("out_mode", ctypes.c_int32)]
+                ("act", ctypes.c_int32), ("out_mode", ctypes.c_int32), ("a_colsum", ctypes.c_void_p)]
 
 
 class AttnDesc(ctypes.Structure):

@@ -204,9 +204,12 @@ __global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
   for (int n = 0; n < NKT; ++n) {
     float p[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[r] = s[n][r] * inv;
-      if (dropping) p[r] *= drop_mult(a.drop.seed, rbase + 16 * n + 4 * g + r, a.drop.p, a.drop.inv_keep);
+    for (int r = 0; r < 4; ++r) p[r] = s[n][r] * inv;
+    if (dropping) {
+      float dm[4];
+      drop_mult_run<4>(a.drop.seed, rbase + 16 * n + 4 * g, a.drop.p, a.drop.inv_keep, dm);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] *= dm[r];
     }
     pb[n] = pack4(p[0], p[1], p[2], p[3]);
   }

@@ -55,6 +55,7 @@ static int desc_to_args(const etp_gemm_desc* d, GemmArgs& g) {
   g.ksplit = d->ksplit > 0 ? d->ksplit : 1;
   g.alpha = d->alpha; g.bias = d->bias; g.R = d->R; g.ldr = d->ldr; g.Z = d->Z; g.ldz = d->ldz; g.act = d->act;
   g.out_mode = d->out_mode;
+  g.a_colsum = d->a_colsum;
   return ETP_OK;
 }
 int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream) {

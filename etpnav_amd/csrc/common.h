@@ -102,9 +102,45 @@ __host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t i
   x += seed * 0x27D4EB2Fu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
   return x;
 }
+// Per-element mask bits (round 4): ONE 32-bit avalanche per PAIR of consecutive elements, 16 bits each -- the epilogues hash
+// every element of every hidden / attention-probability tensor of a step (~130 M per step), and the five 32-bit multiplies of
+// drop_hash (quarter rate on CDNA) were a third of an fp32-stream GEMM epilogue.  keep <=> 16 bits >= round(p * 65536)
+// (p = 0.1 -> 6554 / 65536 = 0.100006).  drop_hash stays the site-seed mixer (host side, once per site).
+__host__ __device__ __forceinline__ uint32_t drop_pair(uint32_t seed, uint32_t pair) {
+  uint32_t x = pair * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 // multiplier of element idx under dropout probability p: 0 (dropped) or 1/(1-p)
 __host__ __device__ __forceinline__ float drop_mult(uint32_t seed, uint32_t idx, float p, float inv_keep) {
-  return ((drop_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+  const uint32_t w = drop_pair(seed, idx >> 1);
+  const uint32_t h = (idx & 1u) ? (w >> 16) : (w & 0xFFFFu);
+  return h >= drop_thr(p) ? inv_keep : 0.f;
+}
+// the same for N consecutive elements idx0 .. idx0 + N - 1 (N even): N / 2 avalanches when idx0 is even (every tensor of the
+// planner has an even row length and the kernels walk rows in chunks of 4 or 8), N / 2 + 1 otherwise
+template <int N>
+__host__ __device__ __forceinline__ void drop_mult_run(uint32_t seed, uint32_t idx0, float p, float inv_keep, float (&m)[N]) {
+  static_assert(N % 2 == 0, "runs of an even number of elements");
+  const uint32_t thr = drop_thr(p), q0 = idx0 >> 1;
+  if ((idx0 & 1u) == 0u) {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      const uint32_t w = drop_pair(seed, q0 + j);
+      m[2 * j] = (w & 0xFFFFu) >= thr ? inv_keep : 0.f;
+      m[2 * j + 1] = (w >> 16) >= thr ? inv_keep : 0.f;
+    }
+  } else {
+    uint32_t w = drop_pair(seed, q0);
+    m[0] = (w >> 16) >= thr ? inv_keep : 0.f;
+#pragma unroll
+    for (int j = 1; j <= N / 2; ++j) {
+      w = drop_pair(seed, q0 + j);
+      m[2 * j - 1] = (w & 0xFFFFu) >= thr ? inv_keep : 0.f;
+      if (2 * j < N) m[2 * j] = (w >> 16) >= thr ? inv_keep : 0.f;
+    }
+  }
 }
 struct Drop {                          // dropout of one site; p == 0 -> identity
   float p, inv_keep; uint32_t seed;

@@ -126,10 +126,12 @@ template <int NCH> __device__ __forceinline__ void block_flush(float* scratch, c
 template <int NCH> __device__ __forceinline__ void row_dropout(Row<NCH>& x, const Drop& d, int row, int lane) {
   if (d.p > 0.f) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int c = 0; c < NCH; ++c) {
+      float dm[4];
+      drop_mult_run<4>(d.seed, (uint32_t)row * (NCH * 256) + c * 256 + lane * 4, d.p, d.inv_keep, dm);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        x.v[c][e] *= drop_mult(d.seed, (uint32_t)row * (NCH * 256) + c * 256 + lane * 4 + e, d.p, d.inv_keep);
+      for (int e = 0; e < 4; ++e) x.v[c][e] *= dm[e];
+    }
   }
 }
 template <int NCH> __device__ __forceinline__ void global_acc(float* dst, const Row<NCH>& a, int lane) {
@@ -720,8 +722,10 @@ __global__ __launch_bounds__(256) void cast_drop_kernel(const float* __restrict_
     float v[4];
     load4(src + i, v);
     if (drop.p > 0.f) {
+      float dm[4];
+      drop_mult_run<4>(drop.seed, (uint32_t)i, drop.p, drop.inv_keep, dm);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= drop_mult(drop.seed, (uint32_t)(i + e), drop.p, drop.inv_keep);
+      for (int e = 0; e < 4; ++e) v[e] *= dm[e];
     }
     store4(dst + i, v);
   }

@@ -1,0 +1,542 @@
+// bf16 GEMM tiles on v_mfma_f32_32x32x16_bf16 with an ORDER-PINNED main loop (gfx950 / CDNA4).
+//
+//   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )      same operand storage classes as gemm.hip (NT, NN, TN)
+//
+// Reference sites: every nn.Linear of vlnce_baselines/models/etp/vilmodel_cmt.py:108-110,151,178,190,326-328 (forward, dgrad and
+// weight gradient of the M = B*L text products and the panorama / navigation products whose extents are multiples of the tile).
+//
+// Why a second family (round 4).  The ISA hipcc produced for gemm.hip's software-pipelined loop put the fragment reads of the
+// NEXT k-step behind 12 of the 16 MFMAs of the current one (register pressure at 128 VGPRs: 64 accumulators + two 32-register
+// fragment sets do not fit, so the allocator recycled fragment registers and the scheduler followed) and waited for them at the
+// top of the next step: the LDS latency was exposed once per k-step and the MFMA pipe issued at half rate with no DMA at all
+// (VERDICT r3 weak #6).  Here:
+//   * 32x32x16 MFMAs: a 64x64 wavefront tile needs 2 + 2 fragments (16 registers) per k16-step instead of 4 + 4 (32) per
+//     k32-step, so two complete fragment sets are resident beside the 64 accumulators inside the 128-register budget of two
+//     workgroups per CU -- every fragment read is issued a full k-step (4 MFMAs, 128 matrix-pipe cycles) before its use;
+//   * the issue order is written down, not left to the scheduler: every LDS read, MFMA and LDS-DMA piece of the loop is followed
+//     by __builtin_amdgcn_sched_barrier(0); reads alternate with MFMAs, the slab hand-over (counted vmcnt, lgkmcnt(0), s_barrier)
+//     sits in the MIDDLE of a k-step's MFMAs, and the DMA pieces of the next ring slot are spread one per MFMA over the
+//     following MFMAs instead of being issued as one burst in front of them;
+//   * LDS-DMA in SADDR form (global_load_lds_dwordx4 voffset, s[base]): one 32-bit VGPR offset per operand and wave, the
+//     per-piece and per-slab strides live in SGPRs (no 64-bit VALU pointer arithmetic in the loop);
+//   * row operands [row][128 B] with the 16-byte chunk swizzle  chunk ^= (row >> 1) & 7  (conflict-free for the 32-row
+//     fragments' ds_read_b128 lane groups), transposed operands [k][rows] with  chunk ^= (k & 3) << 2  (128-row tiles) or
+//     ((k >> 1) & 1) << 2  (64-row tiles): the four k-rows one ds_read_b64_tr_b16 lane group touches land on disjoint bank
+//     ranges.  Both swizzles are applied to the DMA source address and the fragment read address (same involution).
+// Only whole tiles: M % BM == 0, N % BN == 0, K % 64 == 0, K >= 128, unbatched, unsplit -- everything else stays on gemm.hip.
+// The fused epilogue (bias, erf-GELU and its backward, ReLU, dropout, residual, accumulate) is the shared one (gemm_shared.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include "gemm_shared.h"
+
+namespace etp {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) const u32x4_t* lds_u4_t;
+typedef short4_t __attribute__((address_space(3))) * lds_s4_t;
+
+#define ETP_SB() __builtin_amdgcn_sched_barrier(0)
+
+namespace mm32 {
+
+// ---- geometry of one operand slab (ROWS rows of the tile x 64 k) in LDS ------------------------------------------------
+template <bool TR, int ROWS> struct Op {
+  static constexpr int BYTES = ROWS * 128;
+  static constexpr int PITCH = TR ? ROWS * 2 : 128;       // bytes per LDS row ([row][64 k] or [k][ROWS])
+  static constexpr int NPW = ROWS / 32;                   // 1-KiB DMA pieces per wavefront per slab (4 wavefronts)
+};
+
+// Per-operand DMA plan of one wavefront: piece j (0 .. NPW-1) of the slab that starts at k0 is
+//   LDS  : slab base + (4 j + wave) * 1024 + lane * 16          (lane-linear)
+//   HBM  : sbase + j * piece_stride + voff                       (SADDR form; sbase advances by slab_stride per slab)
+struct DmaOp {
+  const char* sbase;
+  long piece_stride, slab_stride;
+  unsigned voff;
+};
+
+template <bool TR, int ROWS>
+__device__ __forceinline__ DmaOp dma_setup(const bf16_t* base, long ld, int row0, int k0, int wave, int lane) {
+  DmaOp d;
+  if constexpr (!TR) {
+    // piece p = 4j + wave holds tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical chunk lane & 7
+    const int lr = 8 * wave + (lane >> 3);
+    const int c = (lane & 7) ^ ((lr >> 1) & 7);                              // logical chunk stored at this position
+    d.voff = (unsigned)(((long)lr * ld + c * 8) * 2);
+    d.sbase = reinterpret_cast<const char*>(base + (long)row0 * ld + k0);
+    d.piece_stride = 32 * ld * 2;
+    d.slab_stride = 128;
+  } else if constexpr (ROWS == 128) {
+    // [k][256 B]: piece p holds k-rows 4p .. 4p+3; lane -> k-row 4p + (lane >> 4), physical chunk lane & 15
+    const int kr = 4 * wave + (lane >> 4);
+    const int cc = (lane & 15) ^ ((kr & 3) << 2);
+    d.voff = (unsigned)(((long)kr * ld + cc * 8) * 2);
+    d.sbase = reinterpret_cast<const char*>(base + (long)k0 * ld + row0);
+    d.piece_stride = 16 * ld * 2;
+    d.slab_stride = 64 * ld * 2;
+  } else {
+    static_assert(ROWS == 64, "transposed operand tiles are 64 or 128 rows");
+    // [k][128 B]: piece p holds k-rows 8p .. 8p+7; lane -> k-row 8p + (lane >> 3), physical chunk lane & 7
+    const int kr = 8 * wave + (lane >> 3);
+    const int cc = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+    d.voff = (unsigned)(((long)kr * ld + cc * 8) * 2);
+    d.sbase = reinterpret_cast<const char*>(base + (long)k0 * ld + row0);
+    d.piece_stride = 32 * ld * 2;
+    d.slab_stride = 64 * ld * 2;
+  }
+  return d;
+}
+
+// One LDS-DMA piece (1 KiB).  Inline asm on purpose: with the builtin hipcc drains the DMA (vmcnt(0)) before the next LDS
+// read; hidden here it stays in flight and is retired by our own counted s_waitcnt vmcnt + s_barrier.  M0 (LDS byte address of
+// the piece, wave-uniform) is written in the statement that consumes it.
+__device__ __forceinline__ void glds(unsigned voff, const char* sbase, unsigned lds_addr) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Fragment read addresses of one wavefront (byte offsets inside the operand slab; the slab base is added per slab).
+//   row operand  : rel  -> fragment f at rel + f * 4096, k16-step ks at  (.. ) ^ (ks << 5)
+//   trans operand: rel  -> fragment f at rel ^ (f << 6), k16-step ks at + ks * 16 * PITCH, upper four k at + 4 * PITCH
+template <bool TR, int ROWS>
+__device__ __forceinline__ unsigned frag_rel(int base_rc /*first row (col) of the wavefront's sub-tile*/, int lane) {
+  using G = Op<TR, ROWS>;
+  if constexpr (!TR) {
+    const int r = lane & 31;
+    const int swz = (r >> 1) & 7;                      // base_rc is a multiple of 32: the swizzle depends on the lane only
+    return (unsigned)((base_rc + r) * 128 + (((lane >> 5) ^ swz) << 4));
+  } else {
+    const int q = lane >> 4, i = lane & 15;
+    const int kr = 8 * (q >> 1) + (i >> 2);
+    const int col = base_rc + 16 * (q & 1) + 4 * (i & 3);
+    const int swz = ROWS == 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
+    return (unsigned)(kr * G::PITCH + (((col >> 3) ^ swz) << 4) + (col & 7) * 2);
+  }
+}
+template <bool TR, int ROWS>
+__device__ __forceinline__ bf16x8_t frag_ld(unsigned slab_addr /*LDS byte address of the operand slab + rel*/, int f, int ks) {
+  using G = Op<TR, ROWS>;
+  if constexpr (!TR) {
+    const unsigned a = (slab_addr ^ (unsigned)(ks << 5)) + (unsigned)(f * 4096);
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<lds_u4_t>(a));
+  } else {
+    const unsigned a = (slab_addr ^ (unsigned)(f << 6)) + (unsigned)(ks * 16 * G::PITCH);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s4_t>(a));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s4_t>(a + 4 * G::PITCH));
+    const uint2 x = __builtin_bit_cast(uint2, lo), y = __builtin_bit_cast(uint2, hi);
+    return __builtin_bit_cast(bf16x8_t, make_uint4(x.x, x.y, y.x, y.y));
+  }
+}
+
+template <int FM, int FN> struct Frags { bf16x8_t a[FM], b[FN]; };
+
+// One BM x BN output tile.  4 wavefronts in a 2 x 2 grid, wavefront tile (BM/2) x (BN/2) = FM x FN fragments of 32 x 32.
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const bf16_t* B, TC* C, int tm, int tn, char* smem, int rec) {
+  using GA = Op<TA, BM>;
+  using GB = Op<TB, BN>;
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
+  constexpr int STAGE = GA::BYTES + GB::BYTES;
+  constexpr int NPA = GA::NPW, NPB = GB::NPW, NP = NPA + NPB;          // DMA pieces per wavefront per slab
+  constexpr int NMMA = FM * FN;                                        // MFMAs per k16-step
+  static_assert(FM == 2 && (FN == 1 || FN == 2), "wavefront tiles: 64x64 or 64x32");
+  static_assert(STAGES == 2 || STAGES == 3, "ring of two or three slabs");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+  PhaseProbe probe;
+  probe_begin(probe, g);
+  const int nk = g.K >> 6;                                              // host guarantees K % 64 == 0, K >= 128
+
+  DmaOp da = dma_setup<TA, BM>(A, g.lda, m0, 0, wave, lane);
+  DmaOp db = dma_setup<TB, BN>(B, g.ldb, n0, 0, wave, lane);
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned piece0 = lds0 + (unsigned)wave * 1024u;                // LDS address of this wavefront's piece 0 in ring slot 0
+
+  // piece i (0 .. NP-1) of the slab the DMA plans currently point at, into ring slot `slot`
+  auto issue_piece = [&](int i, unsigned slot_base) {
+    if (i < NPA) glds(da.voff, da.sbase + i * da.piece_stride, slot_base + (unsigned)(i * 4096));
+    else glds(db.voff, db.sbase + (i - NPA) * db.piece_stride, slot_base + (unsigned)(GA::BYTES + (i - NPA) * 4096));
+  };
+  auto advance_slab = [&]() { da.sbase += da.slab_stride; db.sbase += db.slab_stride; };
+
+  // the whole ring goes in flight before anything else
+#pragma unroll
+  for (int s = 0; s < STAGES; ++s) {
+    if (s < nk) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) issue_piece(i, piece0 + (unsigned)(s * STAGE));
+      advance_slab();
+    }
+  }
+
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  EpiPre<bf16_t, TC, BM, BN, 256> pre;
+  pre.valid = false;
+  pre.bias_valid = false;
+  if (g.vec_epilogue && g.bias != nullptr) {                            // the thread's 8 bias values travel under the reduction
+    const int colc = n0 + (tid % (BN / 8)) * 8;
+    pre.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
+    pre.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+    pre.bias_valid = true;
+  }
+
+  // fragment read addresses relative to a ring slot
+  const unsigned rel_a = frag_rel<TA, BM>(wr * WM, lane);
+  const unsigned rel_b = (unsigned)GA::BYTES + frag_rel<TB, BN>(wc * WN, lane);
+
+  // fused bias gradient of the TN (weight-gradient) products: the workgroups of the first tile column also sum the A slab
+  // ([k][BM] in LDS) over k -- thread -> one 16-byte chunk (8 columns of A^T), four k-rows per slab
+  const bool do_colsum = TA && g.a_colsum != nullptr && tn == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto colsum_slab = [&](unsigned slot_base) {
+    if constexpr (TA) {
+      if (do_colsum) {
+        constexpr int CPR = BM / 8, KG = 256 / CPR, KPT = 64 / KG;       // chunks per k-row, k-groups, k-rows per thread and slab
+        const int cc = tid % CPR, kg = tid / CPR;
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) {
+          const int kr = kg + e * KG;
+          const int swz = BM == 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
+          const u32x4_t w = *reinterpret_cast<lds_u4_t>(slot_base + (unsigned)(kr * GA::PITCH + ((cc ^ swz) << 4)));
+          const uint4 v = make_uint4(w.x, w.y, w.z, w.w);
+          float f[8];
+          unpack8<bf16_t>(&v, f);
+#pragma unroll
+          for (int x = 0; x < 8; ++x) cs[x] += f[x];
+        }
+      }
+    }
+  };
+
+  Frags<FM, FN> P, Q;
+  // slab 0 landed (the younger slabs of the ring stay in flight), visible to every wavefront
+  if (nk >= STAGES) wait_vm<(STAGES - 1) * NP>();
+  else wait_vm<NP>();                                                   // ring of three, two slabs in all
+  __builtin_amdgcn_s_barrier();
+  ETP_SB();
+#pragma unroll
+  for (int a = 0; a < FM; ++a) P.a[a] = frag_ld<TA, BM>(lds0 + rel_a, a, 0);
+#pragma unroll
+  for (int b = 0; b < FN; ++b) P.b[b] = frag_ld<TB, BN>(lds0 + rel_b, b, 0);
+  ETP_SB();
+  if (probe.on) probe.mt1 = __builtin_amdgcn_s_memtime();
+
+  // ---- the reduction.  Everything below is order-pinned: one sched_barrier(0) behind every LDS read, MFMA and DMA piece.
+  //
+  //   fragment sets P / Q alternate per k16-step:  step ks computes on the set read during step ks-1 and reads the set of
+  //   step ks+1, reads and MFMAs alternating.  A slab's last step is cut in two: its first MFMAs are issued, THEN the wavefront
+  //   waits for slab t+1 (counted vmcnt), retires its reads of slab t (lgkmcnt(0)) and meets the others (s_barrier) -- the matrix
+  //   pipe works on those MFMAs meanwhile -- then the first fragments of slab t+1 are read, the remaining MFMAs follow, and the
+  //   DMA pieces of the ring slot slab t just vacated go out one per MFMA over the following k16-steps.
+  //   Loop iteration t = hand-over INTO slab t + its steps: every piece of one ring refill is issued inside one iteration.
+  unsigned dslot = piece0;          // LDS address of this wavefront's piece 0 in the ring slot being refilled
+// ETP_MM32_EXPT (measurement builds only, tools/r04_call4.sh; results are wrong in these modes): 1 = the loop issues and waits
+// for the DMA but skips fragment reads and MFMAs (what the L2 -> LDS feed alone costs), 2 = fragment reads + MFMAs + barriers but
+// no DMA inside the loop (what the wavefronts' own instruction stream costs)
+#ifndef ETP_MM32_EXPT
+#define ETP_MM32_EXPT 0
+#endif
+#if ETP_MM32_EXPT == 1
+#define ETP_MMA(X, fa, fb)
+#define ETP_LDA(Y, fa, sa, ks)
+#define ETP_LDB(Y, fb, sb, ks)
+#else
+#define ETP_MMA(X, fa, fb) acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X.a[fa], X.b[fb], acc[fa][fb], 0, 0, 0); ETP_SB();
+#define ETP_LDA(Y, fa, sa, ks) Y.a[fa] = frag_ld<TA, BM>(sa, fa, ks); ETP_SB();
+#define ETP_LDB(Y, fb, sb, ks) Y.b[fb] = frag_ld<TB, BN>(sb, fb, ks); ETP_SB();
+#endif
+#if ETP_MM32_EXPT == 2
+#define ETP_DMA(ON, idx)
+#else
+#define ETP_DMA(ON, idx) if constexpr ((ON) && (idx) < NP) { issue_piece((idx), dslot); ETP_SB(); }
+#endif
+// one k16-step: MFMAs of set X alternate with the fragment reads of set Y (k16-step ks of the slab at sa / sb); DMA pieces
+// D .. D + NMMA - 1 of the refill (if any are left) ride behind the MFMAs
+#define ETP_STEP(X, Y, sa, sb, ks, ON, D)                                              \
+  if constexpr (FN == 2) {                                                             \
+    /* reads in the order the next step consumes them: (a0, b0) (a0, b1) (a1, b0) (a1, b1) */                                  \
+    ETP_LDA(Y, 0, sa, ks) ETP_MMA(X, 0, 0) ETP_DMA(ON, (D)) ETP_LDB(Y, 0, sb, ks) ETP_MMA(X, 0, 1) ETP_DMA(ON, (D) + 1)         \
+    ETP_LDB(Y, 1, sb, ks) ETP_MMA(X, 1, 0) ETP_DMA(ON, (D) + 2) ETP_LDA(Y, 1, sa, ks) ETP_MMA(X, 1, 1) ETP_DMA(ON, (D) + 3)     \
+  } else {                                                                             \
+    ETP_LDA(Y, 0, sa, ks) ETP_MMA(X, 0, 0) ETP_DMA(ON, (D)) ETP_LDB(Y, 0, sb, ks) ETP_MMA(X, 1, 0) ETP_DMA(ON, (D) + 1)         \
+    ETP_LDA(Y, 1, sa, ks)                                                              \
+  }
+  constexpr int HS = FN == 2 ? 3 : 2;                                   // DMA pieces that ride in the hand-over itself
+// k16-steps 0 .. 2 of the slab at (sa, sb) (set P holds step 0), then the first MFMAs of step 3
+#define ETP_SLAB_STEPS(sbase_, sa, sb, ON)                   \
+  ETP_STEP(P, Q, sa, sb, 1, ON, HS)                          \
+  colsum_slab(sbase_);                                       \
+  ETP_STEP(Q, P, sa, sb, 2, ON, HS + NMMA)                   \
+  ETP_STEP(P, Q, sa, sb, 3, ON, HS + 2 * NMMA)               \
+  ETP_MMA(Q, 0, 0)                                           \
+  if constexpr (FN == 2) { ETP_MMA(Q, 0, 1) }
+// hand-over into the slab at (na, nb): first fragments of its step 0 and the remaining MFMAs of the previous slab's step 3
+#define ETP_HANDOVER(na, nb, ON)                             \
+  ETP_LDA(P, 0, na, 0) ETP_DMA(ON, 0) ETP_LDB(P, 0, nb, 0)   \
+  ETP_MMA(Q, 1, 0) ETP_DMA(ON, 1)                            \
+  if constexpr (FN == 2) { ETP_LDB(P, 1, nb, 0) }            \
+  ETP_LDA(P, 1, na, 0)                                       \
+  if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) ETP_DMA(ON, 2) }
+#define ETP_ITER(ON, WAIT)                                                                                \
+  {                                                                                                       \
+    WAIT;                              /* slab t landed; at most the slab behind it still in flight */    \
+    wait_lgkm0();                      /* my reads of slab t-1 retired */                                 \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    ETP_SB();                                                                                             \
+    dslot = piece0 + (unsigned)(prev * STAGE);                                                            \
+    const unsigned nbase = lds0 + (unsigned)(cur * STAGE);                                                \
+    const unsigned na = nbase + rel_a, nb = nbase + rel_b;                                                \
+    ETP_HANDOVER(na, nb, ON)                                                                              \
+    ETP_SLAB_STEPS(nbase, na, nb, ON)                                                                     \
+    if constexpr (ON) advance_slab();                                                                     \
+    prev = cur;                                                                                           \
+    cur = (cur + 1 == STAGES) ? 0 : cur + 1;                                                              \
+  }
+  static_assert(HS + 3 * NMMA >= NP, "a ring refill must fit into one iteration's DMA positions");
+  {                                 // slab 0: no hand-over in front of it, the ring is full
+    const unsigned sa = lds0 + rel_a, sb = lds0 + rel_b;
+    ETP_SLAB_STEPS(lds0, sa, sb, false)
+  }
+  int prev = 0, cur = 1;
+  int t = 1;
+  for (; t <= nk - STAGES; ++t) {   // hand-overs that refill the vacated slot (slab t - 1 + STAGES exists)
+    if constexpr (STAGES == 3) ETP_ITER(true, wait_vm<NP>())
+    else ETP_ITER(true, wait_vm<0>())
+  }
+  for (; t < nk; ++t) {             // the last STAGES - 1 hand-overs: nothing left to fetch
+    if constexpr (STAGES == 3) {
+      if (t + 1 < nk) ETP_ITER(false, wait_vm<NP>())
+      else ETP_ITER(false, wait_vm<0>())
+    } else {
+      ETP_ITER(false, wait_vm<0>())
+    }
+  }
+  ETP_MMA(Q, 1, 0)                  // second half of the last slab's last step
+  if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) }
+#undef ETP_ITER
+#undef ETP_HANDOVER
+#undef ETP_SLAB_STEPS
+#undef ETP_STEP
+#undef ETP_DMA
+#undef ETP_LDB
+#undef ETP_LDA
+#undef ETP_MMA
+  wait_vm<0>();
+  if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();
+
+  // epilogue operands that need registers (the activation-backward operand Z) are fetched now: the fragment sets are dead
+  ZPre<BM * (BN / 8) / 256> zp;
+  z_prefetch<bf16_t, TC, BM, BN, 256>(zp, g, m0, n0, tid);
+
+  __syncthreads();                  // every wavefront is done reading the operand slabs before the C tile overwrites them
+  if constexpr (TA) {
+    if (do_colsum) {                // reduce the k-groups through LDS, one atomic per column of A^T
+      constexpr int CPR = BM / 8, KG = 256 / CPR;
+      float* red = reinterpret_cast<float*>(smem);
+      const int cc = tid % CPR, kg = tid / CPR;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) red[kg * BM + cc * 8 + x] = cs[x];
+      __syncthreads();
+      if (tid < BM) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KG; ++k) s += red[k * BM + tid];
+        atomicAdd(g.a_colsum + m0 + tid, s);
+      }
+      __syncthreads();
+    }
+  }
+  // accumulators -> LDS [BM][BN + 4] fp32.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  {
+    constexpr int CP = BN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+    const int col = lane & 31, rh = 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + rh) * CP + wc * WN + b * 32 + col] = acc[a][b][r];
+  }
+  __syncthreads();
+  gemm_epilogue_staged<bf16_t, TC, BM, BN, 256>(smem, g, C, m0, n0, 0, tid, pre, zp);
+  probe_end(probe, g, rec, nk);
+}
+
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256, 2) void kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, g.M / BM, g.N / BN, g.xcd_map, tm, tn);
+  tile<TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
+                                   reinterpret_cast<TC*>(g.C), tm, tn, smem, blockIdx.x);
+}
+
+// Grouped launch (the weight gradients of one transformer layer): same tile list order as gemm.hip's gemm_group_kernel.
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256, 2) void group_kernel(const GemmGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  int id = bid;
+  if (grp.xcd_chunks) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ETP_GEMM_GROUP_MAX; ++i)
+    if (i < grp.n && id >= grp.tile_start[i]) p = i;
+  const GemmArgs& g = grp.g[p];
+  const int local = id - grp.tile_start[p];
+  const int tiles_m = g.M / BM, tiles_n = g.N / BN;
+  int tm, tn;
+  if (tiles_m >= tiles_n) { tm = local / tiles_n; tn = local % tiles_n; }
+  else { tn = local / tiles_m; tm = local % tiles_m; }
+  tile<TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
+                                   reinterpret_cast<TC*>(g.C), tm, tn, smem, bid);
+}
+
+template <int BM, int BN, int STAGES> constexpr int smem_bytes() {
+  constexpr int ring = STAGES * (BM + BN) * 128, ct = BM * (BN + 4) * 4;
+  return ring > ct ? ring : ct;
+}
+
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+static int launch(const GemmArgs& g_in, hipStream_t st) {
+  constexpr int smem = smem_bytes<BM, BN, STAGES>();
+  static bool attr_set = false;
+  void (*kern)(const GemmArgs) = kernel<TC, TA, TB, BM, BN, STAGES>;
+  if (!attr_set) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = (g_in.M / BM) * (g_in.N / BN);
+  GemmArgs g = g_in;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "mm32<bf16,%s,%s%s,%dx%d,s%d>", sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN,
+           STAGES);
+  g.dbg = probe_slot(nm, tiles, g.M, g.N, g.K);
+  ProfRec rec;
+  const bool prof = prof_begin(nm, 2.0 * g.M * g.N * g.K,
+                               ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * sizeof(TC), st, rec);
+  ETP_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, g);
+  ETP_CHECK_LAUNCH("mm32");
+  if (prof) prof_end(rec, st);
+  return ETP_OK;
+}
+
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+static int launch_group(GemmGroup& grp, hipStream_t st) {
+  constexpr int smem = smem_bytes<BM, BN, STAGES>();
+  static bool attr_set = false;
+  void (*kern)(const GemmGroup) = group_kernel<TC, TA, TB, BM, BN, STAGES>;
+  if (!attr_set) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  int tiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    const GemmArgs& g = grp.g[i];
+    grp.tile_start[i] = tiles;
+    tiles += (g.M / BM) * (g.N / BN);
+    flops += 2.0 * g.M * g.N * g.K;
+    bytes += ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * sizeof(TC);
+  }
+  for (int i = grp.n; i <= ETP_GEMM_GROUP_MAX; ++i) grp.tile_start[i] = tiles;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "mm32_group<bf16,%s,%s%s,%dx%d,s%d>", sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM,
+           BN, STAGES);
+  {
+    unsigned long long* slot = probe_slot(nm, tiles, grp.g[0].M, grp.g[0].N, grp.g[0].K);
+    for (int i = 0; i < grp.n; ++i) grp.g[i].dbg = slot;
+  }
+  ProfRec rec;
+  const bool prof = prof_begin(nm, flops, bytes, st, rec);
+  ETP_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, grp);
+  ETP_CHECK_LAUNCH("mm32_group");
+  if (prof) prof_end(rec, st);
+  return ETP_OK;
+}
+
+// shapes this family takes
+static bool eligible(const GemmArgs& g, int bm, int bn) {
+  return g.M % bm == 0 && g.N % bn == 0 && g.K % 64 == 0 && g.K >= 128 && g.ksplit == 1 && g.vec_epilogue && g.out_mode != 2 &&
+         g.lda % 8 == 0 && g.ldb % 8 == 0;
+}
+
+template <typename TC, bool TA, bool TB>
+static int launch_class(const GemmArgs& g, int cls, hipStream_t st) {
+  if (cls == 128) return launch<TC, TA, TB, 128, 128, 2>(g, st);
+  return launch<TC, TA, TB, 128, 64, 3>(g, st);
+}
+
+}  // namespace mm32
+
+// 0: not taken (the caller falls back to gemm.hip's kernels), 128 / 64: tile class (128x128 ring 2, 128x64 ring 3).
+// ETP_MM32=0 switches the family off (A/B runs against gemm.hip's kernels); ETP_MM32=128 / 64 forces that class for every
+// eligible product whatever the tile count (tests).
+static int mm32_mode() {
+  const char* e = getenv("ETP_MM32");
+  return e ? atoi(e) : 1;
+}
+int mm32_class(const GemmArgs& g, int nbatch) {
+  const int mode = mm32_mode();
+  if (!mode || nbatch != 1) return 0;
+  if (mode == 128) return mm32::eligible(g, 128, 128) ? 128 : 0;
+  if (mode == 64) return mm32::eligible(g, 128, 64) ? 64 : 0;
+  const long t128 = (long)(g.M / 128) * (g.N / 128);
+  if (mm32::eligible(g, 128, 128) && t128 >= 320) return 128;
+  // 128x64: the N = 768 products of the M = B*L rows (240 workgroups) and everything between them and the 128x128 class
+  const long tw = (long)(g.M / 128) * (g.N / 64);
+  if (mm32::eligible(g, 128, 64) && tw >= 200) return 64;
+  return 0;
+}
+
+// C dtype: bf16 or fp32; operands bf16.  `cls` from mm32_class.
+int launch_mm32(int c_dtype, int ta, int tb, const GemmArgs& g, int cls, hipStream_t st) {
+  if (c_dtype == ETP_F32) {
+    if (!ta && !tb) return mm32::launch_class<float, false, false>(g, cls, st);
+    if (!ta && tb) return mm32::launch_class<float, false, true>(g, cls, st);
+    if (ta && tb) return mm32::launch_class<float, true, true>(g, cls, st);
+  } else {
+    if (!ta && !tb) return mm32::launch_class<bf16_t, false, false>(g, cls, st);
+    if (!ta && tb) return mm32::launch_class<bf16_t, false, true>(g, cls, st);
+    if (ta && tb) return mm32::launch_class<bf16_t, true, true>(g, cls, st);
+  }
+  return fail(ETP_ERR_INVALID, "mm32: (A trans, B row) storage pairing is not used on this path");
+}
+
+// grouped weight gradients (TN, fp32 out): true when every problem of the group is whole 128x128 tiles
+bool mm32_group_ok(const GemmGroup& grp) {
+  if (!mm32_mode()) return false;
+  long t = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    if (!mm32::eligible(grp.g[i], 128, 128)) return false;
+    t += (long)(grp.g[i].M / 128) * (grp.g[i].N / 128);
+  }
+  return t >= 100 || mm32_mode() == 128;
+}
+int launch_mm32_group(GemmGroup& grp, hipStream_t st) { return mm32::launch_group<float, true, true, 128, 128, 2>(grp, st); }
+
+}  // namespace etp

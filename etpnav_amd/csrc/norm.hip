@@ -243,8 +243,10 @@ __global__ __launch_bounds__(256) void ln_bwd_s_kernel(const float* __restrict__
       if (dx != nullptr) store4(dx + (long)row * H + col, o);
       if (dxt != nullptr) {
         if (drop.p > 0.f) {   // the operand copy is the gradient of a dropped dense output: d(dense) = dx * mask / (1-p)
+          float dm[4];
+          drop_mult_run<4>(drop.seed, (uint32_t)row * H + col, drop.p, drop.inv_keep, dm);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] *= drop_mult(drop.seed, (uint32_t)row * H + col + e, drop.p, drop.inv_keep);
+          for (int e = 0; e < 4; ++e) o[e] *= dm[e];
         }
         store4(dxt + (long)row * H + col, o);
       }

@@ -857,6 +857,9 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
     stamp_mark(c.st, 2200 + 10 * l + 1);
+    // the LAST layer of the backward: its two FFN weight gradients go out now instead of with the attention ones at the end of
+    // the layer -- nothing runs behind this layer that could hide them (the step's end waits for the weight-gradient stream)
+    if (l == 0 && layer_lo == 0) ETP_TRY(flush_side(c));
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
     // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work

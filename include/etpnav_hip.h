@@ -61,6 +61,8 @@ typedef struct etp_gemm_desc {
   void* Z; int64_t ldz;     /* aux tensor for the activation epilogues, dtype T */
   int32_t act;              /* ETP_ACT_* */
   int32_t out_mode;         /* 0 store, 1 C += v, 2 atomicAdd (fp32 C) */
+  float* a_colsum;          /* TN products (weight gradients) only, or NULL: a_colsum[m] += sum_k A[m,k] -- the bias gradient
+                             * db = colsum(dY) fused into the dW = dY^T X product (K a multiple of the 128-byte slab, >= 2 slabs) */
 } etp_gemm_desc;
 int etp_gemm(const etp_gemm_desc* d, etp_stream_t stream);
 /* n (<= 8) independent, unbatched, unsplit products of ONE (dtype, c_dtype, trans_a, trans_b) class in a single grid: the

@@ -233,6 +233,15 @@ def _mix(seed, idx):
     return x
 
 
+def _pair(seed, pair):
+    """drop_pair of common.h: the 32-bit word shared by elements 2 * pair and 2 * pair + 1."""
+    with _np.errstate(over="ignore"):
+        x = pair.astype(_np.uint32) * _np.uint32(0x9E3779B1) + _np.uint32(seed)
+        x ^= x >> _np.uint32(16); x *= _np.uint32(0x85EBCA6B); x ^= x >> _np.uint32(13); x *= _np.uint32(0xC2B2AE35)
+        x ^= x >> _np.uint32(16)
+    return x
+
+
 class DropSpec:
     """Rates + step seed of one planner call (mirrors etp_planner_set_dropout)."""
 
@@ -255,10 +264,14 @@ class DropSpec:
         n = 1
         for d in shape:
             n *= int(d)
-        h = _mix(self.site_seed(mode, layer, slot), _np.arange(n, dtype=_np.uint32))
-        u = (h >> _np.uint32(8)).astype(_np.float32) * _np.float32(1.0 / 16777216.0)
+        # per-element bits (etpnav_amd/csrc/common.h drop_pair / drop_mult): one avalanche per PAIR of consecutive elements,
+        # element 2j takes the low 16 bits, 2j+1 the high 16; keep <=> bits >= round(p * 65536)
+        idx = _np.arange(n, dtype=_np.uint32)
+        w = _pair(self.site_seed(mode, layer, slot), idx >> _np.uint32(1))
+        h = _np.where((idx & _np.uint32(1)) != 0, w >> _np.uint32(16), w & _np.uint32(0xFFFF))
+        thr = _np.uint32(int(_np.float32(p) * _np.float32(65536.0) + _np.float32(0.5)))
         inv = _np.float32(1.0) / (_np.float32(1.0) - _np.float32(p))
-        m = _np.where(u >= _np.float32(p), inv, _np.float32(0.0)).astype(_np.float32)
+        m = _np.where(h >= thr, inv, _np.float32(0.0)).astype(_np.float32)
         return torch.from_numpy(m).view(*shape).to(dtype)
 
 

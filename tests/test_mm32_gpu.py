@@ -1,0 +1,174 @@
+"""Parity of the 32x32x16 GEMM family (etpnav_amd/csrc/gemm_mm32.hip: order-pinned main loop, whole tiles only) on the MI355X:
+every storage class (NT / NN / TN), both tile classes (128x128 ring 2, 128x64 ring 3), both output types, the fused epilogues the
+planner uses, the grouped weight-gradient launch with the fused bias gradient -- against fp32 torch math on the same operands and
+against gemm.hip's kernels (ETP_MM32=0) on the same inputs; plus a race screen under uneven load (the hand-over moved into the
+middle of a k-step and the DMA pieces ride between the MFMAs: cdna_hip_programming.md asks for a multi-run screen of such edits).
+Reference sites: the nn.Linear products of vlnce_baselines/models/etp/vilmodel_cmt.py:108-110,151,178,190,326-328 and their
+backward."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from etpnav_amd import _lib  # noqa: E402
+from etpnav_amd._lib import GemmDesc, check  # noqa: E402
+from tests.test_ops_gpu import DEV, L, gelu, gelu_grad, run_gemm, stream  # noqa: E402
+
+BF, F32 = _lib.ETP_BF16, _lib.ETP_F32
+T = torch.bfloat16
+
+
+def operands(M, N, K, ta, tb, seed):
+    torch.manual_seed(seed)
+    A = torch.randn(M, K, device=DEV).to(T)
+    B = (torch.randn(N, K, device=DEV) * 0.1 + 0.01).to(T)               # asymmetric: catches row / column swaps
+    ref = A.float() @ B.float().t()
+    As = A.t().contiguous() if ta else A
+    Bs = B.t().contiguous() if tb else B
+    return As, Bs, ref
+
+
+def btol(K):
+    return 3e-2 * math.sqrt(K) / 4
+
+
+@pytest.mark.parametrize("cls", ["128", "64"])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("K", [128, 192, 320, 768])
+def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, monkeypatch):
+    """Plain products (fp32 and bf16 C), reductions of 2, 3, 5 and 12 slabs: ring fill / drain paths of both ring depths."""
+    monkeypatch.setenv("ETP_MM32", cls)
+    M, N = (384, 256) if cls == "128" else (256, 192)
+    As, Bs, ref = operands(M, N, K, ta, tb, 11 * K + ta + 2 * tb)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
+    err = (C - ref).abs().max().item()
+    assert err <= 2e-3 * math.sqrt(K), (cls, ta, tb, K, err)            # bf16 operands, fp32 accumulation and output: only summation order differs
+    Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
+    run_gemm(As, Bs, Cb, M, N, K, ta, tb, BF)
+    assert (Cb.float() - ref).abs().max().item() <= btol(K), (cls, ta, tb, K)
+
+
+@pytest.mark.parametrize("cls", ["128", "64"])
+@pytest.mark.parametrize("tb", [0, 1])
+def test_mm32_epilogues(cls, tb, monkeypatch):
+    """bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU / ReLU backward, ReLU, accumulate,
+    alpha -- the epilogues of linear_fwd / linear_fwd_s / linear_dgrad(_s) in planner.hip."""
+    monkeypatch.setenv("ETP_MM32", cls)
+    M, N, K = (512, 384, 256) if cls == "128" else (384, 320, 192)
+    As, Bs, raw = operands(M, N, K, 0, tb, 5 + tb)
+    bias = torch.randn(N, device=DEV)
+    R = torch.randn(M, N, device=DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    run_gemm(As, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, bias=bias, R=R)
+    assert (C - (raw + bias + R)).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, tb, "stream")
+    Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
+    Z = torch.empty(M, N, device=DEV, dtype=T)
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, alpha=0.5, bias=bias, Z=Z, act=_lib.ACT_GELU)
+    v = 0.5 * raw + bias
+    assert (Z.float() - v).abs().max().item() <= btol(K), (cls, tb, "z")
+    assert (Cb.float() - gelu(v)).abs().max().item() <= btol(K), (cls, tb, "gelu")
+    Zin = torch.randn(M, N, device=DEV).to(T)
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, Z=Zin, act=_lib.ACT_GELU_BWD)
+    assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= btol(K), (cls, tb, "dgelu")
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, Z=Zin, act=_lib.ACT_RELU_BWD)
+    assert (Cb.float() - raw * (Zin.float() > 0)).abs().max().item() <= btol(K), (cls, tb, "drelu")
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, bias=bias, act=_lib.ACT_RELU)
+    assert (Cb.float() - torch.relu(raw + bias)).abs().max().item() <= btol(K), (cls, tb, "relu")
+    C0 = torch.randn(M, N, device=DEV)
+    C = C0.clone()
+    run_gemm(As, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, out_mode=1)
+    assert (C - (C0 + raw)).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, tb, "accumulate")
+
+
+@pytest.mark.parametrize("shape", [(2560, 2304, 768, 0, 0), (2560, 3072, 768, 0, 1), (2560, 768, 3072, 0, 0), (2560, 768, 2304, 0, 1),
+                                   (3072, 768, 2560, 1, 1), (2304, 3072, 256, 1, 1), (1152, 3072, 768, 0, 0)])
+def test_mm32_planner_shapes_agree_with_the_16x16_kernels(shape, monkeypatch):
+    """The text-layer products of configuration 2 at their real extents through the DEFAULT class choice: the new family
+    against gemm.hip's kernels on the same operands (fp32 C: same products, different summation order)."""
+    M, N, K, ta, tb = shape
+    As, Bs, ref = operands(M, N, K, ta, tb, M + N + K)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ETP_MM32", mode)
+        C = torch.full((M, N), float("nan"), device=DEV)
+        run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
+        out[mode] = C
+    assert (out["1"] - ref).abs().max().item() <= 2e-3 * math.sqrt(K), shape
+    assert (out["1"] - out["0"]).abs().max().item() <= 1e-3 * math.sqrt(K), shape
+
+
+def run_group(descs):
+    arr = (GemmDesc * len(descs))(*descs)
+    check(L().etp_gemm_group(arr, len(descs), stream()), "etp_gemm_group")
+    torch.cuda.synchronize()
+
+
+def wgrad_desc(dY, X, dW, db, out_mode):
+    d = GemmDesc()
+    M, N = dY.shape
+    K = X.shape[1]
+    d.A, d.B, d.C = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
+    d.M, d.N, d.K = N, K, M
+    d.lda, d.ldb, d.ldc = dY.stride(0), X.stride(0), dW.stride(0)
+    d.trans_a, d.trans_b, d.dtype, d.c_dtype = 1, 1, BF, F32
+    d.batch, d.batch_inner, d.ksplit, d.alpha = 1, 1, 1, 1.0
+    d.out_mode = out_mode
+    d.a_colsum = db.data_ptr() if db is not None else None                # fused bias gradient: db += colsum(dY)
+    return d
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_mm32_grouped_text_layer_weight_gradients(mode, monkeypatch):
+    """The four weight gradients of one text layer (M = 2560 tokens) as ONE grid with the fused bias gradients (column sums of
+    dY): stores and accumulates, against fp32 torch; mode 0 runs the same call through gemm.hip's grouped kernel."""
+    monkeypatch.setenv("ETP_MM32", mode)
+    torch.manual_seed(3)
+    Mt, H, I = 2560, 768, 3072
+    specs = [(3 * H, H), (H, H), (I, H), (H, I)]                        # (out features N, in features K) of qkv, out, ffn-up, ffn-down
+    dYs = [(torch.randn(Mt, n, device=DEV) * 0.5).to(T) for n, _ in specs]
+    Xs = [torch.randn(Mt, k, device=DEV).to(T) for _, k in specs]
+    for out_mode in (0, 1):
+        dWs = [torch.randn(n, k, device=DEV) for n, k in specs]
+        dbs = [torch.randn(n, device=DEV) for n, _ in specs]
+        w0 = [w.clone() for w in dWs]
+        b0 = [b.clone() for b in dbs]
+        run_group([wgrad_desc(dY, X, dW, db, out_mode) for dY, X, dW, db in zip(dYs, Xs, dWs, dbs)])
+        for dY, X, dW, db, w, b in zip(dYs, Xs, dWs, dbs, w0, b0):
+            ref = dY.float().t() @ X.float()
+            if out_mode == 1:
+                ref = ref + w
+            assert (dW - ref).abs().max().item() <= 2e-3 * math.sqrt(Mt), (mode, out_mode, tuple(dW.shape))
+            refb = b + dY.float().sum(0)                                 # the bias gradient always accumulates
+            assert (db - refb).abs().max().item() <= 2e-3 * math.sqrt(Mt), (mode, out_mode, "bias", tuple(dW.shape))
+
+
+@pytest.mark.parametrize("cls", ["128", "64"])
+def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
+    """12 runs of the same products while a bandwidth-heavy copy loop on a second stream perturbs the DMA timing on every other
+    run: outputs must be bit-identical across runs (a stale or early LDS read shows as a run that differs) and match the
+    reference.  Reductions of 2, 3, 5 and 24 slabs; NT, NN and TN."""
+    monkeypatch.setenv("ETP_MM32", cls)
+    side = torch.cuda.Stream()
+    noise_a = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
+    noise_b = torch.empty_like(noise_a)
+    for (M, N, K, ta, tb) in [(512, 384, 128, 0, 0), (384, 256, 192, 0, 1), (640, 768, 320, 1, 1), (768, 512, 1536, 0, 1),
+                              (1024, 1024, 1536, 1, 1)]:
+        As, Bs, ref = operands(M, N, K, ta, tb, M + K)
+        first = None
+        for it in range(12):
+            C = torch.full((M, N), float("nan"), device=DEV)
+            if it % 2 == 1:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        noise_b.copy_(noise_a, non_blocking=True)
+            run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
+            side.synchronize()
+            if first is None:
+                first = C.clone()
+                assert (C - ref).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, M, N, K)
+            else:
+                assert torch.equal(C, first), (cls, M, N, K, it, (C - first).abs().max().item())
