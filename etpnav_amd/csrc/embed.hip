@@ -428,6 +428,14 @@ __global__ __launch_bounds__(256) void gmap_embed_fwd_kernel(const float* __rest
   }
 }
 
+// Register budget (round 4): the first form of this kernel kept seven per-lane accumulators for d w_pos (7 x NCH x 4 floats) beside
+// the four others, the hoisted projection weights and two rows in flight: 256 VGPRs + 52 AGPRs, with the row's position features
+// parked in AGPRs between their two uses -- and that parked copy was sporadically wrong whenever a grouped weight-gradient GEMM
+// ran beside this kernel on the side stream (d w_pos off by up to 2 % in ~40 % of the steps of configuration 2, every other
+// output exact; found by tests/test_planner_gpu.py in file order, present since round 3; profiles/r04_gmap_pos_race.txt).  Now
+// d w_pos is accumulated per THREAD for the thread's own columns from the four rows a block has just finished (they pass through
+// the LDS scratch): 3 x 7 accumulators instead of 84, no cross-wave reduction for them, and the kernel stays far below 256
+// registers (no AGPRs, no scratch).
 template <typename T, int NCH, int PK>
 __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ step_ids,
                                                              const float* __restrict__ pos, const float* __restrict__ w_pos,
@@ -437,39 +445,58 @@ __global__ __launch_bounds__(256) void gmap_embed_bwd_kernel(const float* __rest
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
   constexpr int H = NCH * 256;
   extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
-  Row<NCH> a_g, a_b, a_bp, a_w[PK], a_s0;                            // dgamma, dbeta, d_b_pos, d_w_pos[.,j], d_step_emb[0]
+  Row<NCH> a_g, a_b, a_bp, a_s0;                                     // dgamma, dbeta, d_b_pos, d_step_emb[0]
   row_zero<NCH>(a_g); row_zero<NCH>(a_b); row_zero<NCH>(a_bp); row_zero<NCH>(a_s0);
+  float a_w[NCH][PK];                                                // d w_pos[col][j] of this thread's columns tid + 256 k
 #pragma unroll
-  for (int j = 0; j < PK; ++j) row_zero<NCH>(a_w[j]);
-  const int lane = threadIdx.x & 63;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    Row<NCH> t, d;
-    pos_project<NCH, PK>(t, pos + (long)row * PK, w_pos, b_pos, lane);
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  for (int k = 0; k < NCH; ++k)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int j = 0; j < PK; ++j) a_w[k][j] = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int base = blockIdx.x * 4; base < M; base += gridDim.x * 4) {   // four rows per block and iteration, one per wavefront
+    const int row = base + wave;
+    if (row < M) {
+      Row<NCH> t, d;
+      pos_project<NCH, PK>(t, pos + (long)row * PK, w_pos, b_pos, lane);
+      const float mean = stats[2 * row], rstd = stats[2 * row + 1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t.v[c][e] = (t.v[c][e] - mean) * rstd;
-    row_load<NCH>(d, dx + (long)row * H, lane);
-    // step id 0 marks the [stop] token and every unvisited (ghost) node (ss_trainer_ETP.py:364-366,393): most rows hit
-    // table row 0, and per-row atomics on one row serialise in L2 -- those rows go through the block accumulator instead
-    const int64_t sid = step_ids[row];
-    if (sid == 0) acc_scaled<NCH>(a_s0, d, 1.0f);
-    else global_acc<NCH>(d_step_emb + sid * H, d, lane);
-    acc_mul<NCH>(a_g, d, t);
-    acc_scaled<NCH>(a_b, d, 1.0f);
-    row_ln_bwd<NCH>(d, t, gamma, rstd, lane);
-    acc_scaled<NCH>(a_bp, d, 1.0f);
-    const float* pr = pos + (long)row * PK;
+      for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int j = 0; j < PK; ++j) acc_scaled<NCH>(a_w[j], d, pr[j]);
+        for (int e = 0; e < 4; ++e) t.v[c][e] = (t.v[c][e] - mean) * rstd;
+      row_load<NCH>(d, dx + (long)row * H, lane);
+      // step id 0 marks the [stop] token and every unvisited (ghost) node (ss_trainer_ETP.py:364-366,393): most rows hit
+      // table row 0, and per-row atomics on one row serialise in L2 -- those rows go through the block accumulator instead
+      const int64_t sid = step_ids[row];
+      if (sid == 0) acc_scaled<NCH>(a_s0, d, 1.0f);
+      else global_acc<NCH>(d_step_emb + sid * H, d, lane);
+      acc_mul<NCH>(a_g, d, t);
+      acc_scaled<NCH>(a_b, d, 1.0f);
+      row_ln_bwd<NCH>(d, t, gamma, rstd, lane);
+      acc_scaled<NCH>(a_bp, d, 1.0f);
+      row_store<NCH>(d, scratch + wave * H, lane);                   // d (LayerNorm input gradient) of this row for the d w_pos pass
+    }
+    __syncthreads();
+    const int nrows = min(4, M - base);
+    for (int r = 0; r < nrows; ++r) {
+      const float* pr = pos + (long)(base + r) * PK;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const float dv = scratch[r * H + k * 256 + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < PK; ++j) a_w[k][j] += dv * pr[j];
+      }
+    }
+    __syncthreads();
   }
   block_flush<NCH>(scratch, a_g, dgamma, 1, 0);
   block_flush<NCH>(scratch, a_b, dbeta, 1, 0);
   block_flush<NCH>(scratch, a_bp, d_b_pos, 1, 0);
   block_flush<NCH>(scratch, a_s0, d_step_emb, 1, 0);
 #pragma unroll
-  for (int j = 0; j < PK; ++j) block_flush<NCH>(scratch, a_w[j], d_w_pos, PK, j);
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int j = 0; j < PK; ++j) atomicAdd(d_w_pos + (long)(k * 256 + threadIdx.x) * PK + j, a_w[k][j]);
 }
 
 // --------------------------------------------------------------------------------------

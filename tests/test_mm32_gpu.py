@@ -172,3 +172,46 @@ def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
                 assert (C - ref).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, M, N, K)
             else:
                 assert torch.equal(C, first), (cls, M, N, K, it, (C - first).abs().max().item())
+
+
+@pytest.mark.parametrize("tb", [0, 1])
+def test_gemm_eight_wavefront_64x64_class(tb):
+    """Grids of at most one 64x64 workgroup per CU (the M = 512 node-side products of the x-layers, gemm.hip gemm_dma8_kernel:
+    eight wavefronts per tile, ring of six slabs): ragged and whole shapes, reductions of 4 .. 48 slabs, the planner's epilogues."""
+    for (M, N, K) in [(300, 200, 256), (130, 72, 320), (512, 768, 768), (512, 768, 3072), (512, 2304, 768), (64, 64, 1024)]:
+        torch.manual_seed(M + N + K + tb)
+        A = torch.randn(M, K, device=DEV).to(T)
+        B = (torch.randn(N, K, device=DEV) * 0.1).to(T)
+        Bs = B.t().contiguous() if tb else B
+        ldb = None
+        if tb and N % 8:
+            pad = torch.zeros(K, (N + 7) // 8 * 8, device=DEV, dtype=T); pad[:, :N] = Bs; Bs = pad
+        bias = torch.randn(N, device=DEV)
+        raw = A.float() @ B.float().t()
+        R = torch.randn(M, N, device=DEV)
+        C = torch.full((M, N), float("nan"), device=DEV)
+        run_gemm(A, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, bias=bias, R=R)
+        assert (C - (raw + bias + R)).abs().max().item() <= 2e-3 * math.sqrt(K), (M, N, K, tb, "stream")
+        Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
+        Z = torch.empty(M, N, device=DEV, dtype=T)
+        run_gemm(A, Bs, Cb, M, N, K, 0, tb, BF, bias=bias, Z=Z, act=_lib.ACT_GELU)
+        assert (Z.float() - (raw + bias)).abs().max().item() <= btol(K), (M, N, K, tb, "z")
+        assert (Cb.float() - gelu(raw + bias)).abs().max().item() <= btol(K), (M, N, K, tb, "gelu")
+        Zin = torch.randn(M, N, device=DEV).to(T)
+        run_gemm(A, Bs, Cb, M, N, K, 0, tb, BF, Z=Zin, act=_lib.ACT_GELU_BWD)
+        assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= btol(K), (M, N, K, tb, "dgelu")
+
+
+def test_gemm_eight_wavefront_weight_gradient_with_bias_gradient():
+    """TN storage on the eight-wavefront class: dW = dY^T X with the fused column sums (bias gradient), 512 tokens."""
+    torch.manual_seed(9)
+    Mt, n, k = 512, 768, 768
+    dY = (torch.randn(Mt, n, device=DEV) * 0.5).to(T)
+    X = torch.randn(Mt, k, device=DEV).to(T)
+    dW = torch.full((n, k), float("nan"), device=DEV)
+    db = torch.zeros(n, device=DEV)
+    d = wgrad_desc(dY, X, dW, db, 0)
+    check(L().etp_gemm(ctypes.byref(d), stream()), "etp_gemm")
+    torch.cuda.synchronize()
+    assert (dW - dY.float().t() @ X.float()).abs().max().item() <= 2e-3 * math.sqrt(Mt)
+    assert (db - dY.float().sum(0)).abs().max().item() <= 2e-3 * math.sqrt(Mt)
