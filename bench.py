@@ -132,8 +132,11 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train (default): dropout active at every site, as under the reference's policy.train() "
                          "(ss_trainer_ETP.py:483); eval: dropout off (the parity-fixture configuration)")
-    ap.add_argument("--comm-dtype", default="fp32", choices=["bf16", "fp32"],
-                    help="gradient transport: fp32 (default, DDP's numerics) or bf16 (half the xGMI bytes, bf16 sums)")
+    ap.add_argument("--comm-dtype", default="auto", choices=["auto", "bf16", "fp32"],
+                    help="gradient transport.  auto (default) = the compute dtype: bf16 sums for the bf16 step (its gradients carry "
+                         "bf16 rounding already; 282 MB per step instead of 563 MB: at 2 GPUs -- ONE 153 GB/s xGMI link per peer -- "
+                         "the fp32 reduce-scatter + all-gather needs ~3.7 ms against a ~2.5 ms backward window and cannot hide, "
+                         "bf16 ~1.8 ms can), fp32 for --dtype fp32 (DDP's numerics)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -152,6 +155,8 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
+    if args.comm_dtype == "auto":
+        args.comm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: spawn one rank per GPU ourselves (what run_r2r/main.bash:53 does with
@@ -279,6 +284,40 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- communication leg (N > 1): what a scaling curve needs to be read.  Device-side stamps (etp_stamp: s_memrealtime on the
+    # stream) around the part of the step that only waits for the reduction: `exposed` = from the moment the main stream has
+    # finished the backward (every bucket announced) until reducer.finish() lets it continue.
+    comm_info = None
+    if world > 1 and reducer is not None:
+        Lc = _lib.lib()
+        stamps = torch.zeros(2 * 8, dtype=torch.int64, device=f"cuda:{local_rank}")
+        for k in range(8):
+            if use_graph:
+                one_step()
+                continue
+            step.run_data_parallel(txt_groups, lambda i, side: reducer.reduce_bucket(i, also=side), overlapped=reducer.overlapped)
+            for i in range(1 + len(txt_groups), len(reducer.ranges)):
+                reducer.reduce_bucket(i)
+            reducer.reduce_sparse_rows(step.inp["txt_ids"], capacity=w["B"] * w["L"])
+            s_main = model._engine.stream()
+            _lib.check(Lc.etp_stamp(ctypes.c_void_p(stamps.data_ptr() + 16 * k), s_main), "stamp")
+            reducer.finish()
+            _lib.check(Lc.etp_stamp(ctypes.c_void_p(stamps.data_ptr() + 16 * k + 8), s_main), "stamp")
+        barrier()
+        st = stamps.cpu().view(8, 2)
+        exposed = [(int(b) - int(a)) * 1e-5 for a, b in st.tolist() if a and b]            # 100 MHz ticks -> ms
+        esz = 2 if args.comm_dtype == "bf16" else 4
+        dense = sum(e - s0 for s0, e in reducer.ranges)
+        sparse_b = (w["B"] * w["L"]) * (reducer.sparse[2] * esz + 8) if reducer.sparse is not None else 0
+        t = torch.tensor([sum(exposed[2:]) / max(len(exposed[2:]), 1) if exposed else -1.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_info = {"exposed_ms": round(float(t.item()), 4), "bytes_per_step": int(dense * esz + sparse_b * world),
+                     "dense_bytes": int(dense * esz), "buckets": len(reducer.ranges), "dtype": args.comm_dtype, "kind": comm_kind,
+                     "row_sparse_table": reducer.sparse is not None,
+                     "note": "exposed_ms = device-side time (etp_stamp) the main stream spends between the end of its backward and the "
+                             "return of the gradient reduction, max over ranks, mean of 6 steps after the timed region; "
+                             "bytes_per_step = payload one rank contributes per step (dense buckets + its row-sparse block x world)"}
 
     # ---- roofline leg: HIP-event timing of every GEMM launch (rank 0), IN the step and alone ----
     # `achieved` / `frac` use the IN-STEP duration: event pairs on the kernel's own launch stream while the step runs with its
@@ -468,6 +507,7 @@ def main():
                        "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
                                     "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
                        "grad_comm_dtype": args.comm_dtype if world > 1 else None},
+            "comm": comm_info,
             "loss": round(loss, 5),
             "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
             "model_flops_per_step": fl,

@@ -151,12 +151,18 @@ def lib() -> ctypes.CDLL:
         torch.cuda.init()
     L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
+    missing = []
     for name, (res, args) in _protos.items():
         if os.environ.get("ETP_LIB") and not hasattr(L, name):
+            missing.append(name)
             continue
         fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if missing:                        # ETP_LIB builds only (A/B measurement): say what the selected build lacks, once
+        import sys
+        print(f"[etpnav_amd] ETP_LIB={LIB_PATH}: {len(missing)} declared symbols are absent from this build and stay unbound: "
+              f"{', '.join(missing[:6])}{' ...' if len(missing) > 6 else ''}", file=sys.stderr)
     _lib = L
     return L
 

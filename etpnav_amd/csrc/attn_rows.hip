@@ -467,8 +467,13 @@ bool attn_rows_ok(int dt, const AttnBuf& a, long ldc) {
 // MEASUREMENT ONLY (tools/r03_call20.sh): ETP_SKIP_ATTN = "fwd" / "bwd" drops the launches so that the step time shows what
 // the attention kernels cost in the step (results are wrong in that mode); see ETP_SKIP_LN in norm.hip.
 static bool skip_attn(const char* what) {
+#ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
   static const char* e = getenv("ETP_SKIP_ATTN");
   return e && strstr(e, what) != nullptr;
+#else
+  (void)what;
+  return false;
+#endif
 }
 
 int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {

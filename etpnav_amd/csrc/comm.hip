@@ -76,12 +76,15 @@ int rccl_check(int rc, const char* what) {
 // ---- row-sparse table exchange (word-embedding gradient): pack -> all-gather -> scatter-add ------------------------------
 // slot j of this rank's block: id (or -1: padding / a repeated id) and the table row (zeros for -1).  The packed row is
 // REMOVED from the table (zeroed): the rank's own rows come back inside the gathered block like everybody else's.
+// ids outside [0, n_rows) (an out-of-vocabulary token on ANY rank) are treated as padding on both sides: they must never become
+// addresses.
 template <typename R>
-__global__ void rows_pack_kernel(float* __restrict__ table, long row_len, const int64_t* __restrict__ ids, long n_ids,
+__global__ void rows_pack_kernel(float* __restrict__ table, long n_rows, long row_len, const int64_t* __restrict__ ids, long n_ids,
                                  int64_t* __restrict__ out_ids, R* __restrict__ out_rows) {
   const long j = blockIdx.x;
   __shared__ int dup;
   int64_t id = j < n_ids ? ids[j] : -1;
+  if (id >= n_rows) id = -1;
   if (threadIdx.x == 0) dup = 0;
   __syncthreads();
   if (id >= 0) {                      // a repeated id contributes its row once: the first slot that names it
@@ -104,11 +107,11 @@ __global__ void rows_pack_kernel(float* __restrict__ table, long row_len, const 
   }
 }
 template <typename R>
-__global__ void rows_scatter_kernel(float* __restrict__ table, long row_len, const int64_t* __restrict__ all_ids,
+__global__ void rows_scatter_kernel(float* __restrict__ table, long n_rows, long row_len, const int64_t* __restrict__ all_ids,
                                     const R* __restrict__ all_rows, float scale) {
   const long j = blockIdx.x;
   const int64_t id = all_ids[j];
-  if (id < 0) return;
+  if (id < 0 || id >= n_rows) return;
   const R* src = all_rows + j * row_len;
   float* dst = table + id * row_len;
   for (long c = threadIdx.x; c < row_len; c += blockDim.x) atomicAdd(dst + c, etp::Elem<R>::ld(src + c) * scale);
@@ -116,6 +119,7 @@ __global__ void rows_scatter_kernel(float* __restrict__ table, long row_len, con
 
 struct etp_comm {
   void* rows_ids = nullptr; void* rows_buf = nullptr;   // gather_rows staging: [world + 1][capacity] ids / rows (slot 0 = send block)
+  void* rows_in = nullptr;                              // the caller's ids, copied on the producer stream (the caller may free its tensor)
   int64_t rows_cap = 0, rows_len = 0;
   rcclComm_t comm = nullptr;
   int rank = 0, world = 1, comm_dtype = ETP_F32;
@@ -225,12 +229,18 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
     ETP_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (c->rows_ids) (void)hipFree(c->rows_ids);
     if (c->rows_buf) (void)hipFree(c->rows_buf);
-    c->rows_ids = c->rows_buf = nullptr;
+    if (c->rows_in) (void)hipFree(c->rows_in);
+    c->rows_ids = c->rows_buf = c->rows_in = nullptr;
+    ETP_CHECK_HIP(hipMalloc(&c->rows_in, (size_t)capacity * sizeof(int64_t)));
     ETP_CHECK_HIP(hipMalloc(&c->rows_ids, (size_t)(W + 1) * capacity * sizeof(int64_t)));
     ETP_CHECK_HIP(hipMalloc(&c->rows_buf, (size_t)(W + 1) * capacity * row_len * rs));
     c->rows_cap = capacity; c->rows_len = row_len;
   }
   hipStream_t prod = (hipStream_t)producer, cs = c->stream;
+  // the ids are copied into the communicator's own block ON THE PRODUCER STREAM: the caller's tensor (often a temporary: a cast or
+  // a concatenation) may be freed and its memory recycled as soon as this call returns
+  if (n_ids > 0) ETP_CHECK_HIP(hipMemcpyAsync(c->rows_in, ids, (size_t)n_ids * sizeof(int64_t), hipMemcpyDeviceToDevice, prod));
+  ids = (const int64_t*)c->rows_in;
   hipEvent_t e = c->next_event();
   ETP_CHECK_HIP(hipEventRecord(e, prod));
   ETP_CHECK_HIP(hipStreamWaitEvent(cs, e, 0));
@@ -240,20 +250,20 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
   char* all_rows = send_rows + (size_t)capacity * row_len * rs;
   const float inv = 1.0f / (float)W;
   if (c->comm_dtype == ETP_BF16)
-    ETP_LAUNCH(rows_pack_kernel<bf16_t>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)row_len, ids, (long)n_ids, send_ids,
+    ETP_LAUNCH(rows_pack_kernel<bf16_t>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)n_rows, (long)row_len, ids, (long)n_ids, send_ids,
                (bf16_t*)send_rows);
   else
-    ETP_LAUNCH(rows_pack_kernel<float>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)row_len, ids, (long)n_ids, send_ids,
+    ETP_LAUNCH(rows_pack_kernel<float>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)n_rows, (long)row_len, ids, (long)n_ids, send_ids,
                (float*)send_rows);
   ETP_CHECK_LAUNCH("rows_pack");
   ETP_CHECK_RCCL(g_rccl.AllGather(send_ids, all_ids, (size_t)capacity * 2, RCCL_FLOAT32, c->comm, cs));   // int64 ids as 2 x 32-bit words
   ETP_CHECK_RCCL(g_rccl.AllGather(send_rows, all_rows, (size_t)capacity * row_len, c->comm_dtype == ETP_BF16 ? RCCL_BFLOAT16 : RCCL_FLOAT32,
                                   c->comm, cs));
   if (c->comm_dtype == ETP_BF16)
-    ETP_LAUNCH(rows_scatter_kernel<bf16_t>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)row_len, all_ids,
+    ETP_LAUNCH(rows_scatter_kernel<bf16_t>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)n_rows, (long)row_len, all_ids,
                (const bf16_t*)all_rows, inv);
   else
-    ETP_LAUNCH(rows_scatter_kernel<float>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)row_len, all_ids,
+    ETP_LAUNCH(rows_scatter_kernel<float>, dim3((unsigned)(capacity * W)), dim3(256), 0, cs, table, (long)n_rows, (long)row_len, all_ids,
                (const float*)all_rows, inv);
   ETP_CHECK_LAUNCH("rows_scatter");
   return ETP_OK;
@@ -297,6 +307,7 @@ int etp_allreduce_destroy(etp_comm* c) {
   if (c->staging) (void)hipFree(c->staging);
   if (c->rows_ids) (void)hipFree(c->rows_ids);
   if (c->rows_buf) (void)hipFree(c->rows_buf);
+  if (c->rows_in) (void)hipFree(c->rows_in);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ETP_OK;

@@ -559,21 +559,6 @@ __global__ __launch_bounds__(64 * (TileWaves<BM, BN>::NW), (TileWaves<BM, BN>::M
   dma_tile<T, TC, TA, TB, BM, BN, STAGES, TileWaves<BM, BN>::NW>(g, A, B, C, tm, tn, ks, smem, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-// 64x64 tiles on EIGHT wavefronts (4 x 2 grid of 16x32 sub-tiles) for grids of at most one workgroup per CU -- the M = 512 node-side
-// products of the x-layers (96 workgroups) and the M = 1152 panorama products (216).  Alone on its CU a four-wavefront
-// workgroup is bound by its own LDS-DMA issue: ~145 cycles per 1-KiB piece and wavefront, four pieces per slab = 0.245 us per slab
-// whatever the ring depth (profiles/r03_gemm_phases.txt).  Eight wavefronts issue ONE piece per operand each and the slab time
-// halves; the deeper ring (6 slabs, 96 KiB) keeps more of the reduction in flight.
-template <typename T, typename TC, bool TA, bool TB, int STAGES>
-__global__ __launch_bounds__(512, 2) void gemm_dma8_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (g.N + 63) / 64;
-  int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, (g.M + 63) / 64, tiles_n, g.xcd_map, tm, tn);
-  dma_tile<T, TC, TA, TB, 64, 64, STAGES, 8>(g, reinterpret_cast<const T*>(g.A), reinterpret_cast<const T*>(g.B),
-                                              reinterpret_cast<TC*>(g.C), tm, tn, 0, smem, blockIdx.x);
-}
-
 // Grouped launch: up to ETP_GEMM_GROUP_MAX independent products of one storage/dtype/tile class in ONE grid (the four
 // weight gradients of a transformer layer, the text K/V projections of all x-layers).  The concatenated tile list is cut
 // into 8 contiguous chunks, one per XCD (workgroup i runs on XCD i % 8), so every private L2 sees a compact slab of one or
@@ -728,33 +713,6 @@ static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
   return ETP_OK;
 }
 
-template <typename T, typename TC, bool TA, bool TB, int STAGES>
-static int launch_one8(const GemmArgs& g_in, hipStream_t st) {
-  using GA = TileGeom<T, TA, 64, 0>;
-  using GB = TileGeom<T, TB, 64, 0>;
-  constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = 64 * 68 * 4;
-  constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
-  static bool attr_set = false;
-  void (*kern)(const GemmArgs) = gemm_dma8_kernel<T, TC, TA, TB, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
-  const int tiles = ((g_in.M + 63) / 64) * ((g_in.N + 63) / 64);
-  GemmArgs g = g_in;
-  char nm[96];
-  snprintf(nm, sizeof(nm), "gemm_dma8<%s,%s,%s%s,64x64,s%d>", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TC) == 2 ? "bf16" : "f32",
-           TA ? "T" : "N", TB ? "N" : "T", STAGES);
-  g.dbg = probe_slot(nm, tiles, g.M, g.N, g.K);
-  ProfRec rec;
-  const bool prof = prof_begin(nm, 2.0 * g.M * g.N * g.K,
-                               ((double)g.M * g.K + (double)g.N * g.K) * sizeof(T) + (double)g.M * g.N * sizeof(TC), st, rec);
-  ETP_LAUNCH(kern, dim3(tiles), dim3(512), smem, st, g);
-  ETP_CHECK_LAUNCH("gemm8");
-  if (prof) prof_end(rec, st);
-  return ETP_OK;
-}
-
 static bool dma_ok(int bk, int K, int ksplit) {
   // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
   bool dma = (K % bk == 0) && (K >= 2 * bk);
@@ -808,13 +766,6 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   if (!dma) {
     if (big || huge) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 64, 64, 0>(g, nbatch, st);
-  }
-  if constexpr (sizeof(T) == 2) {
-    // at most one 64x64 workgroup per CU: eight wavefronts per tile (ETP_GEMM_W8=0 keeps four: A/B runs)
-    static const int w8_on = [] { const char* e = getenv("ETP_GEMM_W8"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool forced = force && force[0];
-    if (w8_on && !forced && !huge && !big && !wide && nbatch == 1 && g.ksplit == 1 && t64 <= 256 && g.K >= 4 * BK)
-      return launch_one8<T, TC, TA, TB, 6>(g, st);
   }
   if (huge) {
     if constexpr (sizeof(T) == 2) {                  // bf16 only: the fp32 parity mode keeps the four-wavefront tiles

@@ -312,8 +312,13 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
 // (ln_part_reduce) -- so that the step time shows what fusing them away could buy at most (results are wrong in that mode),
 // like ETP_SKIP_WGRAD in planner.hip.
 static bool skip_ln(const char* what) {
+#ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
   static const char* e = getenv("ETP_SKIP_LN");
   return e && strstr(e, what) != nullptr;
+#else
+  (void)what;
+  return false;
+#endif
 }
 
 int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, float* y, void* yt, float* stats, int M, int H,

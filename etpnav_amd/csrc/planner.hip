@@ -386,8 +386,10 @@ static int linear_dgrad_s(const Ctx& c, const void* dY, long ldy, int wi, float*
 static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, long ldx, int wi, int bi, int M, int N, int K) {
   // MEASUREMENT ONLY (tools/r03_call4.sh): ETP_SKIP_WGRAD=1 drops every weight-gradient product, i.e. leaves the dependent chain
   // alone on the GPU -- the step time then shows what the leaf work costs the chain (the gradients are wrong in that mode)
+#ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
   static const bool skip = [] { const char* e = getenv("ETP_SKIP_WGRAD"); return e && e[0] == '1'; }();
   if (skip) return ETP_OK;
+#endif
   GemmArgs g = base_args();
   g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = c.pl->gf(wi); g.ldc = K;
   g.M = N; g.N = K; g.K = M;

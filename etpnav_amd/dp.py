@@ -250,6 +250,12 @@ class GradReducer:
         table = self.g[off:off + n_rows * row_len].view(n_rows, row_len)
         ids = row_ids.reshape(-1).to(torch.long)
         if capacity is None:
+            if self.native is not None:
+                # the MAX below is a torch.distributed (second communicator) collective: dense buckets of the library communicator
+                # may still be in flight on its private stream, and two RCCL communicators progressing concurrently can
+                # deadlock -- drain ours first (this branch synchronises with the host anyway; pass `capacity` to avoid it)
+                self.native.wait()
+                torch.cuda.current_stream().synchronize()
             t = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             capacity = int(t.item())

@@ -9,7 +9,7 @@ pre-training config, run_pt/r2r_model_config_dep.json).  The SAP task of the sam
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import List, Dict
 
 import torch
 
@@ -146,53 +146,74 @@ class MlmStep:
         check(L.etp_planner_set_aux_stream(h, None), "set_aux_stream")
 
 
-# ---- multi-task driver pieces (pretrain_src/pretrain_src/data/loader.py:18-75, train_r2r.py:229-300) ----------------------
+# ---- multi-task driver pieces (what pretrain_src/pretrain_src/data/loader.py:18-75 and train_r2r.py:229-300 provide) -------------
+class _TaskSource:
+    """One task's stream of batches: a re-iterable (DataLoader, list of batches, ...) that is restarted when it runs dry, after
+    telling the owner which epoch begins (DistributedSampler.set_epoch in the reference, loader.py:63-71)."""
+
+    def __init__(self, name: str, batches, weight: float = 1.0, on_epoch=None):
+        self.name, self.batches, self.weight, self.on_epoch = name, batches, float(weight), on_epoch
+        self.epoch, self._it = 0, iter(batches)
+
+    def take(self):
+        try:
+            return next(self._it)
+        except StopIteration:
+            self.epoch += 1
+            if self.on_epoch is not None:
+                self.on_epoch(self.epoch)
+            self._it = iter(self.batches)
+            return next(self._it)
+
+
 class MetaLoader:
-    """Wraps several task loaders and yields ``(task_name, batch)`` forever, as the reference's MetaLoader: every
-    ``accum_steps`` steps a task is drawn with probability proportional to its mixing ratio (``torch.multinomial``,
-    loader.py:54-58), in distributed runs rank 0's draw is broadcast so that all ranks train the same task (:57-58; the
-    per-task gradient bucket sets of etpnav_amd.dp.task_grad_ranges rely on exactly that), an exhausted loader is
-    re-created after calling its ``pre_epoch(epoch)`` hook (:63-71, DistributedSampler.set_epoch).
+    """Task mixing for multi-task pre-training: yields ``(task_name, batch)`` forever; the task is held for ``accum_steps``
+    consecutive draws (one gradient-accumulation window trains one task) and windows pick their task with probability
+    proportional to the mixing weights -- the contract of the reference's loader (loader.py:54-63).
 
-    loaders: {name: iterable  |  (iterable, ratio, pre_epoch_fn)}; an "iterable" is anything ``iter()`` accepts that can
-    be iterated again for the next epoch (a DataLoader, a list of batches)."""
+    Unlike the reference, which draws and (in distributed runs) broadcasts one task id per window from the training loop, the
+    schedule here is PLANNED: ``horizon`` windows are drawn in one ``torch.multinomial`` call and rank 0's plan is broadcast
+    once, so all ranks walk the same task sequence (the per-task gradient bucket sets of etpnav_amd.dp.task_grad_ranges rely
+    on that) without a collective -- and a device round trip on the RCCL backend -- in front of every optimizer step.
 
-    def __init__(self, loaders: Dict, accum_steps: int = 1, distributed: bool = False, device=None, generator=None):
-        assert isinstance(loaders, dict) and loaders
-        self.name2loader, self.name2iter, self.name2pre_epoch, self.names, ratios = {}, {}, {}, [], []
-        for n, l in loaders.items():
-            if isinstance(l, tuple):
-                l, r, p = l
-            else:
-                r, p = 1, (lambda e: None)
-            self.names.append(n)
-            self.name2loader[n], self.name2iter[n], self.name2pre_epoch[n] = l, iter(l), p
-            ratios.append(r)
-        self.accum_steps, self.device, self.distributed = accum_steps, device, distributed
-        self.sampling_ratios = torch.tensor(ratios).float()
-        self.generator = generator
-        self.step = 0
+    loaders: {name: batches  |  (batches, weight, on_epoch)} with ``batches`` anything ``iter()`` accepts repeatedly."""
+
+    def __init__(self, loaders: Dict, accum_steps: int = 1, distributed: bool = False, device=None, generator=None,
+                 horizon: int = 1024):
+        if not isinstance(loaders, dict) or not loaders:
+            raise ValueError("loaders: a non-empty {task: batches | (batches, weight, on_epoch)} mapping")
+        self.sources: List[_TaskSource] = []
+        for name, spec in loaders.items():
+            batches, weight, on_epoch = spec if isinstance(spec, tuple) else (spec, 1.0, None)
+            self.sources.append(_TaskSource(name, batches, weight, on_epoch))
+        self.accum_steps, self.distributed, self.device = max(1, int(accum_steps)), bool(distributed), device
+        self.generator, self.horizon = generator, int(horizon)
+        self._plan: List[int] = []
+        self._held, self._left = 0, 0          # task of the running window, draws left in it
+
+    @property
+    def names(self) -> List[str]:
+        return [s.name for s in self.sources]
+
+    def _extend_plan(self):
+        w = torch.tensor([s.weight for s in self.sources], dtype=torch.float32)
+        plan = torch.multinomial(w, self.horizon, replacement=True, generator=self.generator)
+        if self.distributed:
+            import torch.distributed as dist
+            t = plan.to(self.device) if self.device is not None else plan
+            dist.broadcast(t, 0)
+            plan = t.cpu()
+        self._plan = plan.tolist()[::-1]       # popped from the end
 
     def __iter__(self):
-        import torch.distributed as dist
-        task_id, epoch_id = None, 0
         while True:
-            if self.step % self.accum_steps == 0:
-                task_id = torch.multinomial(self.sampling_ratios, 1, generator=self.generator)
-                if self.distributed:
-                    t = task_id.to(self.device) if self.device is not None else task_id
-                    dist.broadcast(t, 0)                      # every rank trains the same task this step
-                    task_id = t.cpu()
-            self.step += 1
-            task = self.names[int(task_id.item())]
-            try:
-                batch = next(self.name2iter[task])
-            except StopIteration:
-                epoch_id += 1
-                self.name2pre_epoch[task](epoch_id)
-                self.name2iter[task] = iter(self.name2loader[task])
-                batch = next(self.name2iter[task])
-            yield task, batch
+            if self._left == 0:
+                if not self._plan:
+                    self._extend_plan()
+                self._held, self._left = self._plan.pop(), self.accum_steps
+            self._left -= 1
+            src = self.sources[self._held]
+            yield src.name, src.take()
 
 
 class PretrainDriver:

@@ -110,18 +110,21 @@ def compare_grads_bf16(z, grads):
     return worst_s, worst_l
 
 
-def compare_full_bf16(mine, ref, skip_prefix="__input__"):
-    """Full-tensor check of a bf16-mode gradient set against oracle gradients: relative L2 error and cosine per tensor."""
+def compare_full_bf16(mine, ref, skip_prefix="__input__", rel=None, cos_min=None):
+    """Full-tensor check of a bf16-mode gradient set against oracle gradients: relative L2 error and cosine per tensor.
+    rel / cos_min default to the B <= 2 fixture bounds (12 % / 0.99); the benchmarked shapes pass their own, tighter ones
+    (tests/test_baseline_shapes_gpu.py: set from the observed worst tensors, profiles/r04_parity_bf16_observed.txt)."""
+    BF16_FULL_REL_, BF16_COS_MIN_ = (BF16_FULL_REL if rel is None else rel), (BF16_COS_MIN if cos_min is None else cos_min)
     worst_r, worst_c = (0.0, ""), (1.0, "")
     for k, g in ref.items():
         if k.startswith(skip_prefix):
             continue
         a, b = mine[k].detach().double().cpu().reshape(-1), g.detach().double().cpu().reshape(-1)
         nb, d = float(b.norm()), float((a - b).norm())
-        assert d <= BF16_FULL_REL * nb + BF16_ABS_FLOOR, f"grad {k}: ||err|| {d:.3e} > {BF16_FULL_REL} * ||ref|| {nb:.3e}"
+        assert d <= BF16_FULL_REL_ * nb + BF16_ABS_FLOOR, f"grad {k}: ||err|| {d:.3e} > {BF16_FULL_REL_} * ||ref|| {nb:.3e}"
         if nb > 1e-3:
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
-            assert cos >= BF16_COS_MIN, f"grad {k}: cosine {cos:.5f} < {BF16_COS_MIN}"
+            assert cos >= BF16_COS_MIN_, f"grad {k}: cosine {cos:.5f} < {BF16_COS_MIN_}"
             worst_c = min(worst_c, (cos, k))
             worst_r = max(worst_r, (d / nb, k))
     return worst_r, worst_c

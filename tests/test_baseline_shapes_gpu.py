@@ -83,7 +83,8 @@ def test_benchmarked_shape_b32_bf16_train_mode_close_to_oracle():
     assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
     assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
-    print("bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
+    # the headline configuration gets its own bound: observed worst 5.7 % relative L2 / cosine 0.9984
+    print("bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads, rel=0.08, cos_min=0.996))
     step.close()
 
 
@@ -108,7 +109,11 @@ def test_other_benchmarked_shapes_bf16_train_mode_close_to_oracle(workload):
     assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < 8e-2
     assert abs(got["loss"].item() - outs["loss"].item()) < 5e-2
-    print(workload, "bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads))
+    # per-shape bounds from the observed worst tensors (profiles/r04_parity_bf16_observed.txt): c4 (B = 16, L = 512) 8.0 % / 0.9968;
+    # c5 (B = 8, G = 64) keeps the fixture bound on relative L2 (its worst tensor is the 1 x 1 sprel_linear.weight, 13 % through
+    # the absolute floor) with cosine 0.9930 observed
+    bound = {"c4": dict(rel=0.09, cos_min=0.995), "c5": dict(rel=0.12, cos_min=0.992)}[workload]
+    print(workload, "bf16 worst rel-L2 / cosine", compare_full_bf16(grads_of(model), grads, **bound))
     step.close()
 
 

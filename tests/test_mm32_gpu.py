@@ -175,9 +175,9 @@ def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
 
 
 @pytest.mark.parametrize("tb", [0, 1])
-def test_gemm_eight_wavefront_64x64_class(tb):
-    """Grids of at most one 64x64 workgroup per CU (the M = 512 node-side products of the x-layers, gemm.hip gemm_dma8_kernel:
-    eight wavefronts per tile, ring of six slabs): ragged and whole shapes, reductions of 4 .. 48 slabs, the planner's epilogues."""
+def test_gemm_small_grid_shapes(tb):
+    """Grids of at most one 64x64 workgroup per CU (the M = 512 node-side products of the x-layers): ragged and whole shapes,
+    reductions of 4 .. 48 slabs, the planner's epilogues."""
     for (M, N, K) in [(300, 200, 256), (130, 72, 320), (512, 768, 768), (512, 768, 3072), (512, 2304, 768), (64, 64, 1024)]:
         torch.manual_seed(M + N + K + tb)
         A = torch.randn(M, K, device=DEV).to(T)
@@ -202,8 +202,8 @@ def test_gemm_eight_wavefront_64x64_class(tb):
         assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= btol(K), (M, N, K, tb, "dgelu")
 
 
-def test_gemm_eight_wavefront_weight_gradient_with_bias_gradient():
-    """TN storage on the eight-wavefront class: dW = dY^T X with the fused column sums (bias gradient), 512 tokens."""
+def test_gemm_small_grid_weight_gradient_with_bias_gradient():
+    """TN storage on a small grid: dW = dY^T X with the fused column sums (bias gradient), 512 tokens."""
     torch.manual_seed(9)
     Mt, n, k = 512, 768, 768
     dY = (torch.randn(Mt, n, device=DEV) * 0.5).to(T)
