@@ -323,7 +323,7 @@ def main():
     # `achieved` / `frac` use the IN-STEP duration: event pairs on the kernel's own launch stream while the step runs with its
     # real three-stream schedule (the dominant kernel is the grouped weight-gradient GEMM, a leaf on the weight-gradient
     # stream: its pairs bracket the launch including whatever the dependent chain takes from it -- the figure rocprofv3's
-    # per-kernel average of the same command reports, profiles/r03_bench_kernel_stats.csv).  `achieved_isolated` is the same
+    # per-kernel average of the same command reports, profiles/r04_bench_kernel_stats.csv).  `achieved_isolated` is the same
     # kernel with the step replayed on ONE stream (nothing else resident).  VERDICT r2 weak #5: round 2 printed only the latter.
     roofline, gemm_table = None, []
     peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
@@ -361,7 +361,7 @@ def main():
             if dom is not None:
                 # second in-step pass that brackets ONLY the dominant kernel's launches: with every GEMM bracketed the ~330
                 # event packets per step share the three queues with the kernels and stretch each bracket (86.8 us against
-                # 69.9 us for this kernel in rocprofv3's trace of the same command, profiles/r03_bench_kernel_stats.csv)
+                # 69.9 us for this kernel in rocprofv3's trace of the same command, profiles/r04_bench_kernel_stats.csv)
                 step.close()
                 step = PlannerStep(model, batch, overlap=True, dropout="config" if args.mode == "train" else None, drop_seed=rank)
                 L.etp_prof_filter(d["kernel"].encode())
@@ -420,19 +420,19 @@ def main():
                                 "compare rocprof_avg_launch_us); the event brackets also hold the queue's wait for the other two "
                                 "streams' packets, so `achieved` is the conservative figure"}
             # rocprofv3's view of the same kernel in the same command (committed trace summary), for the cross-check
-            ks = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+            ks = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")
             if args.workload == "c2" and args.dtype == "bf16" and os.path.exists(ks):
                 import csv
                 from tools.pmc_sq import short as _short
                 for r in csv.DictReader(open(ks)):
                     if _short(r["Name"]) == d["kernel"]:
                         roofline["rocprof_avg_launch_us"] = round(float(r["AverageNs"]) * 1e-3, 2)
-                        roofline["rocprof_source"] = ("profiles/r03_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this "
+                        roofline["rocprof_source"] = ("profiles/r04_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this "
                                                       "command on this round's binary, committed -- not re-measured in this run")
                         break
             # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
             # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on the weight-shadow cast: tools/pmc_traffic.py)
-            pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
             if args.workload == "c2" and args.dtype == "bf16" and os.path.exists(pmc):
                 try:
                     doc = json.load(open(pmc))
@@ -440,7 +440,7 @@ def main():
                     ent = doc["kernels"].get(d["kernel"]) or doc["kernels"].get(key)
                     if ent and ent.get("hbm_bytes_per_launch"):
                         roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
-                        roofline["traffic_source"] = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                        roofline["traffic_source"] = ("profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                                       "this command on this round's binary (tools/pmc_traffic.py), committed -- not "
                                                       "re-measured in this run")
                 except (ValueError, KeyError):
@@ -468,6 +468,27 @@ def main():
                      "roofline": {"bound": "hbm", "achieved": round(obytes / (oms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": round(obytes / (oms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
                      "note": "not part of `value`; replaces torch AdamW + the next step's weight cast and gradient memset"}
+        # whole training iteration as a trainer would run it (ss_trainer_ETP.py:504-506: backward, optimizer step): the fused
+        # optimizer hands the next step fresh bf16 shadows and a zeroed gradient arena, so that step skips its own cast / memset
+        if world == 1 and micro == 1 and not use_graph and args.mode == "train":
+            try:
+                step.close()
+            except Exception:
+                pass
+            step = PlannerStep(model, batch, overlap=True, dropout="config", drop_seed=rank, refresh_weights=False, zero_grads=False)
+            for _ in range(3):
+                step.run_eager(); opt.step()
+            torch.cuda.synchronize()
+            nit = 20
+            e0.record()
+            for _ in range(nit):
+                step.run_eager(); opt.step()
+            e1.record(); torch.cuda.synchronize()
+            ims = e0.elapsed_time(e1) / nit
+            optimizer["train_iteration"] = {"ms": round(ims, 4), "iterations_per_s": round(1e3 / ims, 2),
+                                            "note": "fwd + bwd + fused AdamW per iteration, 20 iterations back to back on the same batch "
+                                                    "(weights move); the step runs with refresh_weights=False, zero_grads=False "
+                                                    "because the optimizer kernel already wrote the shadows and zeroed the arena"}
     if rank == 0:
         fl = flops_per_step(w, cfg)
         # whole-step roofline: t_roof = sum over the step's kernels of max(flops/peak_mfma, bytes/peak_hbm),

@@ -68,6 +68,15 @@ __device__ __forceinline__ DmaOp dma_setup(const bf16_t* base, long ld, int row0
     d.sbase = reinterpret_cast<const char*>(base + (long)row0 * ld + k0);
     d.piece_stride = 32 * ld * 2;
     d.slab_stride = 128;
+  } else if constexpr (ROWS == 256) {
+    // [k][512 B]: piece p holds k-rows 2p, 2p+1; lane -> k-row 2p + (lane >> 5), physical chunk lane & 31.  Same swizzle as the
+    // 128-row tile (bits 2..3 of the chunk index ^= k & 3): it stays inside one 256-byte half of the k-row
+    const int kr = 2 * wave + (lane >> 5);
+    const int cc = (lane & 31) ^ ((kr & 3) << 2);
+    d.voff = (unsigned)(((long)kr * ld + cc * 8) * 2);
+    d.sbase = reinterpret_cast<const char*>(base + (long)k0 * ld + row0);
+    d.piece_stride = 8 * ld * 2;
+    d.slab_stride = 64 * ld * 2;
   } else if constexpr (ROWS == 128) {
     // [k][256 B]: piece p holds k-rows 4p .. 4p+3; lane -> k-row 4p + (lane >> 4), physical chunk lane & 15
     const int kr = 4 * wave + (lane >> 4);
@@ -118,7 +127,7 @@ __device__ __forceinline__ unsigned frag_rel(int base_rc /*first row (col) of th
     const int q = lane >> 4, i = lane & 15;
     const int kr = 8 * (q >> 1) + (i >> 2);
     const int col = base_rc + 16 * (q & 1) + 4 * (i & 3);
-    const int swz = ROWS == 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
+    const int swz = ROWS >= 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
     return (unsigned)(kr * G::PITCH + (((col >> 3) ^ swz) << 4) + (col & 7) * 2);
   }
 }
@@ -140,6 +149,14 @@ __device__ __forceinline__ bf16x8_t frag_ld(unsigned slab_addr /*LDS byte addres
 template <int FM, int FN> struct Frags { bf16x8_t a[FM], b[FN]; };
 
 // One BM x BN output tile.  4 wavefronts in a 2 x 2 grid, wavefront tile (BM/2) x (BN/2) = FM x FN fragments of 32 x 32.
+// Three shapes: 128x128 and 128x64 (64x64 / 64x32 per wavefront, two workgroups per CU) and 256x128 (128x64 per wavefront, one
+// workgroup per CU, 128 accumulator registers).  Per k16-step a 64x64 wavefront tile reads 4 KiB of fragments for 4 MFMAs: with
+// two workgroups resident that is 128 B/clk per CU, half of the LDS's best rate (256 B/clk for ds_read_b128 / b64; b64 reads,
+// which ds_read_b64_tr_b16 is, reach it only from ~4 wavefronts per SIMD: MI355X_MICROARCH.md, LDS), and the MFMA-only build
+// of the grouped weight gradient already takes 43 us of the full kernel's 51 (profiles/r04a_mm32_probe_mfma_only.json): the
+// wavefronts' own read + MFMA stream, not the DMA, sets most of the loop time.  A 128x64 wavefront tile reads 6 KiB for
+// 8 MFMAs (96 B/clk per CU) and the 256x128 tile moves 25 % fewer L2 bytes per FLOP, but its single wavefront per SIMD
+// exposes every LDS latency: it only wins on reductions of >= 4096 rows (mm32_group_class below).
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const bf16_t* B, TC* C, int tm, int tn, char* smem, int rec) {
   using GA = Op<TA, BM>;
@@ -148,7 +165,7 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
   constexpr int STAGE = GA::BYTES + GB::BYTES;
   constexpr int NPA = GA::NPW, NPB = GB::NPW, NP = NPA + NPB;          // DMA pieces per wavefront per slab
   constexpr int NMMA = FM * FN;                                        // MFMAs per k16-step
-  static_assert(FM == 2 && (FN == 1 || FN == 2), "wavefront tiles: 64x64 or 64x32");
+  static_assert((FM == 2 && (FN == 1 || FN == 2)) || (FM == 4 && FN == 2), "wavefront tiles: 64x64, 64x32 or 128x64");
   static_assert(STAGES == 2 || STAGES == 3, "ring of two or three slabs");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,7 +232,7 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
 #pragma unroll
         for (int e = 0; e < KPT; ++e) {
           const int kr = kg + e * KG;
-          const int swz = BM == 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
+          const int swz = BM >= 128 ? ((kr & 3) << 2) : (((kr >> 1) & 1) << 2);
           const u32x4_t w = *reinterpret_cast<lds_u4_t>(slot_base + (unsigned)(kr * GA::PITCH + ((cc ^ swz) << 4)));
           const uint4 v = make_uint4(w.x, w.y, w.z, w.w);
           float f[8];
@@ -272,7 +289,12 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
 // one k16-step: MFMAs of set X alternate with the fragment reads of set Y (k16-step ks of the slab at sa / sb); DMA pieces
 // D .. D + NMMA - 1 of the refill (if any are left) ride behind the MFMAs
 #define ETP_STEP(X, Y, sa, sb, ks, ON, D)                                              \
-  if constexpr (FN == 2) {                                                             \
+  if constexpr (FM == 4) {                                                             \
+    ETP_LDA(Y, 0, sa, ks) ETP_MMA(X, 0, 0) ETP_DMA(ON, (D)) ETP_LDB(Y, 0, sb, ks) ETP_MMA(X, 0, 1) ETP_DMA(ON, (D) + 1)         \
+    ETP_LDB(Y, 1, sb, ks) ETP_MMA(X, 1, 0) ETP_DMA(ON, (D) + 2) ETP_LDA(Y, 1, sa, ks) ETP_MMA(X, 1, 1) ETP_DMA(ON, (D) + 3)     \
+    ETP_LDA(Y, 2, sa, ks) ETP_MMA(X, 2, 0) ETP_DMA(ON, (D) + 4) ETP_LDA(Y, 3, sa, ks) ETP_MMA(X, 2, 1) ETP_DMA(ON, (D) + 5)     \
+    ETP_MMA(X, 3, 0) ETP_DMA(ON, (D) + 6) ETP_MMA(X, 3, 1) ETP_DMA(ON, (D) + 7)                                                 \
+  } else if constexpr (FN == 2) {                                                      \
     /* reads in the order the next step consumes them: (a0, b0) (a0, b1) (a1, b0) (a1, b1) */                                  \
     ETP_LDA(Y, 0, sa, ks) ETP_MMA(X, 0, 0) ETP_DMA(ON, (D)) ETP_LDB(Y, 0, sb, ks) ETP_MMA(X, 0, 1) ETP_DMA(ON, (D) + 1)         \
     ETP_LDB(Y, 1, sb, ks) ETP_MMA(X, 1, 0) ETP_DMA(ON, (D) + 2) ETP_LDA(Y, 1, sa, ks) ETP_MMA(X, 1, 1) ETP_DMA(ON, (D) + 3)     \
@@ -280,7 +302,7 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
     ETP_LDA(Y, 0, sa, ks) ETP_MMA(X, 0, 0) ETP_DMA(ON, (D)) ETP_LDB(Y, 0, sb, ks) ETP_MMA(X, 1, 0) ETP_DMA(ON, (D) + 1)         \
     ETP_LDA(Y, 1, sa, ks)                                                              \
   }
-  constexpr int HS = FN == 2 ? 3 : 2;                                   // DMA pieces that ride in the hand-over itself
+  constexpr int HS = FM == 4 ? 5 : (FN == 2 ? 3 : 2);                   // DMA pieces that ride in the hand-over itself
 // k16-steps 0 .. 2 of the slab at (sa, sb) (set P holds step 0), then the first MFMAs of step 3
 #define ETP_SLAB_STEPS(sbase_, sa, sb, ON)                   \
   ETP_STEP(P, Q, sa, sb, 1, ON, HS)                          \
@@ -288,14 +310,21 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
   ETP_STEP(Q, P, sa, sb, 2, ON, HS + NMMA)                   \
   ETP_STEP(P, Q, sa, sb, 3, ON, HS + 2 * NMMA)               \
   ETP_MMA(Q, 0, 0)                                           \
-  if constexpr (FN == 2) { ETP_MMA(Q, 0, 1) }
+  if constexpr (FN == 2) { ETP_MMA(Q, 0, 1) }                \
+  if constexpr (FM == 4) { ETP_MMA(Q, 1, 0) ETP_MMA(Q, 1, 1) }
 // hand-over into the slab at (na, nb): first fragments of its step 0 and the remaining MFMAs of the previous slab's step 3
 #define ETP_HANDOVER(na, nb, ON)                             \
-  ETP_LDA(P, 0, na, 0) ETP_DMA(ON, 0) ETP_LDB(P, 0, nb, 0)   \
-  ETP_MMA(Q, 1, 0) ETP_DMA(ON, 1)                            \
-  if constexpr (FN == 2) { ETP_LDB(P, 1, nb, 0) }            \
-  ETP_LDA(P, 1, na, 0)                                       \
-  if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) ETP_DMA(ON, 2) }
+  if constexpr (FM == 4) {                                   \
+    ETP_LDA(P, 0, na, 0) ETP_DMA(ON, 0) ETP_LDB(P, 0, nb, 0) ETP_MMA(Q, 2, 0) ETP_DMA(ON, 1)                      \
+    ETP_LDB(P, 1, nb, 0) ETP_MMA(Q, 2, 1) ETP_DMA(ON, 2) ETP_LDA(P, 1, na, 0) ETP_MMA(Q, 3, 0) ETP_DMA(ON, 3)     \
+    ETP_LDA(P, 2, na, 0) ETP_MMA(Q, 3, 1) ETP_DMA(ON, 4) ETP_LDA(P, 3, na, 0)                                     \
+  } else {                                                   \
+    ETP_LDA(P, 0, na, 0) ETP_DMA(ON, 0) ETP_LDB(P, 0, nb, 0) \
+    ETP_MMA(Q, 1, 0) ETP_DMA(ON, 1)                          \
+    if constexpr (FN == 2) { ETP_LDB(P, 1, nb, 0) }          \
+    ETP_LDA(P, 1, na, 0)                                     \
+    if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) ETP_DMA(ON, 2) } \
+  }
 #define ETP_ITER(ON, WAIT)                                                                                \
   {                                                                                                       \
     WAIT;                              /* slab t landed; at most the slab behind it still in flight */    \
@@ -330,8 +359,12 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
       ETP_ITER(false, wait_vm<0>())
     }
   }
-  ETP_MMA(Q, 1, 0)                  // second half of the last slab's last step
-  if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) }
+  if constexpr (FM == 4) {          // second half of the last slab's last step
+    ETP_MMA(Q, 2, 0) ETP_MMA(Q, 2, 1) ETP_MMA(Q, 3, 0) ETP_MMA(Q, 3, 1)
+  } else {
+    ETP_MMA(Q, 1, 0)
+    if constexpr (FN == 2) { ETP_MMA(Q, 1, 1) }
+  }
 #undef ETP_ITER
 #undef ETP_HANDOVER
 #undef ETP_SLAB_STEPS
@@ -384,7 +417,7 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
 }
 
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, 2) void kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 1 : 2)) void kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, g.M / BM, g.N / BN, g.xcd_map, tm, tn);
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void kernel(const GemmArgs g) {
 
 // Grouped launch (the weight gradients of one transformer layer): same tile list order as gemm.hip's gemm_group_kernel.
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, 2) void group_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 1 : 2)) void group_kernel(const GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x, nwg = gridDim.x;
   int id = bid;
@@ -537,6 +570,29 @@ bool mm32_group_ok(const GemmGroup& grp) {
   }
   return t >= 100 || mm32_mode() == 128;
 }
-int launch_mm32_group(GemmGroup& grp, hipStream_t st) { return mm32::launch_group<float, true, true, 128, 128, 2>(grp, st); }
+// 256x128 tiles (one workgroup per CU, 128x64 per wavefront) when every problem is whole 256x128 tiles, the reduction is long
+// enough to pay for a tile that has the CU to itself (no second workgroup covers its fill, its epilogue and -- with one
+// wavefront per SIMD -- the latency of its ds_read_b64_tr_b16 fragment reads) and the list still covers most of the chip.
+// Measured (tools/experiments/r04_group_class_probe.py, one text layer's four products, us per launch, 128x128 / 256x128):
+// 512 tokens 18.1 / 24.6, 1152: 29.0 / 34.4, 2560: 51.4 / 61.8, 8192: 148.8 / 143.5 -- only the 8192-token reductions of
+// BASELINE config 4 take it.  ETP_MM32_GROUP=128 / 256 forces a class (tests, A/B runs).
+static int mm32_group_class(const GemmGroup& grp) {
+  const char* e = getenv("ETP_MM32_GROUP");
+  const int force = e ? atoi(e) : 0;
+  if (force == 128) return 128;
+  long t = 0;
+  int kmin = 1 << 30;
+  for (int i = 0; i < grp.n; ++i) {
+    if (!mm32::eligible(grp.g[i], 256, 128)) return 128;
+    t += (long)(grp.g[i].M / 256) * (grp.g[i].N / 128);
+    kmin = grp.g[i].K < kmin ? grp.g[i].K : kmin;
+  }
+  if (force == 256) return 256;
+  return (kmin >= 4096 && t >= 160) ? 256 : 128;
+}
+int launch_mm32_group(GemmGroup& grp, hipStream_t st) {
+  if (mm32_group_class(grp) == 256) return mm32::launch_group<float, true, true, 256, 128, 3>(grp, st);
+  return mm32::launch_group<float, true, true, 128, 128, 2>(grp, st);
+}
 
 }  // namespace etp

@@ -146,6 +146,44 @@ def test_mm32_grouped_text_layer_weight_gradients(mode, monkeypatch):
             assert (db - refb).abs().max().item() <= 2e-3 * math.sqrt(Mt), (mode, out_mode, "bias", tuple(dW.shape))
 
 
+@pytest.mark.parametrize("Mt", [128, 192, 320, 1152, 2560])
+def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, monkeypatch):
+    """The 256x128 class of the grouped weight gradient (128x64 per wavefront, one workgroup per CU, ring of three slabs), forced
+    for every token count: reductions of 2 .. 40 slabs, stores and accumulates, fused bias gradients, against fp32 torch and --
+    bit for bit across three runs and within fp32 summation-order noise -- against the 128x128 class."""
+    torch.manual_seed(Mt)
+    H, I = 768, 3072
+    specs = [(3 * H, H), (H, H), (I, H), (H, I), (256, 128)]
+    dYs = [(torch.randn(Mt, n, device=DEV) * 0.5).to(T) for n, _ in specs]
+    Xs = [torch.randn(Mt, k, device=DEV).to(T) for _, k in specs]
+    out = {}
+    for cls in ("256", "128"):
+        monkeypatch.setenv("ETP_MM32_GROUP", cls)
+        for out_mode in (0, 1):
+            first = None
+            for it in range(3 if cls == "256" else 1):
+                torch.manual_seed(7 + out_mode)
+                dWs = [torch.randn(n, k, device=DEV) for n, k in specs]
+                dbs = [torch.zeros(n, device=DEV) for n, _ in specs]
+                w0 = [w.clone() for w in dWs]
+                run_group([wgrad_desc(dY, X, dW, db, out_mode) for dY, X, dW, db in zip(dYs, Xs, dWs, dbs)])
+                if first is None:
+                    first = [w.clone() for w in dWs]
+                    for dY, X, dW, db, w in zip(dYs, Xs, dWs, dbs, w0):
+                        ref = dY.float().t() @ X.float()
+                        if out_mode == 1:
+                            ref = ref + w
+                        assert (dW - ref).abs().max().item() <= 2e-3 * math.sqrt(Mt), (cls, out_mode, tuple(dW.shape))
+                        assert (db - dY.float().sum(0)).abs().max().item() <= 2e-3 * math.sqrt(Mt), (cls, out_mode, "bias", tuple(dW.shape))
+                else:
+                    for a, b in zip(dWs, first):
+                        assert torch.equal(a, b), (cls, out_mode, it, tuple(a.shape))
+            out[(cls, out_mode)] = first
+    for out_mode in (0, 1):
+        for a, b in zip(out[("256", out_mode)], out[("128", out_mode)]):
+            assert (a - b).abs().max().item() <= 1e-4 * math.sqrt(Mt), (out_mode, tuple(a.shape))
+
+
 @pytest.mark.parametrize("cls", ["128", "64"])
 def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
     """12 runs of the same products while a bandwidth-heavy copy loop on a second stream perturbs the DMA timing on every other

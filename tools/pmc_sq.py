@@ -46,6 +46,13 @@ def short(kernel: str) -> str:
         tr = "TN" if (ta and tb) else ("NN" if tb else "NT")
         st = f",s{a[6]}" if len(a) > 6 else ""
         return f"gemm{m.group(1) or ''}<{t},{tc},{tr},{a[4]}x{a[5]}{st}>"
+    m = re.search(r"mm32::(group_)?kernel<([^>]*)>", kernel)        # gemm_mm32.hip: <TC, TA, TB, BM, BN, STAGES>, operands always bf16
+    if m:
+        a = [x.strip() for x in m.group(2).split(",")]
+        tc = "f32" if "float" in a[0] else "bf16"
+        ta, tb = a[1] == "true", a[2] == "true"
+        tr = "TN" if (ta and tb) else ("NN" if tb else "NT")
+        return f"mm32{'_group' if m.group(1) else ''}<bf16,{tc},{tr},{a[3]}x{a[4]},s{a[5]}>"
     m2 = re.search(r"(\w+_kernel)\s*<", kernel) or re.search(r"::(\w+_kernel)", kernel) or re.search(r"(\w+_kernel)", kernel)
     return m2.group(1) if m2 else kernel[:48]
 

@@ -25,16 +25,12 @@ csv.field_size_limit(1 << 30)
 
 
 def bench_name(kernel: str):
-    m = re.search(r"gemm(_dma|_group)?_kernel<([^>]*)>", kernel)
-    if not m:
-        m2 = re.search(r"(\w+_kernel)<", kernel) or re.search(r"::(\w+_kernel)", kernel) or re.search(r"(\w+_kernel)", kernel)
-        return m2.group(1) if m2 else kernel[:60]
-    a = [x.strip() for x in m.group(2).split(",")]
-    t = "bf16" if "short" in a[0] else "f32"
-    tc = "bf16" if "short" in a[1] else "f32"
-    ta, tb = a[2] == "true", a[3] == "true"
-    tr = "TN" if (ta and tb) else ("NN" if tb else "NT")
-    return f"gemm{m.group(1) or ''}<{t},{tc},{tr},{a[4]}x{a[5]}>"
+    """Short kernel class name as bench.py prints it, without the ring-depth suffix (one traffic row per tile class)."""
+    try:
+        from tools.pmc_sq import short
+    except ImportError:                                   # run as a script from tools/
+        from pmc_sq import short
+    return re.sub(r",s\d+>$", ">", short(kernel))
 
 
 def load(path, counter):
