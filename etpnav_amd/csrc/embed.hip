@@ -965,6 +965,46 @@ int copy_f32(const float* src, float* dst, long n, hipStream_t st) {
   ETP_CHECK_LAUNCH("copy_f32");
   return ETP_OK;
 }
+// dst[t][i] = src[i], t < T  (16-byte vectors): the text K|V cache of Bt instructions replicated for T stacked rollout steps
+__global__ __launch_bounds__(256) void repeat_block_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16, int T) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+    const uint4 v = src[i];
+    for (int t = 0; t < T; ++t) dst[(long)t * n16 + i] = v;
+  }
+}
+int repeat_block(const void* src, void* dst, long bytes, int T, hipStream_t st) {
+  if (bytes <= 0 || T <= 0) return ETP_OK;
+  ETP_REQUIRE(bytes % 16 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "repeat_block: 16-byte aligned blocks required");
+  const long n16 = bytes / 16;
+  const int grid = (int)std::min<long>((n16 + 255) / 256, 4096);
+  ETP_LAUNCH(repeat_block_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16, T);
+  ETP_CHECK_LAUNCH("repeat_block");
+  return ETP_OK;
+}
+// dst[i] = sum_t src[t][i] accumulated in fp32 (4 elements per thread and iteration; n % 4 == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_steps_kernel(const T* __restrict__ src, T* __restrict__ dst, long n, int steps) {
+  const long n4 = n / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < steps; ++t) {
+      float v[4];
+      load4(src + (long)t * n + i * 4, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += v[e];
+    }
+    store4(dst + i * 4, a);
+  }
+}
+int sum_steps(int dtype, const void* src, void* dst, long n, int steps, hipStream_t st) {
+  if (n <= 0) return ETP_OK;
+  ETP_REQUIRE(n % 4 == 0 && steps > 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "sum_steps: n % 4 == 0 and 16-byte aligned buffers");
+  const int grid = (int)std::min<long>((n / 4 + 255) / 256, 4096);
+  if (dtype == ETP_BF16) ETP_LAUNCH(sum_steps_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n, steps);
+  else ETP_LAUNCH(sum_steps_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n, steps);
+  ETP_CHECK_LAUNCH("sum_steps");
+  return ETP_OK;
+}
 int scale_f32(float* p, long n, float scale, hipStream_t st) {
   if (n <= 0) return ETP_OK;
   const int grid = (int)std::min<long>((n + 255) / 256, 4096);

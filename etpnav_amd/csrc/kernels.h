@@ -67,6 +67,8 @@ int vocab_ce(int dtype, const float* logits, const int64_t* labels, float* loss,
              hipStream_t st);
 int gelu_bwd_inplace(int dtype, void* d, const void* z, long n, hipStream_t st);
 int zero_f32(float* dst, long n, hipStream_t st);
+int repeat_block(const void* src, void* dst, long bytes, int T, hipStream_t st);            // dst[t][.] = src[.], t < T
+int sum_steps(int dtype, const void* src, void* dst, long n, int steps, hipStream_t st);   // dst[i] = sum_t src[t][i], fp32 accumulation
 
 // optim.hip: fused AdamW (+ bf16 shadow refresh + gradient zeroing) and the gradient norm / non-finite scan
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,

@@ -1229,6 +1229,26 @@ int etp_nav_kv_fwd(etp_planner* p, const float* txt, int B, int L, void* kvbuf, 
     ETP_TRY(linear_fwd(c, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, kc.kv[l], 2 * H, Mt, 2 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
   return ETP_OK;
 }
+// Batched rollout on the cache (forward_navigation_steps stacks T steps along the batch axis, episode t*Bt + b reads
+// instruction b): replicate every K|V block of the Bt-instruction cache T times into a cache laid out for T*Bt episodes --
+// a copy instead of T re-projections of the same text rows (the text block of the destination is not written: the cached entry
+// points never read it) -- and the reduction of the stacked call's d_kv over the T steps for etp_nav_kv_bwd.
+int etp_nav_kv_repeat(etp_planner* p, const void* kvbuf, int Bt, int L, int T, void* kvbuf_steps, etp_stream_t stream) {
+  ETP_REQUIRE(p && kvbuf && kvbuf_steps && Bt > 0 && L > 0 && T > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  KvCache src = plan_kv(p, const_cast<void*>(kvbuf), Bt, L), dst = plan_kv(p, kvbuf_steps, T * Bt, L);
+  const long blk = (long)Bt * L * 2 * c.H * (long)c.es;
+  for (int l = 0; l < p->cfg.n_x; ++l) ETP_TRY(repeat_block(src.kv[l], dst.kv[l], blk, T, c.st));
+  return ETP_OK;
+}
+int etp_nav_kv_sum_steps(etp_planner* p, const void* d_kv_steps, int Bt, int L, int T, void* d_kv, etp_stream_t stream) {
+  ETP_REQUIRE(p && d_kv_steps && d_kv && Bt > 0 && L > 0 && T > 0, "bad arguments");
+  Ctx c = make_ctx(p, stream);
+  const long n = (long)Bt * L * 2 * c.H;
+  for (int l = 0; l < p->cfg.n_x; ++l)
+    ETP_TRY(sum_steps(c.dt, offs(d_kv_steps, (long)l * T * n, c.es), offs(d_kv, (long)l * n, c.es), n, T, c.st));
+  return ETP_OK;
+}
 // d_kv: [n_x][B*L][2H] in the operand dtype = the SUM over the rollout's steps of what etp_nav_bwd_kv returned
 int etp_nav_kv_bwd(etp_planner* p, const float* txt, const void* d_kv, int B, int L, const void* kvbuf, float* d_txt,
                    etp_stream_t stream) {

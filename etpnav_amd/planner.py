@@ -297,6 +297,32 @@ class _NavKVFn(torch.autograd.Function):
         return None, None, d_txt
 
 
+class _NavKVStepsFn(torch.autograd.Function):
+    """K|V of Bt instructions -> the cache of T stacked rollout steps (episode t*Bt + b reads instruction b):
+    etp_nav_kv_repeat forward, etp_nav_kv_sum_steps backward (the sum over the steps that the reference's shared txt_embeds
+    tensor accumulates through autograd, ss_trainer_ETP.py:819-822,1055)."""
+
+    @staticmethod
+    def forward(ctx, eng: Engine, kv, Bt: int, L: int, T: int):
+        n_x, _, H2 = kv.shape
+        es = kv.element_size()
+        src = ctypes.c_void_p(kv.data_ptr() - int(eng.L.etp_nav_kv_offset(eng.handle, Bt, L)))
+        cache = eng.buf(eng.L.etp_nav_kv_bytes(eng.handle, T * Bt, L))
+        check(eng.L.etp_nav_kv_repeat(eng.handle, src, Bt, L, T, ptr(cache), eng.stream()), "etp_nav_kv_repeat")
+        off = int(eng.L.etp_nav_kv_offset(eng.handle, T * Bt, L))
+        out = cache[off:off + n_x * T * Bt * L * H2 * es].view(kv.dtype).view(n_x, T * Bt * L, H2)
+        ctx.eng, ctx.dims, ctx.kv_shape = eng, (Bt, L, T), kv.shape
+        return out                       # a view into `cache` (keeps the buffer alive), laid out for etp_nav_fwd_kv with B = T*Bt
+
+    @staticmethod
+    def backward(ctx, d_kv_steps):
+        eng, (Bt, L, T) = ctx.eng, ctx.dims
+        d_kv_steps = d_kv_steps.to(eng.tdtype).contiguous()
+        d_kv = torch.empty(ctx.kv_shape, dtype=eng.tdtype, device=eng.device)
+        check(eng.L.etp_nav_kv_sum_steps(eng.handle, ptr(d_kv_steps), Bt, L, T, ptr(d_kv), eng.stream()), "etp_nav_kv_sum_steps")
+        return None, d_kv, None, None, None
+
+
 class _NavCachedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, eng: Engine, drop, kv, L, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
@@ -361,6 +387,7 @@ class GlocalTextPathNavCMT(nn.Module):
         # masks from a counter-based generator keyed by (seed, call counter, site, element)
         # text K/V cache across rollout steps; off = the reference's per-step re-projection
         self.cache_text_kv = False
+        self.batch_steps_kv = True        # forward_navigation_steps: project the text keys/values once, not T times
         self._kv_cache = None
         self.drop_env_prob = 0.0          # >0 fuses the policy's drop_env (Policy_ViewSelection_ETP.py:102,345) into forward_panorama
         self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -551,8 +578,14 @@ class GlocalTextPathNavCMT(nn.Module):
 
         steps: list of dicts with gmap_step_ids [B,G_t], gmap_img_fts [B,G_t,H], gmap_pos_fts [B,G_t,7], gmap_masks [B,G_t],
         gmap_visited_masks [B,G_t], gmap_pair_dists [B,G_t,G_t].  Returns a list of {'gmap_embeds', 'global_logits'} per step,
-        sliced back to G_t.  (The text K/V projections are recomputed for the T * B * L stacked rows: large, efficient GEMMs,
-        like the reference's own per-step re-projection; cache_text_kv does not apply to this call.)"""
+        sliced back to G_t.
+
+        Text keys/values (self.batch_steps_kv, default on): the K|V projections of the B instructions are computed ONCE
+        (etp_nav_kv_fwd, shared with cache_text_kv's per-step calls), replicated for the T stacked steps by a copy
+        (etp_nav_kv_repeat) and their gradient is summed over the steps (etp_nav_kv_sum_steps) before ONE projection back to
+        the text (etp_nav_kv_bwd) -- instead of projecting T * B * L stacked text rows forward and backward in every x-layer,
+        which is the re-projection of vilmodel_cmt.py:326-328 the reference repeats per step.  batch_steps_kv = False keeps
+        the stacked re-projection (same results up to the rounding of the summed bf16 key/value gradients)."""
         T = len(steps)
         if T == 0:
             return []
@@ -570,10 +603,26 @@ class GlocalTextPathNavCMT(nn.Module):
             return x
 
         cat = lambda key, dims, value=0: torch.cat([pad(st[key], dims, value) for st in steps], dim=0)
-        out = self.forward_navigation(txt_embeds.repeat(T, 1, 1), txt_masks.repeat(T, 1), None,
-                                      cat("gmap_step_ids", (1,)), cat("gmap_img_fts", (1,)), cat("gmap_pos_fts", (1,)),
-                                      cat("gmap_masks", (1,), False), cat("gmap_visited_masks", (1,), False),
-                                      cat("gmap_pair_dists", (1, 2)))
+        if self.batch_steps_kv and int(_cfg_get(self.config, "num_x_layers", 4)) > 0:
+            eng = self._prep()
+            t = torch.float32
+            L = txt_embeds.shape[1]
+            kv = self._text_kv(eng, txt_embeds)
+            kv_steps = _NavKVStepsFn.apply(eng, kv, B, L, T)
+            embeds, logits = _NavCachedFn.apply(self._anchor, eng, self._dropout(), kv_steps, L,
+                                                txt_masks.to(torch.bool).repeat(T, 1).contiguous(),
+                                                cat("gmap_step_ids", (1,)).long().contiguous(),
+                                                cat("gmap_img_fts", (1,)).to(t).contiguous(),
+                                                cat("gmap_pos_fts", (1,)).float().contiguous(),
+                                                cat("gmap_masks", (1,), False).to(torch.bool).contiguous(),
+                                                cat("gmap_visited_masks", (1,), False).to(torch.bool).contiguous(),
+                                                cat("gmap_pair_dists", (1, 2)).float().contiguous())
+            out = {"gmap_embeds": embeds, "global_logits": logits}
+        else:
+            out = self.forward_navigation(txt_embeds.repeat(T, 1, 1), txt_masks.repeat(T, 1), None,
+                                          cat("gmap_step_ids", (1,)), cat("gmap_img_fts", (1,)), cat("gmap_pos_fts", (1,)),
+                                          cat("gmap_masks", (1,), False), cat("gmap_visited_masks", (1,), False),
+                                          cat("gmap_pair_dists", (1, 2)))
         res = []
         for t, g in enumerate(Gs):
             res.append({"gmap_embeds": out["gmap_embeds"][t * B:(t + 1) * B, :g],

@@ -351,6 +351,14 @@ int64_t etp_nav_kv_offset(const etp_planner* p, int B, int L);   /* byte offset 
 int etp_nav_kv_fwd(etp_planner* p, const float* txt_embeds, int B, int L, void* kv_cache, etp_stream_t stream);
 int etp_nav_kv_bwd(etp_planner* p, const float* txt_embeds, const void* d_kv, int B, int L, const void* kv_cache,
                    float* d_txt_embeds /*[B,L,H], overwritten*/, etp_stream_t stream);
+/* The cache under the batched rollout call (T steps stacked along the batch axis, episode t*Bt + b reads instruction b; the
+ * reference re-projects the same instruction at every step, ss_trainer_ETP.py:819-822 -> vilmodel_cmt.py:326-328):
+ *   etp_nav_kv_repeat     K|V blocks of a Bt-instruction cache replicated T times into a cache sized for T*Bt episodes
+ *                         (etp_nav_kv_bytes(p, T*Bt, L)) -- a copy in place of T projections of the same rows
+ *   etp_nav_kv_sum_steps  d_kv of the stacked call [n_x][T*Bt*L][2H] summed over the steps (fp32 accumulation) into
+ *                         [n_x][Bt*L][2H], the operand of etp_nav_kv_bwd */
+int etp_nav_kv_repeat(etp_planner* p, const void* kv_cache, int Bt, int L, int T, void* kv_cache_steps, etp_stream_t stream);
+int etp_nav_kv_sum_steps(etp_planner* p, const void* d_kv_steps, int Bt, int L, int T, void* d_kv, etp_stream_t stream);
 int etp_nav_fwd_kv(etp_planner* p, const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
                    const float* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
                    const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G, float* gmap_embeds,

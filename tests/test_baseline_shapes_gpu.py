@@ -163,13 +163,16 @@ def _hip_rollout_batched(model, ids, masks, steps):
     return {"txt_embeds": txt.detach(), "loss": loss.detach(), "steps": [{k: v.detach() for k, v in o.items()} for o in outs]}
 
 
+@pytest.mark.parametrize("kv", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_batched_rollout_steps_match_reference_golden(dtype):
+def test_batched_rollout_steps_match_reference_golden(dtype, kv):
     """forward_navigation_steps (second half): the T = 3 steps of the REAL reference's rollout fixture as ONE
     (T * B)-episode navigation call -- outputs of every step and all parameter gradients (text encoder included: the sum over
-    the steps) against the reference."""
+    the steps) against the reference.  kv: text keys/values projected once and replicated for the stacked steps
+    (etp_nav_kv_repeat / etp_nav_kv_sum_steps) vs the T-fold stacked re-projection."""
     z, cfg, P, ids, masks, steps = load_rollout()
     model = build_model(cfg, P, dtype)
+    model.batch_steps_kv = kv
     dsteps = [{k: v.cuda() for k, v in st.items()} for st in steps]
     outs = _hip_rollout_batched(model, ids.cuda(), masks.cuda(), dsteps)
     if dtype == torch.float32:
@@ -180,7 +183,8 @@ def test_batched_rollout_steps_match_reference_golden(dtype):
         print("batched rollout bf16", compare_grads_bf16(z, grads_of(model)))
 
 
-def test_batched_rollout_with_growing_graphs_equals_per_step_calls():
+@pytest.mark.parametrize("kv", [True, False])
+def test_batched_rollout_with_growing_graphs_equals_per_step_calls(kv):
     """Steps whose graphs have DIFFERENT node counts (the topological map grows during an episode): the batched call pads
     them to the largest count; every step's outputs on its own nodes and every gradient must equal the per-step calls."""
     cfg = po.PlannerConfig.r2r(vocab_size=2048)
@@ -195,6 +199,7 @@ def test_batched_rollout_with_growing_graphs_equals_per_step_calls():
         bt["gmap_img_fts"] = torch.randn(B, G, cfg.hidden_size, generator=gen) * 0.5
         steps.append({k: v.cuda() for k, v in bt.items() if k.startswith("gmap_") or k == "labels"})
     model = build_model(cfg, P, torch.float32)
+    model.batch_steps_kv = kv
     a = _hip_rollout(model, ids, masks, steps)
     ga = grads_of(model)
     b = _hip_rollout_batched(model, ids, masks, steps)

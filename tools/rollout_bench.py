@@ -4,7 +4,9 @@ Three ways of issuing the same work (identical outputs and gradients: tests/test
     per_step        forward_navigation once per step, text K/V re-projected every call  (what the trainer does:
                     ss_trainer_ETP.py:819-822,878 then one backward over the summed losses, :1055)
     per_step_kv     the same with cache_text_kv (one projection of the text K/V serves all T steps)
-    batched         forward_navigation_steps: the T steps as one (T * B)-episode call
+    batched_reproject  forward_navigation_steps with batch_steps_kv = False: the T steps as one (T * B)-episode call that
+                    projects the T-fold stacked text rows to keys/values in every x-layer (round 3's form)
+    batched         forward_navigation_steps: the same call on the K/V cache (one projection, replicated by a copy)
 
     python tools/rollout_bench.py [--B 8] [--L 80] [--T 5,10,15] [--G 16] [--dtype bf16] [--iters 20]
 Prints one JSON object (ms per episode fwd+bwd, episodes/s) -> profiles/r03_rollout_bench.json.
@@ -26,7 +28,8 @@ from etpnav_amd.synthetic import make_batch  # noqa: E402
 def episode(model, ids, masks, steps, how):
     model.zero_grad()
     txt = model.forward_txt(ids, masks)
-    if how == "batched":
+    if how.startswith("batched"):
+        model.batch_steps_kv = how == "batched"          # "batched_reproject": the T-fold stacked K/V projection (round 3)
         outs = model.forward_navigation_steps(txt, masks, steps)
     else:
         outs = [model.forward_navigation(txt, masks, None, st["gmap_step_ids"], st["gmap_img_fts"], st["gmap_pos_fts"],
@@ -64,7 +67,7 @@ def main():
             b["gmap_img_fts"] = torch.randn(a.B, G, cfg.hidden_size, generator=gen) * 0.5
             steps.append({k: v.cuda() for k, v in b.items() if k.startswith("gmap_") or k == "labels"})
         row = {"T": T, "B": a.B, "L": a.L, "G_last": a.G}
-        for how in ("per_step", "per_step_kv", "batched"):
+        for how in ("per_step", "per_step_kv", "batched_reproject", "batched"):
             model.cache_text_kv = how == "per_step_kv"
             for _ in range(3):
                 episode(model, ids, masks, steps, how)
@@ -77,6 +80,7 @@ def main():
             row[how + "_ms"] = round(ms, 3)
         row["batched_speedup_vs_per_step"] = round(row["per_step_ms"] / row["batched_ms"], 2)
         row["batched_speedup_vs_per_step_kv"] = round(row["per_step_kv_ms"] / row["batched_ms"], 2)
+        row["batched_speedup_vs_reproject"] = round(row["batched_reproject_ms"] / row["batched_ms"], 2)
         rows.append(row)
     print(json.dumps({"what": "rollout episode fwd+bwd through the module API, wall clock incl. host (one MI355X)",
                       "dtype": a.dtype, "mode": a.mode, "iters": a.iters, "rows": rows}))
