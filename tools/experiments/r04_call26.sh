@@ -18,7 +18,7 @@ rm -rf $O/prof
 P="--steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --no-roofline"
 (cd /tmp && $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pf -o p -- python $R/bench.py $P > /dev/null 2> $R/$O/pf.err)
 (cd /tmp && $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pw -o p -- python $R/bench.py $P > /dev/null 2> $R/$O/pw.err)
-python tools/pmc_traffic.py $O/pf/p_counter_collection.csv $O/pw/p_counter_collection.csv --cast-elems 38961152 --out $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+python tools/pmc_traffic.py $O/pf/p_counter_collection.csv $O/pw/p_counter_collection.csv --cast-elems 36601856 --out $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json
 rm -rf $O/pf $O/pw
 # 4. SQ counters

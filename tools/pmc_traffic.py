@@ -13,6 +13,9 @@ panorama / navigation part of the matrix region, all on the capped 4096-block gr
 the MEAN element count of those launches = etp_planner_matrix_elems / 3 (38 961 152 for the config-2 model).  The
 factor known_bytes / counter_value of that kernel is applied to every other kernel of the same pass.  Round-1 result:
 2048 B per FETCH_SIZE unit (KB, under-reported 2x on wide reads, as the guide says) and 1024 B per WRITE_SIZE unit.
+Since round 3 the text cast is split (layer 0 on the main stream, a smaller grid): the three largest-grid launches cover
+n_matrix minus layer 0's elements, so --cast-elems = (116 883 456 - 7 077 888) / 3 = 36 601 856 for the config-2 model.
+Check of any calibration: a kernel with a known output (the 2560 x 768 fp32 stream products: 7.86 MB) must read back its size.
 """
 import argparse
 import csv
