@@ -767,6 +767,18 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
     if (big || huge) return launch_one<T, TC, TA, TB, 128, 128, 0>(g, nbatch, st);
     return launch_one<T, TC, TA, TB, 64, 64, 0>(g, nbatch, st);
   }
+  if constexpr (sizeof(T) == 2 && !TA) {
+    // 32x64 tiles (four wavefronts of 16x32, ring 4) for grids that would give fewer than half the CUs a 64x64 workgroup -- the
+    // M = 512 node-side products of the x-layers (96 -> 192 workgroups) and everything of config 5.  A lone workgroup's slab
+    // time is set by its own wait -> barrier -> read -> MFMA chain (0.24 us per 64x64x64 slab whatever the ring depth or the
+    // wavefront count, profiles/r04_gemm_phases.txt), not by bytes: halving the tile rows doubles the workgroups that share
+    // the reduction's work at (nearly) the same time per slab.  A row-major only (its 32-row slab is four 1-KiB DMA pieces).
+    // ETP_GEMM_SMALL=0 switches the class off (A/B runs), ETP_GEMM_TILE=32 forces it.
+    static const int small_on = [] { const char* e = getenv("ETP_GEMM_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool forced = force && force[0];
+    const bool take = forced ? force[0] == '3' : (small_on && nbatch == 1 && g.ksplit == 1 && t64 <= 128 && g.M >= 32 && g.K >= 4 * BK);
+    if (take) return launch_one<T, TC, TA, TB, 32, 64, 4>(g, nbatch, st);
+  }
   if (huge) {
     if constexpr (sizeof(T) == 2) {                  // bf16 only: the fp32 parity mode keeps the four-wavefront tiles
       if (stages == 3) return launch_one<T, TC, TA, TB, 256, 128, 3>(g, nbatch, st);
