@@ -37,7 +37,7 @@ def btol(K):
 
 @pytest.mark.parametrize("cls", ["128", "64"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("K", [128, 192, 320, 768])
+@pytest.mark.parametrize("K", [128, 192, 256, 320, 384, 768])
 def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, monkeypatch):
     """Plain products (fp32 and bf16 C), reductions of 2, 3, 5 and 12 slabs: ring fill / drain paths of both ring depths."""
     monkeypatch.setenv("ETP_MM32", cls)

@@ -52,7 +52,8 @@ def short(kernel: str) -> str:
         tc = "f32" if "float" in a[0] else "bf16"
         ta, tb = a[1] == "true", a[2] == "true"
         tr = "TN" if (ta and tb) else ("NN" if tb else "NT")
-        return f"mm32{'_group' if m.group(1) else ''}<bf16,{tc},{tr},{a[3]}x{a[4]},s{a[5]}>"
+        spi = "x2" if len(a) > 6 and a[6] == "2" else ""      # slabs per hand-over (absent in builds before it existed)
+        return f"mm32{'_group' if m.group(1) else ''}<bf16,{tc},{tr},{a[3]}x{a[4]},s{a[5]}{spi}>"
     m2 = re.search(r"(\w+_kernel)\s*<", kernel) or re.search(r"::(\w+_kernel)", kernel) or re.search(r"(\w+_kernel)", kernel)
     return m2.group(1) if m2 else kernel[:48]
 

@@ -33,7 +33,7 @@ def bench_name(kernel: str):
         from tools.pmc_sq import short
     except ImportError:                                   # run as a script from tools/
         from pmc_sq import short
-    return re.sub(r",s\d+>$", ">", short(kernel))
+    return re.sub(r",s\d+(x2)?>$", ">", short(kernel))
 
 
 def load(path, counter):
