@@ -20,7 +20,7 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
 // part != NULL: two-stage dgamma/dbeta reduction -- the kernel writes per-block column sums to `part`
 // (ln_bwd_part_bytes(M, H) bytes) and the caller issues ln_part_reduce(part, M, H, dgamma, dbeta) anywhere later (it is a
 // leaf of the backward graph); part == NULL: per-block atomics straight into dgamma / dbeta.
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 1024;
 size_t ln_bwd_part_bytes(int M, int H);
 int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx,
              void* dxt, float* dgamma, float* dbeta, int M, int H, hipStream_t st, Drop drop = drop_none(), float* part = nullptr);

@@ -332,7 +332,7 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
   return ETP_OK;
 }
 // number of workgroups ln_bwd_s launches for M rows (= slabs of the two-stage reduction): every wave gets the same number
-// of rows, at most LN_BWD_MAX_BLOCKS blocks (>= 2 per CU at M = 2560)
+// of rows, at most LN_BWD_MAX_BLOCKS blocks (one row per wavefront up to 4096 rows: 640 blocks at M = 2560; round 4, was 512 / two rows per wavefront)
 static int ln_bwd_blocks(int M) {
   const int groups = (M + 3) / 4;
   static const int cap = [] { const char* e = getenv("ETP_LNBWD_GRID"); return e ? std::max(1, atoi(e)) : LN_BWD_MAX_BLOCKS; }();
