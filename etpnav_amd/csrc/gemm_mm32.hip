@@ -100,7 +100,9 @@ __device__ __forceinline__ DmaOp dma_setup(const bf16_t* base, long ld, int row0
 
 // One LDS-DMA piece (1 KiB).  Inline asm on purpose: with the builtin hipcc drains the DMA (vmcnt(0)) before the next LDS
 // read; hidden here it stays in flight and is retired by our own counted s_waitcnt vmcnt + s_barrier.  M0 (LDS byte address of
-// the piece, wave-uniform) is written in the statement that consumes it.
+// the piece, wave-uniform) is written in the statement that consumes it.  M0 is neither saved nor declared clobbered: it is a
+// reserved register on this target (hipcc rejects it on a clobber list and writes it itself immediately in front of each
+// instruction of its own that reads it), and these kernels contain no compiler-generated M0 use to share a value with.
 __device__ __forceinline__ void glds(unsigned voff, const char* sbase, unsigned lds_addr) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
