@@ -360,8 +360,8 @@ def main():
             dom_all = dom
             if dom is not None:
                 # second in-step pass that brackets ONLY the dominant kernel's launches: with every GEMM bracketed the ~330
-                # event packets per step share the three queues with the kernels and stretch each bracket (86.8 us against
-                # 69.9 us for this kernel in rocprofv3's trace of the same command, profiles/r04_bench_kernel_stats.csv)
+                # event packets per step share the three queues with the kernels and stretch each bracket (round 3: 86.8 us
+                # against 69.9 us for this kernel in rocprofv3's trace; round 4: 67.8 against 55-60, profiles/r04_bench_kernel_stats.csv)
                 step.close()
                 step = PlannerStep(model, batch, overlap=True, dropout="config" if args.mode == "train" else None, drop_seed=rank)
                 L.etp_prof_filter(d["kernel"].encode())
