@@ -345,3 +345,9 @@ def test_bench_self_launches_two_ranks_on_one_device():
         r = json.loads(line)
         assert r["n_gpus"] == 2 and r["scaling"] == scaling and r["config"]["global_batch"] == gb, r["config"]
         assert r["config"]["ranks_seen"] == 2 and r["value"] > 0
+        # the fields a scaling curve is read with: exposed communication time from device-side stamps, payload
+        # per rank and step, bucket count, transport dtype (bf16 by default in the bf16 mode)
+        c = r["comm"]
+        assert c is not None and c["exposed_ms"] >= 0.0 and c["buckets"] >= 10 and c["dtype"] == "bf16" and c["row_sparse_table"]
+        assert c["dense_bytes"] > 100e6 and c["bytes_per_step"] >= c["dense_bytes"], c
+        assert r["config"]["grad_comm_dtype"] == "bf16"
