@@ -12,7 +12,8 @@ for f in planner capi graphrec comm; do
 done
 wait
 # kernels' translation units un-instrumented (their host side is launch stubs only)
+# (object list from etpnav_amd/build.py SOURCES, so a new translation unit cannot be forgotten here)
+REST=$(python -c "from etpnav_amd.build import SOURCES; print(' '.join('etpnav_amd/build/' + s.replace('.hip', '.o') for s in SOURCES if s.replace('.hip', '') not in ('planner', 'capi', 'graphrec', 'comm')))")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o $OUT/libetpnav_hip_asan.so \
-    $OUT/planner.o $OUT/capi.o $OUT/graphrec.o $OUT/comm.o etpnav_amd/build/gemm.o etpnav_amd/build/attn.o etpnav_amd/build/attn_rows.o etpnav_amd/build/norm.o \
-    etpnav_amd/build/embed.o etpnav_amd/build/optim.o etpnav_amd/build/graph.o
+    $OUT/planner.o $OUT/capi.o $OUT/graphrec.o $OUT/comm.o $REST
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ETP_ASAN_LIB=$OUT/libetpnav_hip_asan.so python tools/asan_host_driver.py

@@ -32,13 +32,18 @@ for kw in (dict(), dict(task_type="rxr"), dict(use_lang2visn_attn=True), dict(nu
         assert L.etp_planner_bind(h, None, None, None) != 0                      # null arenas refused
         assert L.etp_txt_fwd(h, None, None, 2, 3, None, None, None) != 0         # unbound / null arguments refused
         assert L.etp_planner_set_dropout(h, 0.1, 0.1, 0.1, 0.4, 123) == 0 and L.etp_planner_set_dropout(h, 1.5, 0, 0, 0, 0) != 0
+        # round 4 entry points: the K/V cache under the batched rollout call and the stamp ring refuse null / empty arguments
+        assert L.etp_nav_kv_repeat(h, None, 2, 3, 4, None, None) != 0 and L.etp_nav_kv_sum_steps(h, None, 2, 3, 4, None, None) != 0
+        assert L.etp_nav_kv_bytes(h, 4 * 2, 3) >= L.etp_nav_kv_bytes(h, 2, 3)
+        assert L.etp_nav_kv_grad_elems(h, 2, 3) == c.n_x * 2 * 3 * 2 * c.hidden
         L.etp_planner_destroy(h)
         n_ok += 1
 out = (ctypes.c_float * 4096)()
 assert L.etp_dropout_multipliers(0.1, 77, 1, 3, 2, 4096, out) == 0
 kept = sum(1 for v in out if v > 0)
 assert 3500 < kept < 3900
-assert L.etp_ln_bwd_part_bytes(2560, 768) > 0
+assert L.etp_ln_bwd_part_bytes(2560, 768) == 640 * 2 * 768 * 4           # one row per wavefront: 640 slabs of [2][H] fp32
+assert L.etp_stamp_count() == 0                                           # no sink installed: marks are no-ops
 bad = _lib.Config()
 assert not L.etp_planner_create(ctypes.byref(bad)) and b"unsupported" in L.etp_last_error()
 # explicit-graph recorder bookkeeping without a device: begin/abort must not leak or double free
