@@ -152,6 +152,9 @@ def main():
                     help="data-parallel path: the text encoder's weight gradients are reduced in this many layer groups (last "
                          "layers first), each as soon as its backward is enqueued (9 = one ~28 MB bucket per layer, DDP's bucket size class; the count "
                          "costs the chain nothing: 3 / 5 / 9 groups all run at 4.29-4.31 ms on one GPU, profiles/r03_ab_runs.json c25)")
+    ap.add_argument("--settle", type=int, default=30,
+                    help="untimed clock-settle steps in front of the warm-up (default 30; the two-rank functional test passes 2: "
+                         "every step there moves the whole gradient arena through gloo on the host)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -266,7 +269,7 @@ def main():
 
     # clock settle: the boxes idle at ~450 MHz and ramp under load; a few untimed steps in front of the W warm-up steps keep a
     # short --warmup from timing the ramp (disclosed in config.settle_steps; not part of W or K)
-    settle = 30
+    settle = max(0, args.settle)
     for _ in range(settle):
         one_step()
     barrier()

@@ -338,7 +338,8 @@ def test_bench_self_launches_two_ranks_on_one_device():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     for scaling, gb in (("weak", 64), ("strong", 32)):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device",
-                              "--steps", "2", "--warmup", "1", "--scaling", scaling], env=env, capture_output=True, text=True,
+                              "--steps", "2", "--warmup", "1", "--settle", "2", "--scaling", scaling], env=env, capture_output=True,
+                             text=True,
                              timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
