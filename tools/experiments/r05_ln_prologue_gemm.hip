@@ -13,7 +13,10 @@
 //   loop      B (the weight) streams through the LDS-DMA ring as in gemm.hip's dma_tile; A fragments come from the resident
 //             panel (no A traffic in the loop at all);
 //   epilogue  the shared fused epilogue (bias, GELU + saved pre-activation, ReLU, ...).
-// The B ring is issued before the prologue, so the weight's first slabs land while the rows are normalised.
+// The B ring is issued before the prologue so that the weight's first slabs could land while the rows are normalised -- but
+// KNOWN LIMIT of this first form: vmcnt retires in order, so the compiler's own wait for the first row's loads (younger than the
+// ring's DMA pieces) also waits for the whole ring; the overlap only exists for rows 2.. of a wavefront.  To try on the GPU:
+// issue the first rows' loads in front of the ring, or count the waits by hand (inline-asm loads).
 // Cost model: the panel costs BM x 3 KiB of fp32 reads per workgroup (96 KiB at BM = 32, from L2: the producer just wrote it),
 // repeated by the N/BN column tiles; at M = 512 that is 12-48 x 1.5 MB = 19-75 MB of L2 reads per launch against one
 // launch + one boundary saved (4 + 3 us).  NOT for the M = 2560 text products (they are feed-bound).
