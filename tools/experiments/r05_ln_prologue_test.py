@@ -30,7 +30,57 @@ def build():
                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
                               ctypes.c_int, ctypes.c_void_p]
+    P.r05_ln_bwd_gemm.restype = ctypes.c_int
+    P.r05_ln_bwd_gemm.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                  ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
     return P
+
+
+def check_backward(L, P, s):
+    """dX = LN_bwd(dY, S) . W (NN storage) against etp_ln_stream_bwd_stage1 + etp_ln_part_reduce + etp_gemm: dx / the bf16 copy
+    bit-identical, dgamma / dbeta within fp32 summation-order noise (the slabs group the rows differently), dX within bf16 rounding."""
+    H = 768
+    for M in (512, 500):
+        for N, act in ((768, _lib.ACT_NONE), (3072, _lib.ACT_GELU_BWD)):
+            for bm in (32, 64):
+                g = torch.Generator(device="cuda").manual_seed(M + N + bm)
+                S = torch.randn(M, H, device="cuda", generator=g) * 1.5 + 0.3
+                dy = torch.randn(M, H, device="cuda", generator=g) * 0.2
+                gamma = 1.0 + 0.1 * torch.randn(H, device="cuda", generator=g)
+                W = (torch.randn(H, N, device="cuda", generator=g) * 0.05).to(torch.bfloat16)       # [reduction][N]
+                Z = (torch.randn(M, N, device="cuda", generator=g)).to(torch.bfloat16) if act == _lib.ACT_GELU_BWD else None
+                mean = S.mean(1); rstd = (S.var(1, unbiased=False) + 1e-12).rsqrt()
+                stats = torch.stack([mean, rstd], 1).contiguous()
+                dx_r, dx_n = torch.empty(M, H, device="cuda"), torch.empty(M, H, device="cuda")
+                dxt_r, dxt_n = torch.empty(M, H, device="cuda", dtype=torch.bfloat16), torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+                dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+                part = torch.empty(int(L.etp_ln_bwd_part_bytes(M, H)) // 4, device="cuda")
+                check(L.etp_ln_stream_bwd_stage1(_lib.ETP_BF16, dy.data_ptr(), S.data_ptr(), stats.data_ptr(), gamma.data_ptr(), None,
+                                                 dx_r.data_ptr(), dxt_r.data_ptr(), dg.data_ptr(), db.data_ptr(), part.data_ptr(), M, H, s), "ln_bwd")
+                check(L.etp_ln_part_reduce(part.data_ptr(), M, H, dg.data_ptr(), db.data_ptr(), s), "ln_part_reduce")
+                C_r = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); C_n = torch.full_like(C_r, float("nan"))
+                d = GemmDesc()
+                d.A, d.B, d.C = dxt_r.data_ptr(), W.data_ptr(), C_r.data_ptr()
+                d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, H, H, N, N
+                d.trans_a, d.trans_b, d.dtype, d.c_dtype = 0, 1, _lib.ETP_BF16, _lib.ETP_BF16
+                d.batch, d.batch_inner, d.ksplit, d.alpha, d.act = 1, 1, 1, 1.0, act
+                if Z is not None:
+                    d.Z, d.ldz = Z.data_ptr(), N
+                check(L.etp_gemm(ctypes.byref(d), s), "gemm")
+                nblk = (M + bm - 1) // bm
+                slabs = torch.empty(nblk, 2, H, device="cuda")
+                rc = P.r05_ln_bwd_gemm(dy.data_ptr(), S.data_ptr(), stats.data_ptr(), gamma.data_ptr(), None, W.data_ptr(), N, C_n.data_ptr(), N, 0,
+                                       None, 0, M, N, dx_n.data_ptr(), dxt_n.data_ptr(), slabs.data_ptr(), act,
+                                       Z.data_ptr() if Z is not None else None, N, bm, s)
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                ok = torch.equal(dx_r, dx_n) and torch.equal(dxt_r, dxt_n)
+                eg = (slabs[:, 0].sum(0) - dg).abs().max().item() / max(dg.abs().max().item(), 1e-6)
+                eb = (slabs[:, 1].sum(0) - db).abs().max().item() / max(db.abs().max().item(), 1e-6)
+                dc = (C_r.float() - C_n.float()).abs().max().item()
+                print(f"bwd M={M:4d} N={N:4d} bm={bm}: dx / copy bit-identical {ok}, dgamma rel {eg:.2e}, dbeta rel {eb:.2e}, max |dC| {dc:.3e}")
+                assert ok and eg < 1e-4 and eb < 1e-4 and dc <= 6e-2
 
 
 def make(M, N, act, seed):
@@ -85,6 +135,7 @@ def main():
                 dz = (d["Z_ref"].float() - d["Z_new"].float()).abs().max().item() if act == _lib.ACT_GELU else 0.0
                 print(f"M={M:4d} N={N:4d} bm={bm}: LN outputs bit-identical {ok_y}, max |dC| {dc:.3e}, max |dZ| {dz:.3e}")
                 assert ok_y and dc <= 6e-2 and dz <= 6e-2
+    check_backward(L, P, s)
     # timing at M = 512
     M, nsets, iters = 512, 6, 60
     for N, act in ((768, _lib.ACT_NONE), (2304, _lib.ACT_NONE), (3072, _lib.ACT_GELU)):
