@@ -213,6 +213,9 @@ int etp_adamw_step_counted(float* params, float* grads, float* exp_avg, float* e
 int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t s) {
   return grad_sqnorm(grads, (long)n, sumsq, nonfinite, (hipStream_t)s);
 }
+int etp_grad_sqnorm_masked(const float* grads, int64_t n, const uint8_t* mask, float* sumsq, int32_t* nonfinite, etp_stream_t s) {
+  return grad_sqnorm(grads, (long)n, sumsq, nonfinite, (hipStream_t)s, mask);
+}
 int etp_gather_sum(int dtype, const void* src, const int32_t* ptr, const int32_t* idx, const float* w, void* out, int N, int H,
                    int accumulate, etp_stream_t s) {
   ETP_REQUIRE(src && ptr && idx && w && out, "null pointer");

@@ -74,7 +74,7 @@ int sum_steps(int dtype, const void* src, void* dst, long n, int steps, hipStrea
 int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shadow, const uint8_t* decay_mask, long n,
                const etp_adamw_cfg& c, const float* sumsq, const int32_t* skip, int zero_grads, hipStream_t st,
                int32_t* step_dev = nullptr);
-int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st);
+int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st, const uint8_t* mask = nullptr);
 
 // attention = batched MFMA GEMMs + masked softmax (planner.hip); head dim 64, heads interleaved in the row
 struct AttnBuf {

@@ -55,11 +55,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     const long e0 = i * 4;
     // every array is streamed exactly once: non-temporal accesses keep 4.7 GB of optimizer traffic out of L2/MALL
     float4 gv = ntload(g + e0);
-    if (!skipped) {
+    // mask byte of this 64-element block: bit 0 = weight decay applies, bit 1 = FROZEN (requires_grad = False:
+    // vilmodel_cmt.py:675-682 fix_lang_embedding / fix_pano_embedding) -- p / m / v / shadow are left alone, the gradient is
+    // still zeroed
+    const uint8_t mb = decay_mask == nullptr ? (uint8_t)1 : decay_mask[e0 >> 6];
+    if (!skipped && !(mb & 2)) {
       float4 pv = ntload(p + e0);
       float4 mv = ntload(m + e0);
       float4 vv = ntload(v + e0);
-      const float wd = (decay_mask == nullptr || decay_mask[e0 >> 6]) ? k.wd : 0.f;
+      const float wd = (mb & 1) ? k.wd : 0.f;
       float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
       float mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -90,13 +94,14 @@ __global__ void adamw_bump_kernel(int32_t* __restrict__ step_dev, const int32_t*
 
 // sum of squares (+ count of non-finite values) of a gradient arena; both outputs ACCUMULATE (zero them first)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ sumsq,
-                                                     int32_t* __restrict__ nonfinite) {
+                                                     int32_t* __restrict__ nonfinite, const uint8_t* __restrict__ mask) {
   __shared__ float red[4];
   __shared__ int bad[4];
   float s = 0.f;
   int nf = 0;
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    if (mask != nullptr && (mask[(i * 4) >> 6] & 2)) continue;      // frozen block: no .grad in the reference, not in the norm
     const float4 x = *reinterpret_cast<const float4*>(g + i * 4);
     s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     nf += !isfinite(x.x) + !isfinite(x.y) + !isfinite(x.z) + !isfinite(x.w);
@@ -140,10 +145,10 @@ int adamw_step(float* p, float* g, float* m, float* v, void* shadow, long n_shad
   return ETP_OK;
 }
 
-int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st) {
+int grad_sqnorm(const float* g, long n, float* sumsq, int32_t* nonfinite, hipStream_t st, const uint8_t* mask) {
   ETP_REQUIRE(g && sumsq && n > 0 && n % 4 == 0 && (uintptr_t)g % 16 == 0, "bad arguments");
   const int grid = (int)std::min<long>((n / 4 + 255) / 256, 256L * 8);
-  ETP_LAUNCH(sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, sumsq, nonfinite);
+  ETP_LAUNCH(sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, sumsq, nonfinite, mask);
   ETP_CHECK_LAUNCH("grad_sqnorm");
   return ETP_OK;
 }

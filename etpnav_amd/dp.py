@@ -356,6 +356,46 @@ def task_grad_ranges(model, task: str, max_gap: int = 0):
     return [(s, min(e, total)) for s, e in merged], (None if task == "mlm" else word)
 
 
+def frozen_spans(model):
+    """Arena spans [start, end) (64-element padded) of the parameters with requires_grad = False (fix_lang_embedding /
+    fix_pano_embedding, vilmodel_cmt.py:675-682): DDP registers no hook for them (ss_trainer_ETP.py:208-212 wraps the module,
+    whose frozen parameters never enter a bucket), so they must not travel here either."""
+    eng = model._engine
+    tab = {n: (off, shape) for n, shape, off in eng.table}
+    spans = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            off, shape = tab[name]
+            n = 1
+            for d in shape:
+                n *= d
+            spans.append((off, min(eng.total, off + (n + 63) // 64 * 64)))
+    spans.sort()
+    merged = []
+    for s, e in spans:
+        if merged and s <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], e)
+        else:
+            merged.append([s, e])
+    return [(s, e) for s, e in merged]
+
+
+def subtract_spans(ranges, spans):
+    """ranges minus spans, order of `ranges` kept; a range cut in the middle becomes several consecutive ranges."""
+    out = []
+    for s, e in ranges:
+        cur = s
+        for fs, fe in spans:
+            if fe <= cur or fs >= e:
+                continue
+            if fs > cur:
+                out.append((cur, fs))
+            cur = max(cur, fe)
+        if cur < e:
+            out.append((cur, e))
+    return out
+
+
 def planner_buckets_layered(model, text_groups: int = 3):
     """Finer buckets for overlap with the text-encoder backward: bucket 0 = non-text matrices (ready after the navigation
     and panorama backward), then one bucket per group of text layers in backward order (last layers first), then vectors
@@ -372,18 +412,34 @@ def planner_buckets_layered(model, text_groups: int = 3):
     ranges, groups = [], []
     if first_non_text < eng.n_matrix:
         ranges.append((first_non_text, eng.n_matrix))
-    text_groups = max(1, min(text_groups, n_l)) if n_l else 0
+    frozen = frozen_spans(model)
+    txt_frozen = n_l > 0 and subtract_spans([(starts[0], starts[n_l])], frozen) == []
+    text_groups = max(1, min(text_groups, n_l)) if (n_l and not txt_frozen) else 0
     hi = n_l
     for gidx in range(text_groups):
         lo = (n_l * (text_groups - 1 - gidx)) // text_groups
         ranges.append((starts[lo], starts[hi]))
         groups.append((lo, hi))
         hi = lo
+    # the text buckets keep their positions 1 .. len(groups) (PlannerStep.run_data_parallel announces bucket 1 + k after text
+    # group k); frozen spans are cut out of bucket 0 and of the vector / table tail only
+    tail = []
     if word_off > eng.n_matrix:
-        ranges.append((eng.n_matrix, word_off))
+        tail.append((eng.n_matrix, word_off))
     if word_end < eng.total:
-        ranges.append((word_end, eng.total))
-    return ranges, (word_off, word_shape[0], word_shape[1]), groups
+        tail.append((word_end, eng.total))
+    word = (word_off, word_shape[0], word_shape[1])
+    if frozen:
+        head = subtract_spans(ranges[:1], frozen) if first_non_text < eng.n_matrix else []
+        if first_non_text < eng.n_matrix and len(head) != 1:
+            # bucket 0 must stay ONE range (its index is part of the step's announcement protocol): take the hull of what is left;
+            # the frozen gaps inside it hold zeros on every rank (never written), so reducing them is harmless
+            head = [(head[0][0], head[-1][1])] if head else [(first_non_text, first_non_text)]
+        ranges = head + ranges[1:] + subtract_spans(tail, frozen)
+        if subtract_spans([(word_off, word_end)], frozen) == []:
+            word = None
+        return ranges, word, groups
+    return ranges + tail, word, groups
 
 
 def planner_buckets(model, split_text: bool = True, dense_word_table: bool = False):
@@ -411,7 +467,13 @@ def planner_buckets(model, split_text: bool = True, dense_word_table: bool = Fal
         ranges.append((eng.n_matrix, word_off))
     if word_end < eng.total:
         ranges.append((word_end, eng.total))
+    word = (word_off, word_shape[0], word_shape[1])
+    frozen = frozen_spans(model)
     if dense_word_table:
         ranges.append((word_off, word_end))
-        return ranges, None
-    return ranges, (word_off, word_shape[0], word_shape[1])
+        word = None
+    if frozen:
+        ranges = subtract_spans(ranges, frozen)
+        if word is not None and subtract_spans([(word_off, word_end)], frozen) == []:
+            word = None
+    return ranges, word

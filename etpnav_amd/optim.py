@@ -47,29 +47,46 @@ class FusedAdamW:
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.decay_mask = None
         self.no_decay_names = []        # parameters excluded from weight decay (checkpoint validation)
-        if any(not p.requires_grad for p in model.parameters()):
-            raise NotImplementedError("FusedAdamW updates the whole arena; frozen parameters (fix_lang_embedding / "
-                                      "fix_pano_embedding) need torch.optim.AdamW over model.parameters()")
+        # frozen parameters (requires_grad = False: fix_lang_embedding / fix_pano_embedding, vilmodel_cmt.py:675-682; the
+        # reference hands torch.optim.AdamW parameters without a .grad, which it skips): bit 1 of the per-block mask byte --
+        # the kernel leaves p / m / v / shadow of those blocks alone, the norm / non-finite scan leaves them out
+        self.frozen_names = [name for name, p in model.named_parameters() if not p.requires_grad]
+        self._build_mask()
         if no_decay is not None:
             self.set_no_decay_names([name for name, _, _ in eng.table if no_decay(name)])
 
     def set_no_decay_names(self, names):
         """Exclude exactly these parameters from weight decay (one mask byte per 64 elements; every parameter starts on a
         64-element boundary of the arena).  An empty list = every parameter decays (no mask)."""
-        eng = self.eng
         names = set(names)
-        self.no_decay_names = [name for name, _, _ in eng.table if name in names]
-        if not self.no_decay_names:
+        self.no_decay_names = [name for name, _, _ in self.eng.table if name in names]
+        self._build_mask()
+
+    def _build_mask(self):
+        """One byte per 64 arena elements (include/etpnav_hip.h, etp_adamw_step): bit 0 = weight decay applies, bit 1 = frozen.
+        None when every parameter decays and none is frozen."""
+        eng = self.eng
+        nd, fz = set(self.no_decay_names), set(self.frozen_names)
+        if not nd and not fz:
             self.decay_mask = None
             return
         mask = torch.ones((eng.total + 63) // 64, dtype=torch.uint8)
         for name, shape, off in eng.table:
-            if name in names:
+            if name in nd or name in fz:
                 n = 1
                 for s in shape:
                     n *= s
-                mask[off // 64:(off + n + 63) // 64] = 0
+                mask[off // 64:(off + n + 63) // 64] = (0 if name in nd else 1) | (2 if name in fz else 0)
         self.decay_mask = mask.to(eng.device)
+
+    def _sqnorm(self, s):
+        eng = self.eng
+        self.sumsq.zero_(); self.nonfinite.zero_()
+        if self.frozen_names:
+            check(eng.L.etp_grad_sqnorm_masked(ptr(eng.grads), eng.total, ptr(self.decay_mask), ptr(self.sumsq), ptr(self.nonfinite), s),
+                  "grad_sqnorm_masked")
+        else:
+            check(eng.L.etp_grad_sqnorm(ptr(eng.grads), eng.total, ptr(self.sumsq), ptr(self.nonfinite), s), "grad_sqnorm")
 
     @property
     def step_count(self) -> int:
@@ -94,10 +111,7 @@ class FusedAdamW:
 
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (still scaled) gradients, as a device scalar."""
-        eng = self.eng
-        s = eng.stream()
-        self.sumsq.zero_(); self.nonfinite.zero_()
-        check(eng.L.etp_grad_sqnorm(ptr(eng.grads), eng.total, ptr(self.sumsq), ptr(self.nonfinite), s), "grad_sqnorm")
+        self._sqnorm(self.eng.stream())
         return self.sumsq.sqrt()
 
     def step(self, grad_scale: float = 1.0, zero_grads: bool = True):
@@ -109,8 +123,7 @@ class FusedAdamW:
         s = eng.stream()
         need_scan = self.max_grad_norm > 0.0 or self.check_finite
         if need_scan:
-            self.sumsq.zero_(); self.nonfinite.zero_()
-            check(eng.L.etp_grad_sqnorm(ptr(eng.grads), eng.total, ptr(self.sumsq), ptr(self.nonfinite), s), "grad_sqnorm")
+            self._sqnorm(s)
         self._step_host += 1
         c = _lib.AdamwCfg(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
                           step=self._step_host, hf_style=int(self.hf_style), correct_bias=int(self.correct_bias),

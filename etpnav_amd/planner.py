@@ -378,10 +378,12 @@ class GlocalTextPathNavCMT(nn.Module):
             for k, v in self.named_parameters():
                 if k.startswith("embeddings.") or k.startswith("lang_encoder."):
                     v.requires_grad = False
+                    v.grad = None             # a frozen parameter has no .grad (the reference's optimizers skip it on that)
         if _cfg_get(config, "fix_pano_embedding", False):
             for k, v in self.named_parameters():
                 if k.startswith("img_embeddings."):
                     v.requires_grad = False
+                    v.grad = None
         self._anchor = torch.zeros(1, device=self._engine.device, requires_grad=True)
         # training-mode dropout (nn.Module.training, as the reference's nn.Dropout layers): rates from the config,
         # masks from a counter-based generator keyed by (seed, call counter, site, element)
@@ -523,7 +525,12 @@ class GlocalTextPathNavCMT(nn.Module):
         """vilmodel_cmt.py:690-719 -> (pano_embeds [B,V,H], pano_masks [B,V] bool)."""
         eng = self._prep()
         dep = dep_fts.float().contiguous() if dep_fts is not None else None
-        return _PanoFn.apply(self._anchor, eng, self._dropout(), rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
+        # fix_pano_embedding AND fix_lang_embedding: nothing behind this branch requires a gradient (token_type_embeddings(1),
+        # :706-708, is frozen with the language side), so unless the features do, autograd must not enter it
+        c = self.config
+        live = rgb_fts.requires_grad or not (_cfg_get(c, "fix_pano_embedding", False) and _cfg_get(c, "fix_lang_embedding", False))
+        anchor = self._anchor if live else self._anchor.detach()
+        return _PanoFn.apply(anchor, eng, self._dropout(), rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
                              nav_types.long().contiguous(), view_lens.long().contiguous())
 
     def _text_kv(self, eng, txt_embeds):

@@ -72,6 +72,16 @@ class PlannerStep:
         language-side x-layer weights this step does not touch)."""
         self.model = model
         self.refresh_weights, self.zero_grads = refresh_weights, zero_grads
+        # frozen sub-models (vlnbert_init.py:51-54 -> vilmodel_cmt.py:422-433,675-682): with fix_lang_embedding the text encoder's
+        # output is detached (LanguageEncoder.forward :431-432) -- no text backward runs and no gradient reaches `embeddings.*` /
+        # `lang_encoder.*`.  fix_pano_embedding alone does NOT stop the panorama backward: forward_panorama adds
+        # embeddings.token_type_embeddings(1) (vilmodel_cmt.py:706-708), which stays trainable, so the gradient still crosses the
+        # (frozen) panorama encoder to reach it; only with BOTH flags nothing behind the panorama branch requires a gradient
+        # (the features are inputs) and autograd never enters it -- neither does this step.  Gradient slots of frozen parameters
+        # in the flat arena are unspecified (their .grad is None, FusedAdamW and the data-parallel buckets leave them out).
+        from .planner import _cfg_get
+        self.train_txt = not bool(_cfg_get(model.config, "fix_lang_embedding", False))
+        self.train_pano = self.train_txt or not bool(_cfg_get(model.config, "fix_pano_embedding", False))
         if grad_overwrite is None:
             grad_overwrite = bool(zero_grads) and not model._engine.cconf.use_lang2visn and \
                 os.environ.get("ETP_GRAD_OVERWRITE", "1") != "0"
@@ -204,6 +214,8 @@ class PlannerStep:
 
     # ------------------------------------------------------------------------------------------
     def _enqueue_pano_bwd(self, s: int):
+        if not self.train_pano:
+            return
         L, h, i = self.L, self.eng.handle, self.inp
         s2 = self.s2 if self.s2 is not None else s
         self._install_streams()
@@ -282,6 +294,11 @@ class PlannerStep:
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
         pb, xb, wb = self.csr_b
         L.etp_stamp_mark(s, 4)
+        if not self.train_pano:    # frozen panorama embedding: the backward stops at the node features (d_gimg)
+            if join_pano:
+                check(L.etp_planner_join_aux(h, s), "join aux")
+            check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
+            return
         check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s),
               "node assembly bwd")
         L.etp_stamp_mark(s, 5)
@@ -304,6 +321,10 @@ class PlannerStep:
         L, eng, i = self.L, self.eng, self.inp
         if layer_hi is None:
             layer_hi = eng.cconf.n_l
+        if not self.train_txt:     # frozen language side: only the joins this call owes its callers
+            if layer_lo == 0:
+                self._join_side(s)
+            return
         self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(eng.handle, int(self.grad_overwrite)), "set_grad_overwrite")
@@ -317,6 +338,15 @@ class PlannerStep:
             check(L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
             self._pano_pending = False
         L.etp_stamp_mark(s, 7)
+
+    def _join_side(self, s: int):
+        """order `s` after the weight-gradient stream and a still-running panorama backward (what the text backward's last
+        range does for a trainable text encoder)"""
+        check(self.L.etp_planner_join_aux(self.eng.handle, s), "join aux")
+        if self._pano_pending:
+            check(self.L.etp_stream_after(self.s2 if self.s2 is not None else s, s), "join")
+            self._pano_pending = False
+        self.L.etp_stamp_mark(s, 7)
 
     def _drop_state(self):
         if self.dropout is None:
@@ -373,6 +403,10 @@ class PlannerStep:
             return
         side = tuple(x for x in (self.aux, self.s2) if x is not None)
         self.enqueue_main(s, True, join_pano=False)          # the panorama backward keeps running beside the text backward
+        if not groups or not self.train_txt:                 # frozen text encoder (dp.planner_buckets_layered returns no text groups)
+            bucket_ready(0, side)
+            self._join_side(s)
+            return
         self._lazy = 2                                       # no join between the layer groups; the last group (layer 0) joins
         try:
             for k, (lo, hi) in enumerate(groups):

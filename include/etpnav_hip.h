@@ -194,8 +194,10 @@ int etp_scale_f32(float* p, int64_t n, float scale, etp_stream_t stream);
  *   hf_style 1: optim/adamw.py         p -= lr*sqrt(bc2)/bc1 * m / (sqrt(v) + eps);  p -= lr*wd*p
  *   bc1 = 1-beta1^step, bc2 = 1-beta2^step (both 1 when correct_bias == 0); step counts from 1.
  *   g = grad * grad_scale * clip, clip = min(1, max_norm / (sqrt(*sumsq)*|grad_scale| + 1e-6)) when max_norm > 0.
- * decay_mask (nullable = decay everywhere): one byte per 64 consecutive elements, non-zero = apply weight_decay
- * (planner parameters start on 64-element boundaries, so any per-parameter grouping such as optim/misc.py:12-22 fits).
+ * decay_mask (nullable = decay everywhere, nothing frozen): one byte per 64 consecutive elements; bit 0 = apply weight_decay
+ * (planner parameters start on 64-element boundaries, so any per-parameter grouping such as optim/misc.py:12-22 fits),
+ * bit 1 = FROZEN block (requires_grad = False: fix_lang_embedding / fix_pano_embedding, vilmodel_cmt.py:675-682;
+ * LanguageEncoder :422-424): p / m / v / shadow are left untouched, the gradient is still zeroed.
  * shadow (nullable): bf16 copy written for elements [0, n_shadow).  skip (nullable, device int32): non-zero -> leave
  * p/m/v/shadow untouched (GradScaler's skipped step); gradients are still zeroed when zero_grads != 0.
  * sumsq / skip are produced by etp_grad_sqnorm (both ACCUMULATE: zero them first).  n % 4 == 0, 16-byte aligned. */
@@ -217,6 +219,10 @@ int etp_adamw_step_counted(float* params, float* grads, float* exp_avg, float* e
                            const uint8_t* decay_mask, int64_t n, const etp_adamw_cfg* cfg, const float* sumsq, const int32_t* skip,
                            int zero_grads, int32_t* step_counter, etp_stream_t stream);
 int etp_grad_sqnorm(const float* grads, int64_t n, float* sumsq, int32_t* nonfinite, etp_stream_t stream);
+/* The same, leaving out the blocks whose mask byte (layout of decay_mask above) has bit 1 set: frozen parameters have no .grad in
+ * the reference, so clip_grad_norm_ / GradScaler's non-finite scan never see them. */
+int etp_grad_sqnorm_masked(const float* grads, int64_t n, const uint8_t* mask, float* sumsq, int32_t* nonfinite,
+                           etp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Planner engine: whole forward/backward of the three planner entry points over one flat parameter arena.

@@ -42,6 +42,12 @@ CASES = {
     "c4_rxr_l512_b2": (dict(kind="rxr"), dict(B=2, L=512, V=36, G=16, ragged=True)),
     # configs[4] at its BASELINE per-sample shape: 80 tokens, 36 views, 64 graph nodes
     "c5_g64_l80_b2": (dict(kind="r2r"), dict(B=2, L=80, V=36, G=64, ragged=False)),
+    # frozen / ablated model variants the boundary reads (vlnbert_init.py:42-54; vilmodel_cmt.py:422-433,675-682): the frozen
+    # parameters get NO gradient in the reference (stored here as zeros), the detached text output stops the backward
+    "fix_lang_small": (dict(kind="r2r", fix_lang_embedding=True), dict(B=3, L=12, V=14, G=7, ragged=True)),
+    "fix_pano_small": (dict(kind="r2r", fix_pano_embedding=True), dict(B=3, L=12, V=14, G=7, ragged=True)),
+    "no_sprels_small": (dict(kind="r2r", graph_sprels=False), dict(B=3, L=12, V=14, G=7, ragged=True)),
+    "no_depth_small": (dict(kind="r2r", use_depth_embedding=False), dict(B=3, L=12, V=14, G=7, ragged=True)),
 }
 
 # Big activations of the large cases are stored as (fingerprint, strided samples) like the gradients: the full

