@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "etpnav_hip.h")
 LIB_PATH = os.environ.get("ETP_LIB") or os.path.join(HERE, "libetpnav_hip.so")
 
 ETP_F32, ETP_BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_SAVEGRAD, ACT_MUL_Z = 0, 1, 2, 3, 4, 5, 6
 
 
 class EtpError(RuntimeError):

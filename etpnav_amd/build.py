@@ -56,7 +56,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    audit_resources(verbose)
     return OUT
+
+
+def audit_resources(verbose: bool = True):
+    """Fail the build when a kernel without MFMAs was given AGPRs or any kernel uses scratch (tools/kernel_resources.py; DESIGN.md
+    §3.6: the round-4 gradient corruption sat in AGPR-parked loads of such a kernel).  ETP_BUILD_AUDIT=0 skips it."""
+    if os.environ.get("ETP_BUILD_AUDIT", "1") == "0":
+        return
+    root = os.path.dirname(HERE)
+    tool = os.path.join(root, "tools", "kernel_resources.py")
+    if not os.path.exists(tool):
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", tool)
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.audit()
+    bad = [r for r in rows if r["violation"]]
+    if verbose:
+        print(f"kernel resource audit: {len(rows)} kernels, {sum(1 for r in rows if int(r['agpr_count']) > 0)} with AGPRs (all matrix-core "
+              f"families), {len(bad)} violations", flush=True)
+    if bad:
+        raise RuntimeError("kernel resource policy violated (tools/kernel_resources.py):\n" +
+                           "\n".join(f"  {r['src']}: {r['full']}: {r['violation']}" for r in bad))
 
 
 if __name__ == "__main__":

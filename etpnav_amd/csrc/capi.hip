@@ -45,8 +45,8 @@ const char* etp_last_error(void) { return g_last_error.c_str(); }
 
 static int desc_to_args(const etp_gemm_desc* d, GemmArgs& g) {
   ETP_REQUIRE(d && d->A && d->B && d->C, "null descriptor/operand");
-  ETP_REQUIRE(d->act >= ETP_ACT_NONE && d->act <= ETP_ACT_RELU_BWD, "bad activation");
-  ETP_REQUIRE((d->act != ETP_ACT_GELU && d->act != ETP_ACT_GELU_BWD && d->act != ETP_ACT_RELU_BWD) || d->Z, "activation needs Z");
+  ETP_REQUIRE(d->act >= ETP_ACT_NONE && d->act <= ETP_ACT_MUL_Z, "bad activation");
+  ETP_REQUIRE((d->act == ETP_ACT_NONE || d->act == ETP_ACT_RELU) || d->Z, "activation needs Z");
   memset(&g, 0, sizeof(g));
   g.A = d->A; g.B = d->B; g.C = d->C; g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;

@@ -279,21 +279,66 @@ __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict
   }
 }
 
+constexpr int PANO_LDS_ROWS = 8;
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ a,
+__global__ __launch_bounds__(256, 2) void pano_embed_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ a,
                                                              const T* __restrict__ d, const float* __restrict__ loc,
                                                              const int64_t* __restrict__ nav, const float* __restrict__ stats,
                                                              PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
                                                              T* __restrict__ dd, int M, Drop drop) {
   constexpr int H = NCH * 256;
-  // register accumulators: g/b x {img,dep,loc,out} + nav_emb[0..1] + type1 + bias_loc + w_loc[.,0..3] = 16 rows
-  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats
-  Row<NCH> A_gi, A_bi, A_gd, A_bd, A_gl, A_bl, A_go, A_bo, A_nav0, A_nav1, A_ty, A_lb, A_lw0, A_lw1, A_lw2, A_lw3;
-  row_zero<NCH>(A_gi); row_zero<NCH>(A_bi); row_zero<NCH>(A_gd); row_zero<NCH>(A_bd); row_zero<NCH>(A_gl); row_zero<NCH>(A_bl);
-  row_zero<NCH>(A_go); row_zero<NCH>(A_bo); row_zero<NCH>(A_nav0); row_zero<NCH>(A_nav1); row_zero<NCH>(A_ty); row_zero<NCH>(A_lb);
-  row_zero<NCH>(A_lw0); row_zero<NCH>(A_lw1); row_zero<NCH>(A_lw2); row_zero<NCH>(A_lw3);
+  // Accumulators of the parameter gradients that reduce over rows.  Round 5 (tools/kernel_resources.py: this kernel held 482
+  // registers, 226 of them AGPRs -- one wavefront per SIMD and the register class DESIGN.md §3.6 bans outside the matrix-core
+  // kernels):
+  //   * the three inner LayerNorm biases, type1 and nav_emb[0] + nav_emb[1] all receive the SAME column sum of `de` (the gradient
+  //     of the branch sum): one accumulator (A_ty) serves five gradients, nav_emb[1] = A_ty - A_nav0 at the flush;
+  //   * the six rows of the angle branch (gamma_loc, bias_loc, w_loc[., 0..3]) and the two plain sums (beta_out, nav_emb[0]) live in
+  //     LDS, one private region per wavefront, every lane read-modify-writes only its own twelve columns (plain 16-byte accesses,
+  //     no atomics, no barrier);
+  //   * four rows stay in registers: gamma x {img, dep, out}, sum(de).
+  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats (block_flush) + 4 wavefronts x PANO_LDS_ROWS x H
+  Row<NCH> A_gi, A_gd, A_go, A_ty;
+  row_zero<NCH>(A_gi); row_zero<NCH>(A_gd); row_zero<NCH>(A_go); row_zero<NCH>(A_ty);
+  enum { L_GL = 0, L_LB = 1, L_LW0 = 2, L_BO = 6, L_NAV0 = 7 };   // LDS rows: gamma_loc, bias_loc, w_loc[., 0..3], beta_out, nav_emb[0]
+  float* wl = scratch + 4 * H + (threadIdx.x >> 6) * PANO_LDS_ROWS * H + (threadIdx.x & 63) * 4;
+#pragma unroll
+  for (int r = 0; r < PANO_LDS_ROWS; ++r)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(wl + r * H + c * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto lds_acc = [&](int r, const Row<NCH>& a, float sc) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float4* q = reinterpret_cast<float4*>(wl + r * H + c * 256);
+      float4 o = *q;
+      o.x += a.v[c][0] * sc; o.y += a.v[c][1] * sc; o.z += a.v[c][2] * sc; o.w += a.v[c][3] * sc;
+      *q = o;
+    }
+  };
+  auto lds_acc_mul = [&](int r, const Row<NCH>& a, const Row<NCH>& b) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float4* q = reinterpret_cast<float4*>(wl + r * H + c * 256);
+      float4 o = *q;
+      o.x += a.v[c][0] * b.v[c][0]; o.y += a.v[c][1] * b.v[c][1]; o.z += a.v[c][2] * b.v[c][2]; o.w += a.v[c][3] * b.v[c][3];
+      *q = o;
+    }
+  };
+  auto lds_row = [&](int r, Row<NCH>& a) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 o = *reinterpret_cast<const float4*>(wl + r * H + c * 256);
+      a.v[c][0] = o.x; a.v[c][1] = o.y; a.v[c][2] = o.z; a.v[c][3] = o.w;
+    }
+  };
   const int lane = threadIdx.x & 63;
+  const PanoEmbedParams p0 = p;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    // The parameter vectors are loop-invariant and the compiler used to hoist all eleven of them (plus the [H, 4] angle projection)
+    // out of this three-trip loop: ~180 registers of operands parked beside the accumulators, 226 of them in AGPRs.  The base
+    // pointers are passed through an empty asm every trip, so every use re-loads from L1 / L2 (a few KB, resident) instead.
+    PanoEmbedParams p = p0;
+    asm volatile("" : "+s"(p.g_img), "+s"(p.b_img), "+s"(p.g_dep), "+s"(p.b_dep), "+s"(p.w_loc), "+s"(p.bias_loc));
+    asm volatile("" : "+s"(p.g_loc), "+s"(p.b_loc), "+s"(p.nav_emb), "+s"(p.type1), "+s"(p.g_out), "+s"(p.b_out));
     const float* st = stats + (long)row * 8;
     Row<NCH> e, x, t, de;
     // rebuild e = sum of the branches, normalised (outer xhat)
@@ -332,21 +377,19 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __rest
     row_load<NCH>(de, dy + (long)row * H, lane);
     row_dropout<NCH>(de, drop, row, lane);
     acc_mul<NCH>(A_go, de, e);
-    acc_scaled<NCH>(A_bo, de, 1.0f);
+    lds_acc(L_BO, de, 1.0f);
     row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);   // de = grad wrt the branch sum
-    acc_scaled<NCH>(A_nav0, de, nv == 0 ? 1.0f : 0.0f);
-    acc_scaled<NCH>(A_nav1, de, nv == 0 ? 0.0f : 1.0f);
-    acc_scaled<NCH>(A_ty, de, 1.0f);
+    lds_acc(L_NAV0, de, nv == 0 ? 1.0f : 0.0f);
+    acc_scaled<NCH>(A_ty, de, 1.0f);                // = d type1 = d beta_{img, dep, loc} = d nav_emb[0] + d nav_emb[1]
     // loc branch (x still holds its xhat)
     t = de;
-    acc_mul<NCH>(A_gl, t, x);
-    acc_scaled<NCH>(A_bl, t, 1.0f);
+    lds_acc_mul(L_GL, t, x);
     row_ln_bwd<NCH>(t, x, p.g_loc, st[5], lane);
-    acc_scaled<NCH>(A_lb, t, 1.0f);
+    lds_acc(L_LB, t, 1.0f);
     {
       const float* l4 = loc + (long)row * 4;
-      acc_scaled<NCH>(A_lw0, t, l4[0]); acc_scaled<NCH>(A_lw1, t, l4[1]);
-      acc_scaled<NCH>(A_lw2, t, l4[2]); acc_scaled<NCH>(A_lw3, t, l4[3]);
+      lds_acc(L_LW0, t, l4[0]); lds_acc(L_LW0 + 1, t, l4[1]);
+      lds_acc(L_LW0 + 2, t, l4[2]); lds_acc(L_LW0 + 3, t, l4[3]);
     }
     // img branch
     row_load<NCH>(x, a + (long)row * H, lane);
@@ -356,7 +399,6 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __rest
       for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
     t = de;
     acc_mul<NCH>(A_gi, t, x);
-    acc_scaled<NCH>(A_bi, t, 1.0f);
     row_ln_bwd<NCH>(t, x, p.g_img, st[1], lane);
     row_store<NCH>(t, da + (long)row * H, lane);
     if (d != nullptr) {
@@ -367,20 +409,27 @@ __global__ __launch_bounds__(256) void pano_embed_bwd_kernel(const float* __rest
         for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
       t = de;
       acc_mul<NCH>(A_gd, t, x);
-      acc_scaled<NCH>(A_bd, t, 1.0f);
       row_ln_bwd<NCH>(t, x, p.g_dep, st[3], lane);
       row_store<NCH>(t, dd + (long)row * H, lane);
     }
   }
-  block_flush<NCH>(scratch, A_gi, g.g_img, 1, 0); block_flush<NCH>(scratch, A_bi, g.b_img, 1, 0);
-  if (d != nullptr) { block_flush<NCH>(scratch, A_gd, g.g_dep, 1, 0); block_flush<NCH>(scratch, A_bd, g.b_dep, 1, 0); }
-  block_flush<NCH>(scratch, A_gl, g.g_loc, 1, 0); block_flush<NCH>(scratch, A_bl, g.b_loc, 1, 0);
-  block_flush<NCH>(scratch, A_go, g.g_out, 1, 0); block_flush<NCH>(scratch, A_bo, g.b_out, 1, 0);
-  block_flush<NCH>(scratch, A_nav0, g.nav_emb, 1, 0); block_flush<NCH>(scratch, A_nav1, g.nav_emb + H, 1, 0);
+  block_flush<NCH>(scratch, A_gi, g.g_img, 1, 0); block_flush<NCH>(scratch, A_ty, g.b_img, 1, 0);
+  if (d != nullptr) { block_flush<NCH>(scratch, A_gd, g.g_dep, 1, 0); block_flush<NCH>(scratch, A_ty, g.b_dep, 1, 0); }
+  block_flush<NCH>(scratch, A_ty, g.b_loc, 1, 0);
+  block_flush<NCH>(scratch, A_go, g.g_out, 1, 0);
   block_flush<NCH>(scratch, A_ty, g.type1, 1, 0);
-  block_flush<NCH>(scratch, A_lb, g.bias_loc, 1, 0);
-  block_flush<NCH>(scratch, A_lw0, g.w_loc, 4, 0); block_flush<NCH>(scratch, A_lw1, g.w_loc, 4, 1);
-  block_flush<NCH>(scratch, A_lw2, g.w_loc, 4, 2); block_flush<NCH>(scratch, A_lw3, g.w_loc, 4, 3);
+  // the LDS-resident rows come back through A_gi (free now)
+  lds_row(L_BO, A_gi); block_flush<NCH>(scratch, A_gi, g.b_out, 1, 0);
+  lds_row(L_NAV0, A_gi); block_flush<NCH>(scratch, A_gi, g.nav_emb, 1, 0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A_gi.v[c][k] = A_ty.v[c][k] - A_gi.v[c][k];           // rows with nav_type 1
+  block_flush<NCH>(scratch, A_gi, g.nav_emb + H, 1, 0);
+  lds_row(L_GL, A_gi); block_flush<NCH>(scratch, A_gi, g.g_loc, 1, 0);
+  lds_row(L_LB, A_gi); block_flush<NCH>(scratch, A_gi, g.bias_loc, 1, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { lds_row(L_LW0 + j, A_gi); block_flush<NCH>(scratch, A_gi, g.w_loc, 4, j); }
 }
 
 // --------------------------------------------------------------------------------------
@@ -779,8 +828,7 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, l
     case 1: { constexpr int NCH = 1; CALL; } break;                                     \
     case 2: { constexpr int NCH = 2; CALL; } break;                                     \
     case 3: { constexpr int NCH = 3; CALL; } break;                                     \
-    case 4: { constexpr int NCH = 4; CALL; } break;                                     \
-    default: return fail(ETP_ERR_INVALID, "hidden size must be 256, 512, 768 or 1024"); \
+    default: return fail(ETP_ERR_INVALID, "hidden size must be 256, 512 or 768");       \
   }
 
 static inline int row_grid(int M, int cap) { return (int)std::min<long>(((long)M + 3) / 4, cap); }
@@ -818,14 +866,30 @@ int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, co
   return ETP_OK;
 }
 
+template <typename TT, int NCH>
+static int launch_pano_embed_bwd(int grid, size_t smem, hipStream_t st, const float* dy, const void* a, const void* d, const float* loc,
+                                 const int64_t* nav, const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da,
+                                 void* dd, int M, Drop drop) {
+  void (*kern)(const float*, const TT*, const TT*, const float*, const int64_t*, const float*, PanoEmbedParams, PanoEmbedGrads, TT*, TT*,
+               int, Drop) = pano_embed_bwd_kernel<TT, NCH>;
+  static bool attr_set = false;       // more than 64 KB of dynamic LDS needs the attribute once per instantiation
+  if (!attr_set) {
+    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  ETP_LAUNCH(kern, dim3(grid), dim3(256), smem, st, dy, (const TT*)a, (const TT*)d, loc, nav, stats, p, g, (TT*)da, (TT*)dd, M, drop);
+  ETP_CHECK_LAUNCH("pano_embed_bwd");
+  return ETP_OK;
+}
+
 int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, const float* loc, const int64_t* nav,
                    const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da, void* dd, int M, int H,
                    hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
-  const size_t smem = 4 * (size_t)H * sizeof(float);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), smem, st, dy, (const bf16_t*)a, (const bf16_t*)d, loc, nav, stats, p, g, (bf16_t*)da, (bf16_t*)dd, M, drop)); }
-  else { ETP_DISPATCH_H(H, ETP_LAUNCH((pano_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), smem, st, dy, (const float*)a, (const float*)d, loc, nav, stats, p, g, (float*)da, (float*)dd, M, drop)); }
+  const size_t smem = (4 + 4 * PANO_LDS_ROWS) * (size_t)H * sizeof(float);   // block_flush staging + the wavefronts' LDS accumulators (108 KB at H = 768)
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, return (launch_pano_embed_bwd<bf16_t, NCH>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))); }
+  else { ETP_DISPATCH_H(H, return (launch_pano_embed_bwd<float, NCH>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))); }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }

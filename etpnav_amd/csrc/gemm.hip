@@ -561,7 +561,7 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
     return launch_one<T, TC, TA, TB, 128, 64, 4>(g, nbatch, st);
   }
   if (stages == 4) return launch_one<T, TC, TA, TB, 64, 64, 4>(g, nbatch, st);
-  if (stages == 2) return launch_one<T, TC, TA, TB, 64, 64, 2>(g, nbatch, st);
+  // (no two-slab ring for 64x64 tiles: its fp32 TN instantiation spilled to scratch, tools/kernel_resources.py; a forced "64s2" runs s3)
   return launch_one<T, TC, TA, TB, 64, 64, 3>(g, nbatch, st);
 }
 
@@ -703,7 +703,6 @@ static int launch_group_tiles(GemmGroup& grp, hipStream_t st) {
     return launch_group_one<T, TC, TA, TB, 128, 128, 2>(grp, st);
   }
   if (stages == 4) return launch_group_one<T, TC, TA, TB, 64, 64, 4>(grp, st);
-  if (stages == 2) return launch_group_one<T, TC, TA, TB, 64, 64, 2>(grp, st);
   return launch_group_one<T, TC, TA, TB, 64, 64, 3>(grp, st);
 }
 

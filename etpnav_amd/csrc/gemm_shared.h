@@ -31,6 +31,40 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// The saved GELU derivative (ETP_ACT_GELU_SAVEGRAD / ETP_ACT_MUL_Z) travels as IEEE half in the 2-byte Z buffer of the bf16 mode: its
+// values lie in [-0.13, 1.13], where fp16 keeps 11 significant bits against bf16's 8 -- the backward's factor is then MORE exact than
+// gelu'(bf16(z)) was (first GPU run with a bf16-stored derivative: embeddings.LayerNorm.bias of the B = 1 fixture moved from 9 % to
+// 11.6 % of its abs-max; with fp16 the factor's rounding error is 8 x smaller than either form).  fp32 mode: Z is fp32.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+template <typename U> __device__ __forceinline__ void unpack8_grad(const uint4* p, float (&f)[8]);
+template <> __device__ __forceinline__ void unpack8_grad<bf16_t>(const uint4* p, float (&f)[8]) {
+  const uint32_t w[4] = {p[0].x, p[0].y, p[0].z, p[0].w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w[e]);
+    f[2 * e] = (float)h[0]; f[2 * e + 1] = (float)h[1];
+  }
+}
+template <> __device__ __forceinline__ void unpack8_grad<float>(const uint4* p, float (&f)[8]) { unpack8<float>(p, f); }
+__device__ __forceinline__ void store8_grad(bf16_t* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = pack_f16(v[0], v[1]); o.y = pack_f16(v[2], v[3]); o.z = pack_f16(v[4], v[5]); o.w = pack_f16(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+__device__ __forceinline__ void store8_grad(float* p, const float (&v)[8]) { store8(p, v); }
+__device__ __forceinline__ float ld_grad(const bf16_t* p) { return (float)__builtin_bit_cast(_Float16, *p); }
+__device__ __forceinline__ float ld_grad(const float* p) { return *p; }
+__device__ __forceinline__ void st_grad(bf16_t* p, float v) { *p = __builtin_bit_cast(bf16_t, (_Float16)v); }
+__device__ __forceinline__ void st_grad(float* p, float v) { *p = v; }
+
+__host__ __device__ __forceinline__ bool act_reads_z(int act) {
+  return act == ETP_ACT_GELU_BWD || act == ETP_ACT_RELU_BWD || act == ETP_ACT_MUL_Z;
+}
+
 // Epilogue operands of a 64x64 tile (residual / activation operand / old C / bias: 2 chunks of 8 columns per thread) fetched
 // BEFORE the main loop of the LDS-DMA kernel: for the planner's K = 768 products the loop is ~3 us, and two dependent global
 // round trips behind it (operand reads, then the bias) were a fifth of the launch (K sweep: 7 us intercept,
@@ -65,7 +99,7 @@ __device__ __forceinline__ void z_prefetch(ZPre<BM * (BN / 8) / NTH>& zp, const 
   constexpr int N = BM * (BN / 8) / NTH, CPRW = BN / 8;
   zp.valid = false;
   if constexpr (sizeof(T) == 2 && (N == 4 || N == 8)) {
-    if (!g.vec_epilogue || !(g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD)) return;
+    if (!g.vec_epilogue || !act_reads_z(g.act)) return;
     zp.valid = true;
 #define ETP_ZFETCH(j)                                                                                             \
   (*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.Z) + (long)min(m0 + (tid + (j) * NTH) / CPRW, g.M - 1) * g.ldz + \
@@ -93,7 +127,7 @@ __device__ __forceinline__ void epi_fetch_chunk(EpiChunk& k, int j, const GemmAr
     k.c0 = p[0];
     if constexpr (VPC == 2) k.c1 = p[1];
   }
-  if (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD) {
+  if (act_reads_z(g.act)) {
     const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.Z) + (long)rowc * g.ldz + colc);
     k.z0 = p[0];
     if constexpr (VPT == 2) k.z1 = p[1];
@@ -137,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
     // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
     constexpr int VPC = 8 * (int)sizeof(TC) / 16;  // 16-byte vectors per 8-element chunk of the C type (1 or 2)
     constexpr int VPT = 8 * (int)sizeof(T) / 16;   // 16-byte vectors per 8-element chunk of T (bf16: 1, fp32: 2)
-    const bool has_r = g.R != nullptr, has_zr = (g.act == ETP_ACT_GELU_BWD || g.act == ETP_ACT_RELU_BWD),
+    const bool has_r = g.R != nullptr, has_zr = act_reads_z(g.act),
                has_c = (g.out_mode == 1);
     const bool has_bias = (g.bias != nullptr && ks == 0);
     // chunks per pass: all global reads of a pass are issued together (ONE memory round trip per pass; round 2 made four
@@ -218,15 +252,24 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
         if (ok) store8(Z + (long)row * g.ldz + col, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      } else if (g.act == ETP_ACT_GELU_SAVEGRAD) {
+        float dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_erf_both(v[e], v[e], dv[e]);
+        if (ok) store8_grad(Z + (long)row * g.ldz + col, dv);
       } else if (g.act == ETP_ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (has_zr) {
         float zf[8];
-        unpack8<T>(zz[jj], zf);
+        if (g.act == ETP_ACT_MUL_Z) unpack8_grad<T>(zz[jj], zf);
+        else unpack8<T>(zz[jj], zf);
         if (g.act == ETP_ACT_GELU_BWD) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(zf[e]);
+        } else if (g.act == ETP_ACT_MUL_Z) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= zf[e];
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
@@ -275,6 +318,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
     if (g.act == ETP_ACT_GELU) {
       Elem<T>::st(Z + (long)row * g.ldz + col, v);
       v = gelu_erf(v);
+    } else if (g.act == ETP_ACT_GELU_SAVEGRAD) {
+      float dv;
+      gelu_erf_both(v, v, dv);
+      st_grad(Z + (long)row * g.ldz + col, dv);
+    } else if (g.act == ETP_ACT_MUL_Z) {
+      v *= ld_grad(Z + (long)row * g.ldz + col);
     } else if (g.act == ETP_ACT_RELU) {
       v = fmaxf(v, 0.f);
     } else if (g.act == ETP_ACT_GELU_BWD) {

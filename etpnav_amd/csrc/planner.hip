@@ -22,6 +22,11 @@
 
 namespace etp {
 
+#ifdef ETP_OLD_GELU        // measurement builds only: the round-4 pair (saved pre-activation, erf arithmetic in the backward epilogue)
+#define ETP_ACT_GELU_SAVEGRAD ETP_ACT_GELU
+#define ETP_ACT_MUL_Z ETP_ACT_GELU_BWD
+#endif
+
 struct AttnP { int qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
 struct FfnP { int i_w, i_b, o_w, o_b, ln_g, ln_b; };
 struct TxtLayerP { AttnP att; FfnP ffn; };
@@ -546,7 +551,7 @@ static inline const void* op2(const Ctx& c, const Act& a, const Drop& d) { retur
 
 // ---- post-LN sub-blocks (BertAttention / BertXAttention / BertIntermediate+BertOutput) ---------
 struct SelfAttStash { void *qkv, *P, *ctx; float* s; float* st; Act y; void* Pd; };
-struct FfnStash { void *z, *h; float* s; float* st; Act y; };
+struct FfnStash { void *z, *h; float* s; float* st; Act y; };      // z: gelu'(pre-activation) (round 5: the forward saves the derivative)
 struct CrossStash { void *q, *kv, *P, *ctx; float* s; float* st; Act y; void* Pd; };
 
 static SelfAttStash plan_self(Bump& b, int dt, long M, int Bn, int nh, int L, int ldS, int H) {
@@ -637,7 +642,7 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
 
 static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M, float eps, int mode, int layer) {
   const int H = c.H, I = c.I;
-  ETP_TRY(linear_fwd(c, x.t, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU, f.z, nullptr, 0));
+  ETP_TRY(linear_fwd(c, x.t, H, p.i_w, p.i_b, f.h, I, M, I, H, ETP_ACT_GELU_SAVEGRAD, f.z, nullptr, 0));    // f.z = gelu'(pre-activation)
   ETP_TRY(linear_fwd_s(c, f.h, I, p.o_w, p.o_b, f.s, M, H, I, x.f, hid(c, mode, layer, SITE_FFN_O)));
   return ln_fwd_s(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y.f, lp(f.y, c.dt), f.st, M, H, eps, c.st);
 }
@@ -649,7 +654,7 @@ static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f,
   ETP_TRY(ln_bwd_chain(c, g_in ? g_in : g, f.s, f.st, p.ln_g, p.ln_b, nullptr, w.t1.f, lp2(c, w.t1, dh), M, dh, w.lnp));
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, f.h, I, p.o_w, p.o_b, M, H, I));
-  ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, f.z, I, nullptr, 0));            // dI = dz
+  ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_MUL_Z, f.z, I, nullptr, 0));               // dI = dz
   ETP_TRY(linear_wgrad(c, w.dI, I, x.t, H, p.i_w, p.i_b, M, I, H));
   return linear_dgrad_s(c, w.dI, I, p.i_w, g, M, I, H, w.t1.f);                                               // g = dx
 }
@@ -682,10 +687,13 @@ extern "C" {
 
 etp_planner* etp_planner_create(const etp_config* cfg) {
   if (!cfg) { set_error("etp_planner_create: null config"); return nullptr; }
-  if (cfg->hidden % 256 != 0 || cfg->hidden > 1024 || cfg->heads * 64 != cfg->hidden || cfg->inter % 8 != 0 ||
+  // hidden 256 / 512 / 768 (the reference's planners are BERT-base / XLM-R-base, 768): the row kernels keep a row's 4 * hidden / 256
+  // values per lane in registers, and at 1024 the panorama / node embedding kernels no longer fit the 256 VGPRs a kernel without
+  // MFMAs may use (tools/kernel_resources.py)
+  if (cfg->hidden % 256 != 0 || cfg->hidden > 768 || cfg->heads * 64 != cfg->hidden || cfg->inter % 8 != 0 ||
       cfg->img_feat % 8 != 0 || (cfg->use_depth && cfg->dep_feat % 8 != 0) || cfg->ang_feat != 4 ||
       (cfg->dtype != ETP_F32 && cfg->dtype != ETP_BF16) || cfg->n_l < 0 || cfg->n_p < 0 || cfg->n_x < 0) {
-    set_error("etp_planner_create: unsupported config (hidden must be 256..1024 in steps of 256 with 64-wide heads, "
+    set_error("etp_planner_create: unsupported config (hidden must be 256, 512 or 768 with 64-wide heads, "
               "feature sizes multiples of 8, angle_feat_size 4)");
     return nullptr;
   }
@@ -861,6 +869,9 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     stamp_mark(c.st, 2200 + 10 * l + 1);
     // the LAST layer of the backward: its two FFN weight gradients go out now instead of with the attention ones at the end of
     // the layer -- nothing runs behind this layer that could hide them (the step's end waits for the weight-gradient stream)
+    // (round 5, measured again with the mm32 kernels: a second fork per layer -- FFN pair here, attention pair at the end -- and a
+    // 256-tile budget that leaves every CU room for a chain workgroup both cost +1..2 %: profiles/r05_ab_runs.json; the patch is
+    // tools/experiments/r05_ln_fold_and_flush_split.patch)
     if (l == 0 && layer_lo == 0) ETP_TRY(flush_side(c));
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
@@ -1023,7 +1034,7 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
     ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x, hid(c, MODE_PANO, l, SITE_ATT_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), c.dt == ETP_BF16 ? nullptr : (float*)t.f,
                      c.dt == ETP_BF16 ? t.f : nullptr, t.st2, M, H, 1e-5f, c.st));
-    ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU, t.z, nullptr, 0, hid(c, MODE_PANO, l, SITE_FFN_I)));
+    ETP_TRY(linear_fwd(c, t.f, H, q.l1_w, q.l1_b, t.h, I, M, I, H, ETP_ACT_GELU_SAVEGRAD, t.z, nullptr, 0, hid(c, MODE_PANO, l, SITE_FFN_I)));
     ETP_TRY(linear_fwd_s(c, t.h, I, q.l2_w, q.l2_b, t.x2, M, H, I, t.x1, hid(c, MODE_PANO, l, SITE_FFN_O)));
     x = t.x2;
   }
@@ -1064,7 +1075,7 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     // FFN: x2 = x1 + W2 gelu(W1 LN2(x1))
     const void* gop = op2(c, g, gd);                                                                              // dx2 * mask(dropout2)
     ETP_TRY(linear_wgrad(c, gop, H, t.h, I, q.l2_w, q.l2_b, M, H, I));
-    ETP_TRY(linear_dgrad(c, gop, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_GELU_BWD, t.z, I, nullptr, 0, 0,
+    ETP_TRY(linear_dgrad(c, gop, H, q.l2_w, w.dI, I, M, H, I, ETP_ACT_MUL_Z, t.z, I, nullptr, 0, 0,
                          hid(c, MODE_PANO, l, SITE_FFN_I)));
     ETP_TRY(linear_wgrad(c, w.dI, I, t.f, H, q.l1_w, q.l1_b, M, I, H));
     ETP_TRY(linear_dgrad_s(c, w.dI, I, q.l1_w, w.t1f, M, I, H, nullptr));                                         // t1f = df

@@ -32,6 +32,12 @@ extern "C" {
 #define ETP_ACT_RELU 2      /* C = relu(v)                           (NextActionPrediction :654-655)           */
 #define ETP_ACT_GELU_BWD 3  /* C = v * gelu_erf'(Z)                                                              */
 #define ETP_ACT_RELU_BWD 4  /* C = v * (Z > 0)                                                                   */
+/* Round 5: the GELU pair the planner's FFN blocks use.  The erf arithmetic made the GELU / GELU' epilogues VALU-bound (measured
+ * with the arithmetic compiled out: FFN-up epilogue 8.2 -> 3.8 us, FFN dgrad 11.5 -> 5.5 us, profiles/r05_epilogue_valu.txt), and the
+ * forward has everything the derivative needs in registers (cdf and exp(-v^2/2)): it saves gelu_erf'(v) instead of v, the backward
+ * epilogue is a multiply.  Same stash footprint; nothing else reads the pre-activation. */
+#define ETP_ACT_GELU_SAVEGRAD 5  /* C = gelu_erf(v), aux Z = gelu_erf'(v)   (bf16 mode: Z holds IEEE HALF values -- the      */
+#define ETP_ACT_MUL_Z 6          /* C = v * Z                                derivative lies in [-0.13, 1.13], 11 bits > bf16's 8) */
 
 typedef void* etp_stream_t; /* hipStream_t */
 

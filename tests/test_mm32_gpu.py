@@ -83,6 +83,15 @@ def test_mm32_epilogues(cls, tb, monkeypatch):
     assert (Cb.float() - raw * gelu_grad(Zin.float())).abs().max().item() <= btol(K), (cls, tb, "dgelu")
     run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, Z=Zin, act=_lib.ACT_RELU_BWD)
     assert (Cb.float() - raw * (Zin.float() > 0)).abs().max().item() <= btol(K), (cls, tb, "drelu")
+    # round 5: forward saves the derivative (ACT_GELU_SAVEGRAD), backward multiplies by it (ACT_MUL_Z)
+    # (the 2-byte Z buffer of this pair holds IEEE half values: the derivative lies in [-0.13, 1.13])
+    Zg = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16)
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, alpha=0.5, bias=bias, Z=Zg, act=_lib.ACT_GELU_SAVEGRAD)
+    assert (Cb.float() - gelu(v)).abs().max().item() <= btol(K), (cls, tb, "gelu+grad")
+    assert (Zg.float() - gelu_grad(v)).abs().max().item() <= 1e-3, (cls, tb, "saved gelu'")
+    Zh = Zin.float().half()
+    run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, Z=Zh, act=_lib.ACT_MUL_Z)
+    assert (Cb.float() - raw * Zh.float()).abs().max().item() <= btol(K), (cls, tb, "mul z")
     run_gemm(As, Bs, Cb, M, N, K, 0, tb, BF, bias=bias, act=_lib.ACT_RELU)
     assert (Cb.float() - torch.relu(raw + bias)).abs().max().item() <= btol(K), (cls, tb, "relu")
     C0 = torch.randn(M, N, device=DEV)

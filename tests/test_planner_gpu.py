@@ -111,7 +111,9 @@ def test_bf16_step_close_to_reference_golden(name):
     step = PlannerStep(model, batch)
     step.run_eager()
     compare_outputs(z, step_outputs(step), atol=5e-2)
-    ws, wl = compare_grads_bf16(z, grads_of(model))
+    from tests.golden_util import BF16_B1_SAMPLE_REL, BF16_B1_L2_REL
+    b1 = batch["txt_ids"].shape[0] == 1       # single-episode fixture: input-dependent common-mode error (golden_util.py, profiles/r05_b1_noise.txt)
+    ws, wl = compare_grads_bf16(z, grads_of(model), **(dict(sample_rel=BF16_B1_SAMPLE_REL, l2_rel=BF16_B1_L2_REL) if b1 else {}))
     print(name, "bf16 worst sample err / abs-max", ws, "worst |dL2| / L2", wl)
 
 

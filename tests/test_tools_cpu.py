@@ -30,3 +30,35 @@ def test_traffic_rows_drop_the_ring_depth_and_other_kernels_keep_their_name():
     # the key bench.py derives from its own kernel label must hit the same row
     label = "mm32_group<bf16,f32,TN,128x128,s2>"
     assert label.split(",s")[0] + ">" == "mm32_group<bf16,f32,TN,128x128>"
+
+
+def test_kernel_resource_policy_holds_for_the_built_objects():
+    """tools/kernel_resources.py: no kernel outside the matrix-core families holds AGPRs, no kernel uses scratch --
+    read from the code-object metadata of the objects etpnav_amd.build produced (the build itself fails on a violation; this test
+    keeps the parser honest and pins the production row kernels' register budgets)."""
+    import pytest
+    from etpnav_amd import build as b
+    from tools import kernel_resources as kr
+    objs = [os.path.join(b.HERE, "build", s.replace(".hip", ".o")) for s in b.SOURCES]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("objects not built here")
+    rows = kr.audit()
+    assert len(rows) > 250 and not [r for r in rows if r["violation"]], [r["full"] for r in rows if r["violation"]]
+    by = {r["name"]: r for r in rows}
+    for k in ("pano_embed_bwd_kernel<unsigned short, 3>", "pano_embed_fwd_kernel<unsigned short, 3>", "gmap_embed_bwd_kernel<float, 3, 7>"):
+        assert int(by[k]["agpr_count"]) == 0 and int(by[k]["vgpr_count"]) <= 256 and int(by[k]["private_segment_fixed_size"]) == 0, by[k]
+    assert any(int(r["agpr_count"]) > 0 and r["mfma"] for r in rows)      # the parser does see AGPRs where they are allowed
+    # the parser on a literal note
+    note = """
+  - .agpr_count:     8
+    .args:
+      - .offset:         0
+        .size:           8
+    .name:           _ZN3etp3fooEv
+    .private_segment_fixed_size: 16
+    .sgpr_count:     10
+    .vgpr_count:     20
+    .vgpr_spill_count: 1
+"""
+    (k,) = kr.parse(note)
+    assert k["agpr_count"] == "8" and k["private_segment_fixed_size"] == "16" and k["vgpr_spill_count"] == "1" and k["name"] == "_ZN3etp3fooEv"

@@ -250,16 +250,19 @@ def _screen(step, model, runs, rel):
         stack = torch.stack([r[n].double().reshape(-1) for r in snaps])
         med = stack.median(0).values
         scale = max(float(med.abs().max()), 1e-6)
-        dev = float(((stack - med).abs().max(1).values / scale).max())
-        if dev > rel:
-            bad.append((dev, n))
+        adev = float((stack - med).abs().max())
+        if adev / scale > rel and adev > _ABS_FLOOR.get(n, 0.0):
+            bad.append((adev / scale, n))
     return sorted(bad, reverse=True)
 
 
 # cancelling sums whose value is ~1e-3 of their summands (or exactly zero in exact arithmetic: d(net.4.bias) = sum of the CE
 # gradient over the nodes of every episode = sum(softmax) - 1 = 0): fp32 atomic order shows at 1e-4 .. 1e-2 of the tiny result
 # (first GPU run of this test: net.4.bias 3.2e-2 of a 1e-6 floor, [sum] word_embeddings 7e-4)
-_NEAR_ZERO_SUMS = ("global_encoder.sprel_linear.", "[sum] ", "global_sap_head.net.4.bias")
+_NEAR_ZERO_SUMS = ("global_encoder.sprel_linear.", "[sum] ")
+# d(global_sap_head.net.4.bias) = sum over all nodes of the CE gradient = B^-1 * sum_b (sum_g softmax - 1) = 0 in exact arithmetic:
+# what is left is the fp32 atomic-order noise of ~500 summands of magnitude 1/B (observed 3e-8 .. 9e-8 absolute)
+_ABS_FLOOR = {"global_sap_head.net.4.bias": 1e-6}
 
 
 @pytest.mark.parametrize("workload", ["c2_train", "c5", "sap"])
@@ -282,7 +285,7 @@ def test_three_stream_step_reproduces_every_gradient(workload):
         batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"], seed=1234)
     step = PlannerStep(model, batch, overlap=True, dropout=(0.1, 0.1, 0.1, 0.4) if workload.endswith("train") else None, drop_seed=9)
     bad = _screen(step, model, runs=10, rel=2e-5)
-    hard = [(d, n) for d, n in bad if not (n.startswith(_NEAR_ZERO_SUMS) and d < 5e-2)]
+    hard = [(d, n) for d, n in bad if not (n.startswith(_NEAR_ZERO_SUMS) and d < 2e-3)]
     print(workload, "tensors above 2e-5:", bad[:8])
     assert not hard, hard[:8]
     step.close()
