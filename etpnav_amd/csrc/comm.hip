@@ -120,6 +120,8 @@ __global__ void rows_scatter_kernel(float* __restrict__ table, long n_rows, long
 struct etp_comm {
   void* rows_ids = nullptr; void* rows_buf = nullptr;   // gather_rows staging: [world + 1][capacity] ids / rows (slot 0 = send block)
   void* rows_in = nullptr;                              // the caller's ids, copied on the producer stream (the caller may free its tensor)
+  hipEvent_t rows_read = nullptr;                       // recorded behind rows_pack: the next call's copy into rows_in waits for it
+  bool rows_pending = false;
   int64_t rows_cap = 0, rows_len = 0;
   rcclComm_t comm = nullptr;
   int rank = 0, world = 1, comm_dtype = ETP_F32;
@@ -163,7 +165,7 @@ int etp_allreduce_init(etp_comm** out, const void* unique_id, int rank, int worl
   c->events.resize(64);
   for (auto& e : c->events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   if (comm_dtype == ETP_BF16 && max_bucket_elems > 0) {
-    c->staging_elems = round_up(max_bucket_elems, (long)world * 64);
+    c->staging_elems = etp_allreduce_staging_elems(max_bucket_elems, world);
     rc = check_hip(hipMalloc(&c->staging, (size_t)c->staging_elems * 2), "hipMalloc(staging)");
     if (rc) { etp_allreduce_destroy(c); return rc; }
   }
@@ -174,6 +176,29 @@ int etp_allreduce_init(etp_comm** out, const void* unique_id, int rank, int worl
 int etp_allreduce_rank(const etp_comm* c) { return c ? c->rank : -1; }
 int etp_allreduce_world(const etp_comm* c) { return c ? c->world : 0; }
 etp_stream_t etp_allreduce_stream(const etp_comm* c) { return c ? (etp_stream_t)c->stream : nullptr; }
+
+// Slice arithmetic of one dense bucket of n fp32 gradients over `world` ranks (a pure function: host-side unit tests cover worlds
+// 2 / 4 / 8 without a second GPU, tests/test_dp_gloo.py):
+//   fp32 transport: reduce-scatter + all-gather over body = per * world elements, per a multiple of 64 (256-byte slices), and one
+//                   all-reduce over the tail [body, n) (fewer than world * 64 elements);
+//   bf16 transport: the bucket is staged as bf16, padded with zeros to per * world elements (per a multiple of 8: 16-byte slices),
+//                   reduce-scatter + all-gather over the whole staged copy, no tail.
+// out[0] = per, out[1] = body (elements covered by the scatter / gather), out[2] = tail elements, out[3] = staged elements.
+int etp_allreduce_plan(int64_t n, int world, int comm_dtype, int64_t* out) {
+  ETP_REQUIRE(out && n >= 0 && world >= 1 && (comm_dtype == ETP_F32 || comm_dtype == ETP_BF16), "bad arguments");
+  if (comm_dtype == ETP_BF16) {
+    const int64_t per = round_up(n, (long)world * 8) / world;
+    out[0] = per; out[1] = per * world; out[2] = 0; out[3] = per * world;
+  } else {
+    const int64_t per = (n / ((int64_t)world * 64)) * 64;
+    out[0] = per; out[1] = per * world; out[2] = n - per * world; out[3] = 0;
+  }
+  return ETP_OK;
+}
+// staging capacity (bf16 elements) etp_allreduce_init allocates for buckets of up to max_bucket_elems
+int64_t etp_allreduce_staging_elems(int64_t max_bucket_elems, int world) {
+  return (max_bucket_elems > 0 && world >= 1) ? round_up(max_bucket_elems, (long)world * 64) : 0;
+}
 
 // grads[0, n) <- mean over ranks, in place.  Everything enqueued on `producer` so far completes before the bucket is read.
 int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_t producer) {
@@ -186,10 +211,12 @@ int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_
   ETP_CHECK_HIP(hipStreamWaitEvent(cs, e, 0));
   const int W = c->world;
   const float inv = 1.0f / (float)W;
+  int64_t plan[4];
+  ETP_TRY(etp_allreduce_plan(n, W, c->comm_dtype, plan));
   if (c->comm_dtype == ETP_BF16) {
-    ETP_REQUIRE(c->staging && n <= c->staging_elems, "bucket larger than max_bucket_elems given to etp_allreduce_init");
+    ETP_REQUIRE(c->staging && plan[3] <= c->staging_elems, "bucket larger than max_bucket_elems given to etp_allreduce_init");
     // pack -> reduce-scatter + all-gather on the packed copy -> unpack with the 1/world scaling
-    const long per = round_up(n, (long)W * 8) / W;                 // elements per rank (16-byte slices); pad region is garbage-free:
+    const long per = plan[0];                                      // elements per rank (16-byte slices); pad region is garbage-free:
     ETP_TRY(cast_f32_to_bf16(grads, c->staging, n, cs));
     if (per * W > n) ETP_CHECK_HIP(hipMemsetAsync((char*)c->staging + n * 2, 0, (size_t)(per * W - n) * 2, cs));
     char* mine = (char*)c->staging + (size_t)c->rank * per * 2;
@@ -197,8 +224,7 @@ int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_
     ETP_CHECK_RCCL(g_rccl.AllGather(mine, c->staging, (size_t)per, RCCL_BFLOAT16, c->comm, cs));
     return cast_bf16_to_f32(c->staging, grads, n, inv, cs);
   }
-  const int64_t per = (n / ((int64_t)W * 64)) * 64;                // 256-byte-aligned slice per rank
-  const int64_t body = per * W;
+  const int64_t per = plan[0], body = plan[1];                     // 256-byte-aligned slice per rank
   if (per > 0) {
     float* mine = grads + (int64_t)c->rank * per;
     ETP_CHECK_RCCL(g_rccl.ReduceScatter(grads, mine, (size_t)per, RCCL_FLOAT32, RCCL_SUM, c->comm, cs));
@@ -239,6 +265,9 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
   hipStream_t prod = (hipStream_t)producer, cs = c->stream;
   // the ids are copied into the communicator's own block ON THE PRODUCER STREAM: the caller's tensor (often a temporary: a cast or
   // a concatenation) may be freed and its memory recycled as soon as this call returns
+  // (a second exchange before etp_allreduce_wait -- another table, the next accumulation window -- must not overwrite the ids the
+  // first one's pack kernel has not read yet: ADVICE r4)
+  if (c->rows_pending) ETP_CHECK_HIP(hipStreamWaitEvent(prod, c->rows_read, 0));
   if (n_ids > 0) ETP_CHECK_HIP(hipMemcpyAsync(c->rows_in, ids, (size_t)n_ids * sizeof(int64_t), hipMemcpyDeviceToDevice, prod));
   ids = (const int64_t*)c->rows_in;
   hipEvent_t e = c->next_event();
@@ -256,6 +285,9 @@ int etp_allreduce_gather_rows(etp_comm* c, float* table, int64_t n_rows, int64_t
     ETP_LAUNCH(rows_pack_kernel<float>, dim3((unsigned)capacity), dim3(256), 0, cs, table, (long)n_rows, (long)row_len, ids, (long)n_ids, send_ids,
                (float*)send_rows);
   ETP_CHECK_LAUNCH("rows_pack");
+  if (!c->rows_read) ETP_CHECK_HIP(hipEventCreateWithFlags(&c->rows_read, hipEventDisableTiming));
+  ETP_CHECK_HIP(hipEventRecord(c->rows_read, cs));
+  c->rows_pending = true;
   ETP_CHECK_RCCL(g_rccl.AllGather(send_ids, all_ids, (size_t)capacity * 2, RCCL_FLOAT32, c->comm, cs));   // int64 ids as 2 x 32-bit words
   ETP_CHECK_RCCL(g_rccl.AllGather(send_rows, all_rows, (size_t)capacity * row_len, c->comm_dtype == ETP_BF16 ? RCCL_BFLOAT16 : RCCL_FLOAT32,
                                   c->comm, cs));

@@ -9,6 +9,8 @@
 // Reference sites are cited at each kernel.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace etp {
@@ -279,63 +281,34 @@ __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict
   }
 }
 
-constexpr int PANO_LDS_ROWS = 8;
-template <typename T, int NCH>
+// Backward of the fuse, in THREE launches (round 5).  The single-launch form kept sixteen row-sized accumulators per lane: 482 registers,
+// 226 of them AGPRs (tools/kernel_resources.py) -- the register class DESIGN.md §3.6 bans outside the matrix-core kernels -- and one
+// wavefront per SIMD.  A first rewrite moved eight accumulators into per-wavefront LDS regions (108 KB): no AGPRs, but its sums then
+// deviated from run to run whenever other kernels' workgroups shared the CU (race screen of tests/test_variants_gpu.py; clean with the
+// CU's whole LDS to itself, which cost the step 0.1 ms; profiles/r05_lds_neighbour.txt).  Now each launch rebuilds the row's branch sum
+// and carries only its own accumulators in registers:
+//   PART 0  the outer LayerNorm: gamma_out, beta_out, sum(de), nav_emb[0]            (4 rows; sum(de) serves type1, the three inner
+//           biases and nav_emb[0] + nav_emb[1]: they all receive the same column sum of the branch-sum gradient `de`)
+//   PART 1  the RGB and depth branches: gamma_img, gamma_dep (2 rows) and the GEMM-side gradients da / dd
+//   PART 2  the angle branch: gamma_loc, bias_loc, w_loc[., 0..3]                    (6 rows)
+// (the row state itself -- e, x, t, de, the operand rows in flight -- is ~175 registers: at most six accumulator rows fit beside it)
+// The base pointers of the parameter vectors pass through an empty asm every row trip: the compiler used to hoist all eleven vectors
+// (plus the [H, 4] angle projection) out of the three-trip loop, ~180 registers of loop-invariant operands.
+template <typename T, int NCH, int PART>
 __global__ __launch_bounds__(256, 2) void pano_embed_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ a,
-                                                             const T* __restrict__ d, const float* __restrict__ loc,
-                                                             const int64_t* __restrict__ nav, const float* __restrict__ stats,
-                                                             PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
-                                                             T* __restrict__ dd, int M, Drop drop) {
+                                                                const T* __restrict__ d, const float* __restrict__ loc,
+                                                                const int64_t* __restrict__ nav, const float* __restrict__ stats,
+                                                                PanoEmbedParams p, PanoEmbedGrads g, T* __restrict__ da,
+                                                                T* __restrict__ dd, int M, Drop drop) {
   constexpr int H = NCH * 256;
-  // Accumulators of the parameter gradients that reduce over rows.  Round 5 (tools/kernel_resources.py: this kernel held 482
-  // registers, 226 of them AGPRs -- one wavefront per SIMD and the register class DESIGN.md §3.6 bans outside the matrix-core
-  // kernels):
-  //   * the three inner LayerNorm biases, type1 and nav_emb[0] + nav_emb[1] all receive the SAME column sum of `de` (the gradient
-  //     of the branch sum): one accumulator (A_ty) serves five gradients, nav_emb[1] = A_ty - A_nav0 at the flush;
-  //   * the six rows of the angle branch (gamma_loc, bias_loc, w_loc[., 0..3]) and the two plain sums (beta_out, nav_emb[0]) live in
-  //     LDS, one private region per wavefront, every lane read-modify-writes only its own twelve columns (plain 16-byte accesses,
-  //     no atomics, no barrier);
-  //   * four rows stay in registers: gamma x {img, dep, out}, sum(de).
-  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats (block_flush) + 4 wavefronts x PANO_LDS_ROWS x H
-  Row<NCH> A_gi, A_gd, A_go, A_ty;
-  row_zero<NCH>(A_gi); row_zero<NCH>(A_gd); row_zero<NCH>(A_go); row_zero<NCH>(A_ty);
-  enum { L_GL = 0, L_LB = 1, L_LW0 = 2, L_BO = 6, L_NAV0 = 7 };   // LDS rows: gamma_loc, bias_loc, w_loc[., 0..3], beta_out, nav_emb[0]
-  float* wl = scratch + 4 * H + (threadIdx.x >> 6) * PANO_LDS_ROWS * H + (threadIdx.x & 63) * 4;
-#pragma unroll
-  for (int r = 0; r < PANO_LDS_ROWS; ++r)
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(wl + r * H + c * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto lds_acc = [&](int r, const Row<NCH>& a, float sc) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      float4* q = reinterpret_cast<float4*>(wl + r * H + c * 256);
-      float4 o = *q;
-      o.x += a.v[c][0] * sc; o.y += a.v[c][1] * sc; o.z += a.v[c][2] * sc; o.w += a.v[c][3] * sc;
-      *q = o;
-    }
-  };
-  auto lds_acc_mul = [&](int r, const Row<NCH>& a, const Row<NCH>& b) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      float4* q = reinterpret_cast<float4*>(wl + r * H + c * 256);
-      float4 o = *q;
-      o.x += a.v[c][0] * b.v[c][0]; o.y += a.v[c][1] * b.v[c][1]; o.z += a.v[c][2] * b.v[c][2]; o.w += a.v[c][3] * b.v[c][3];
-      *q = o;
-    }
-  };
-  auto lds_row = [&](int r, Row<NCH>& a) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const float4 o = *reinterpret_cast<const float4*>(wl + r * H + c * 256);
-      a.v[c][0] = o.x; a.v[c][1] = o.y; a.v[c][2] = o.z; a.v[c][3] = o.w;
-    }
-  };
+  extern __shared__ __attribute__((aligned(16))) float scratch[];   // 4*H floats (block_flush staging)
+  Row<NCH> A0, A1, A2, A3, A4, A5;       // PART 0: go, bo, ty, nav0 | PART 1: gi, gd | PART 2: gl, lb, lw0..3
+  row_zero<NCH>(A0); row_zero<NCH>(A1);
+  if constexpr (PART != 1) { row_zero<NCH>(A2); row_zero<NCH>(A3); }
+  if constexpr (PART == 2) { row_zero<NCH>(A4); row_zero<NCH>(A5); }
   const int lane = threadIdx.x & 63;
   const PanoEmbedParams p0 = p;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    // The parameter vectors are loop-invariant and the compiler used to hoist all eleven of them (plus the [H, 4] angle projection)
-    // out of this three-trip loop: ~180 registers of operands parked beside the accumulators, 226 of them in AGPRs.  The base
-    // pointers are passed through an empty asm every trip, so every use re-loads from L1 / L2 (a few KB, resident) instead.
     PanoEmbedParams p = p0;
     asm volatile("" : "+s"(p.g_img), "+s"(p.b_img), "+s"(p.g_dep), "+s"(p.b_dep), "+s"(p.w_loc), "+s"(p.bias_loc));
     asm volatile("" : "+s"(p.g_loc), "+s"(p.b_loc), "+s"(p.nav_emb), "+s"(p.type1), "+s"(p.g_out), "+s"(p.b_out));
@@ -376,60 +349,70 @@ __global__ __launch_bounds__(256, 2) void pano_embed_bwd_kernel(const float* __r
     // outer LN backward
     row_load<NCH>(de, dy + (long)row * H, lane);
     row_dropout<NCH>(de, drop, row, lane);
-    acc_mul<NCH>(A_go, de, e);
-    lds_acc(L_BO, de, 1.0f);
-    row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);   // de = grad wrt the branch sum
-    lds_acc(L_NAV0, de, nv == 0 ? 1.0f : 0.0f);
-    acc_scaled<NCH>(A_ty, de, 1.0f);                // = d type1 = d beta_{img, dep, loc} = d nav_emb[0] + d nav_emb[1]
-    // loc branch (x still holds its xhat)
-    t = de;
-    lds_acc_mul(L_GL, t, x);
-    row_ln_bwd<NCH>(t, x, p.g_loc, st[5], lane);
-    lds_acc(L_LB, t, 1.0f);
-    {
-      const float* l4 = loc + (long)row * 4;
-      lds_acc(L_LW0, t, l4[0]); lds_acc(L_LW0 + 1, t, l4[1]);
-      lds_acc(L_LW0 + 2, t, l4[2]); lds_acc(L_LW0 + 3, t, l4[3]);
+    if constexpr (PART == 0) {
+      acc_mul<NCH>(A0, de, e);                        // gamma_out
+      acc_scaled<NCH>(A1, de, 1.0f);                  // beta_out
     }
-    // img branch
-    row_load<NCH>(x, a + (long)row * H, lane);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
-    t = de;
-    acc_mul<NCH>(A_gi, t, x);
-    row_ln_bwd<NCH>(t, x, p.g_img, st[1], lane);
-    row_store<NCH>(t, da + (long)row * H, lane);
-    if (d != nullptr) {
-      row_load<NCH>(x, d + (long)row * H, lane);
+    row_ln_bwd<NCH>(de, e, p.g_out, st[7], lane);     // de = grad wrt the branch sum
+    if constexpr (PART == 0) {
+      acc_scaled<NCH>(A2, de, 1.0f);                  // = d type1 = d beta_{img, dep, loc} = d nav_emb[0] + d nav_emb[1]
+      acc_scaled<NCH>(A3, de, nv == 0 ? 1.0f : 0.0f);
+    } else if constexpr (PART == 2) {
+      // loc branch (x still holds its xhat)
+      t = de;
+      acc_mul<NCH>(A0, t, x);
+      row_ln_bwd<NCH>(t, x, p.g_loc, st[5], lane);
+      acc_scaled<NCH>(A1, t, 1.0f);
+      {
+        const float* l4 = loc + (long)row * 4;
+        acc_scaled<NCH>(A2, t, l4[0]); acc_scaled<NCH>(A3, t, l4[1]);
+        acc_scaled<NCH>(A4, t, l4[2]); acc_scaled<NCH>(A5, t, l4[3]);
+      }
+    } else {
+      // img branch
+      row_load<NCH>(x, a + (long)row * H, lane);
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
+        for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[0]) * st[1];
       t = de;
-      acc_mul<NCH>(A_gd, t, x);
-      row_ln_bwd<NCH>(t, x, p.g_dep, st[3], lane);
-      row_store<NCH>(t, dd + (long)row * H, lane);
+      acc_mul<NCH>(A0, t, x);
+      row_ln_bwd<NCH>(t, x, p.g_img, st[1], lane);
+      row_store<NCH>(t, da + (long)row * H, lane);
+      if (d != nullptr) {
+        row_load<NCH>(x, d + (long)row * H, lane);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x.v[c][k] = (x.v[c][k] - st[2]) * st[3];
+        t = de;
+        acc_mul<NCH>(A1, t, x);
+        row_ln_bwd<NCH>(t, x, p.g_dep, st[3], lane);
+        row_store<NCH>(t, dd + (long)row * H, lane);
+      }
     }
   }
-  block_flush<NCH>(scratch, A_gi, g.g_img, 1, 0); block_flush<NCH>(scratch, A_ty, g.b_img, 1, 0);
-  if (d != nullptr) { block_flush<NCH>(scratch, A_gd, g.g_dep, 1, 0); block_flush<NCH>(scratch, A_ty, g.b_dep, 1, 0); }
-  block_flush<NCH>(scratch, A_ty, g.b_loc, 1, 0);
-  block_flush<NCH>(scratch, A_go, g.g_out, 1, 0);
-  block_flush<NCH>(scratch, A_ty, g.type1, 1, 0);
-  // the LDS-resident rows come back through A_gi (free now)
-  lds_row(L_BO, A_gi); block_flush<NCH>(scratch, A_gi, g.b_out, 1, 0);
-  lds_row(L_NAV0, A_gi); block_flush<NCH>(scratch, A_gi, g.nav_emb, 1, 0);
+  if constexpr (PART == 0) {
+    block_flush<NCH>(scratch, A0, g.g_out, 1, 0); block_flush<NCH>(scratch, A1, g.b_out, 1, 0);
+    block_flush<NCH>(scratch, A2, g.b_img, 1, 0);
+    if (d != nullptr) block_flush<NCH>(scratch, A2, g.b_dep, 1, 0);
+    block_flush<NCH>(scratch, A2, g.b_loc, 1, 0);
+    block_flush<NCH>(scratch, A2, g.type1, 1, 0);
+    block_flush<NCH>(scratch, A3, g.nav_emb, 1, 0);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A_gi.v[c][k] = A_ty.v[c][k] - A_gi.v[c][k];           // rows with nav_type 1
-  block_flush<NCH>(scratch, A_gi, g.nav_emb + H, 1, 0);
-  lds_row(L_GL, A_gi); block_flush<NCH>(scratch, A_gi, g.g_loc, 1, 0);
-  lds_row(L_LB, A_gi); block_flush<NCH>(scratch, A_gi, g.bias_loc, 1, 0);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { lds_row(L_LW0 + j, A_gi); block_flush<NCH>(scratch, A_gi, g.w_loc, 4, j); }
+      for (int k = 0; k < 4; ++k) A3.v[c][k] = A2.v[c][k] - A3.v[c][k];           // rows with nav_type 1
+    block_flush<NCH>(scratch, A3, g.nav_emb + H, 1, 0);
+  } else if constexpr (PART == 1) {
+    block_flush<NCH>(scratch, A0, g.g_img, 1, 0);
+    if (d != nullptr) block_flush<NCH>(scratch, A1, g.g_dep, 1, 0);
+  } else {
+    block_flush<NCH>(scratch, A0, g.g_loc, 1, 0);
+    block_flush<NCH>(scratch, A1, g.bias_loc, 1, 0);
+    block_flush<NCH>(scratch, A2, g.w_loc, 4, 0); block_flush<NCH>(scratch, A3, g.w_loc, 4, 1);
+    block_flush<NCH>(scratch, A4, g.w_loc, 4, 2); block_flush<NCH>(scratch, A5, g.w_loc, 4, 3);
+  }
 }
 
 // --------------------------------------------------------------------------------------
@@ -866,12 +849,12 @@ int pano_embed_fwd(int dtype, const void* a, const void* d, const float* loc, co
   return ETP_OK;
 }
 
-template <typename TT, int NCH>
+template <typename TT, int NCH, int PART>
 static int launch_pano_embed_bwd(int grid, size_t smem, hipStream_t st, const float* dy, const void* a, const void* d, const float* loc,
                                  const int64_t* nav, const float* stats, const PanoEmbedParams& p, const PanoEmbedGrads& g, void* da,
                                  void* dd, int M, Drop drop) {
   void (*kern)(const float*, const TT*, const TT*, const float*, const int64_t*, const float*, PanoEmbedParams, PanoEmbedGrads, TT*, TT*,
-               int, Drop) = pano_embed_bwd_kernel<TT, NCH>;
+               int, Drop) = pano_embed_bwd_kernel<TT, NCH, PART>;
   static bool attr_set = false;       // more than 64 KB of dynamic LDS needs the attribute once per instantiation
   if (!attr_set) {
     ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -887,9 +870,20 @@ int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, con
                    hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
-  const size_t smem = (4 + 4 * PANO_LDS_ROWS) * (size_t)H * sizeof(float);   // block_flush staging + the wavefronts' LDS accumulators (108 KB at H = 768)
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, return (launch_pano_embed_bwd<bf16_t, NCH>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))); }
-  else { ETP_DISPATCH_H(H, return (launch_pano_embed_bwd<float, NCH>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))); }
+  // The launches ask for the CU's WHOLE LDS (160 KB; they use 12 KB): no workgroup of another kernel can then share the CU.  Every
+  // form of this backward that shared SIMDs with other kernels' wavefronts returned sums that moved from run to run (race screen of
+  // tests/test_variants_gpu.py, profiles/r05_pano_embed_race.txt): the round-4 kernel was only stable because its 482 registers kept
+  // each SIMD to itself.  The mechanism is open; the exclusivity is now explicit instead of a side effect of AGPRs.
+  const size_t smem = 160 * 1024;
+  if (dtype == ETP_BF16) {
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<bf16_t, NCH, 0>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<bf16_t, NCH, 1>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<bf16_t, NCH, 2>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+  } else {
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<float, NCH, 0>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<float, NCH, 1>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+    ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<float, NCH, 2>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
+  }
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }

@@ -5,8 +5,9 @@ file keyed ``"{scan}_{viewpoint}" -> float array [36, F]`` (one file for the RGB
 demand and optionally cached in memory.
 
 Backends (chosen by file suffix):
-  * ``.hdf5`` / ``.h5``  the reference's files, through ``h5py`` — gated: this image does not ship h5py, the class raises a
-    clear ImportError at open time when it is missing (no silent fallback);
+  * ``.hdf5`` / ``.h5``  the reference's files: through ``h5py`` where the interpreter has it, else through the built-in
+    pure-Python reader of exactly the format subset those files use (``etpnav_amd/hdf5_lite.py``: v0 superblock, symbol-table
+    root group, gzip-compressed chunked float32 datasets; validated against a file written by the real h5py);
   * ``.etpf``            a flat pack written by :func:`write_flat_pack` (raw little-endian float32 rows + a JSON index):
     ``np.memmap``-readable without any dependency; :func:`convert_hdf5` turns the reference's files into it where h5py exists.
 
@@ -75,25 +76,31 @@ class _FlatPack:
 
 
 class _Hdf5:
+    """The reference's files.  h5py when the interpreter has it, else the built-in reader (etpnav_amd/hdf5_lite.py: the subset of the
+    format h5py's default settings write for these files -- validated against a file written by the real h5py,
+    tests/golden/feats_small.hdf5); a file outside that subset raises hdf5_lite.Hdf5Unsupported with the reason."""
+
     def __init__(self, path: str):
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise ImportError(f"{path}: reading the reference's HDF5 feature files needs h5py, which this environment does not "
-                              f"provide; convert them once with etpnav_amd.features.convert_hdf5 where h5py exists") from e
         self.path = path
-        with h5py.File(path, "r") as f:
-            self.keys = list(f.keys())
+        try:
+            import h5py
+            self._h5py = h5py
+            with h5py.File(path, "r") as f:
+                self.keys = list(f.keys())
+        except ImportError:
+            from . import hdf5_lite
+            self._h5py = None
+            self._lite = hdf5_lite.File(path)                 # index of the root group; datasets are decoded on demand
+            self.keys = self._lite.keys()
 
     def read(self, key: str) -> np.ndarray:
-        import h5py
-        with h5py.File(self.path, "r") as f:           # opened per read, as dataset.py:381-384 does (fork-safe for workers)
+        if self._h5py is None:
+            return self._lite[key].astype(np.float32)
+        with self._h5py.File(self.path, "r") as f:     # opened per read, as dataset.py:381-384 does (fork-safe for workers)
             return f[key][...].astype(np.float32)
 
     def all(self) -> np.ndarray:
-        import h5py
-        with h5py.File(self.path, "r") as f:
-            return np.stack([f[k][...].astype(np.float32) for k in self.keys])
+        return np.stack([self.read(k) for k in self.keys])
 
 
 def _open(path: str):
@@ -106,7 +113,7 @@ def _open(path: str):
 
 
 def convert_hdf5(src: str, dst: str):
-    """One-time conversion of a reference HDF5 feature file to the flat pack (needs h5py)."""
+    """One-time conversion of a reference HDF5 feature file to the flat pack (memmap-readable, no decompression per read)."""
     h = _Hdf5(src)
     write_flat_pack(dst, ((k, h.read(k)) for k in h.keys))
 

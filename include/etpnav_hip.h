@@ -451,6 +451,13 @@ typedef struct etp_comm etp_comm;
 int etp_allreduce_unique_id(void* id_out_128_bytes);
 int etp_allreduce_init(etp_comm** out, const void* unique_id, int rank, int world, int comm_dtype, int64_t max_bucket_elems);
 int etp_allreduce_bucket_ready(etp_comm* c, float* grads, int64_t n, etp_stream_t producer);
+/* The slice arithmetic etp_allreduce_bucket_ready applies to a bucket of n fp32 gradients over `world` ranks, as a pure host
+ * function (no communicator, no GPU): out[0] = elements per rank slice, out[1] = elements covered by reduce-scatter + all-gather,
+ * out[2] = tail elements that go through one all-reduce (fp32 transport only), out[3] = bf16 elements staged (bf16 transport only;
+ * the pad [n, out[3]) is zeroed).  DDP's buckets (ss_trainer_ETP.py:208-212) have no counterpart of this: it exists so that the
+ * multi-rank arithmetic can be unit-tested for worlds 2 / 4 / 8 on a one-GPU box. */
+int etp_allreduce_plan(int64_t n, int world, int comm_dtype, int64_t* out);
+int64_t etp_allreduce_staging_elems(int64_t max_bucket_elems, int world);
 /* Row-sparse mean of a table gradient [n_rows, row_len] (the word-embedding table: a step touches <= B*L of its 30 522 /
  * 250 002 rows; DDP would all-reduce the dense table, ss_trainer_ETP.py:208-212).  ids[0, n_ids) = rows this rank touched (any
  * order, repeats allowed); `capacity` >= n_ids is the rank-INDEPENDENT block size (e.g. B * max_txt_len; the reference's collate

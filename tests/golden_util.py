@@ -92,6 +92,28 @@ BF16_SAMPLE_REL, BF16_L2_REL, BF16_FULL_REL, BF16_ABS_FLOOR, BF16_COS_MIN = 1e-1
 BF16_B1_SAMPLE_REL, BF16_B1_L2_REL = 3.5e-1, 2e-1
 
 
+def bf16_bounds(B: int) -> dict:
+    """Per-batch-size tiers of the bf16 gradient bounds: the common-mode error above shrinks with the number of episodes whose rows are
+    summed (B = 1: 1 .. 26 % median; B = 3 .. 4: 3 .. 12 %, profiles/r05_b1_noise.txt second table); from B = 8 on the round-3 bounds hold
+    and the benchmarked shapes (B = 8 / 16 / 32) keep their own tighter ones (9 % / 0.995, tests/test_baseline_shapes_gpu.py).
+    Keys: sample_rel / l2_rel for compare_grads_bf16, rel / cos_min for compare_full_bf16."""
+    if B <= 1:
+        return dict(sample_rel=BF16_B1_SAMPLE_REL, l2_rel=BF16_B1_L2_REL, rel=0.35, cos_min=0.93)
+    if B <= 4:
+        return dict(sample_rel=0.15, l2_rel=0.08, rel=0.18, cos_min=0.98)
+    return dict(sample_rel=BF16_SAMPLE_REL, l2_rel=BF16_L2_REL, rel=BF16_FULL_REL, cos_min=BF16_COS_MIN)
+
+
+def fixture_bounds(B: int) -> dict:
+    b = bf16_bounds(B)
+    return dict(sample_rel=b["sample_rel"], l2_rel=b["l2_rel"])
+
+
+def full_bounds(B: int) -> dict:
+    b = bf16_bounds(B)
+    return dict(rel=b["rel"], cos_min=b["cos_min"])
+
+
 def compare_grads_bf16(z, grads, sample_rel=BF16_SAMPLE_REL, l2_rel=BF16_L2_REL):
     """Golden-fixture check of a bf16-mode gradient set; returns (worst sample ratio, worst L2 ratio, their tensor names)."""
     worst_s, worst_l = (0.0, ""), (0.0, "")

@@ -73,6 +73,79 @@ def test_grad_reducer_world2_gloo(comm_dtype, ragged, capacity):
         assert ok, f"rank {rank}: max err {err}"
 
 
+@pytest.mark.parametrize("world,comm_dtype,ragged,capacity", [(4, torch.float32, True, 12), (4, torch.bfloat16, False, None),
+                                                              (8, torch.float32, True, None), (8, torch.float32, False, 16)])
+def test_grad_reducer_world4_and_world8_gloo(world, comm_dtype, ragged, capacity):
+    """The same reducer over 4 and 8 ranks (the driver's SCALE line runs 1 / 2 / 4 / 8; no box with more than one GPU has been
+    available to the builder in five rounds): dense buckets + the row-sparse table exchange with rank-dependent row counts, a
+    shared id (7) on every rank, a repeated id per rank, fixed and agreed capacities."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_dtype, q, ragged, capacity)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert len(res) == world
+    for rank, ok, err in res:
+        assert ok, f"world {world} rank {rank}: max err {err}"
+
+
+def test_native_bucket_slice_arithmetic_for_worlds_2_4_8():
+    """etp_allreduce_plan (csrc/comm.hip): the per-rank slice / tail / bf16 pad arithmetic etp_allreduce_bucket_ready applies, as a pure
+    host function through the C ABI, on the bucket sizes the planner really produces (dp.planner_buckets_layered of the BERT-base and
+    XLM-R planners, 9 text groups as bench.py uses, with and without frozen sub-models) and on adversarial sizes -- then the
+    collective sequence is replayed on the host for W simulated ranks and must give the mean:
+      fp32: reduce-scatter(sum) of [0, body) into slice r -> scale slice by 1/W -> all-gather; all-reduce(sum) of the tail, scale
+      bf16: stage as bf16 with a zeroed pad -> reduce-scatter + all-gather over per * W -> unpack * 1/W."""
+    import ctypes
+    from etpnav_amd import _lib
+    from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
+    L = _lib.lib()
+    sizes = {1, 63, 64, 65, 511, 512, 513, 4095, 4096, 8 * 64 * 3 + 17, 1 << 20}
+    for kw in (dict(), dict(fix_lang_embedding=True), dict(task_type="rxr")):
+        task = kw.pop("task_type", "r2r")
+        m = GlocalTextPathNavCMT(default_config(task, **kw), dtype=torch.float32, device="cpu")
+        ranges, _, _ = dp.planner_buckets_layered(m, 9)
+        sizes |= {e - s for s, e in ranges}
+        del m
+    out = (ctypes.c_int64 * 4)()
+    for W in (2, 4, 8):
+        for n in sorted(sizes):
+            for dt in (_lib.ETP_F32, _lib.ETP_BF16):
+                assert L.etp_allreduce_plan(n, W, dt, out) == 0
+                per, body, tail, staged = (int(x) for x in out)
+                if dt == _lib.ETP_F32:
+                    assert per % 64 == 0 and body == per * W and body + tail == n and 0 <= tail < W * 64 and staged == 0, (W, n, list(out))
+                else:
+                    assert per % 8 == 0 and body == per * W == staged and tail == 0 and n <= staged < n + W * 8, (W, n, list(out))
+                    assert staged <= int(L.etp_allreduce_staging_elems(n, W)), (W, n)
+        # replay on the host (small buckets only: the arithmetic is size-independent)
+        for n in (1, 65, 513, 8 * 64 * 3 + 17):
+            g = torch.Generator().manual_seed(n + W)
+            ranks = [torch.randn(n, generator=g) for _ in range(W)]
+            mean = sum(ranks) / W
+            L.etp_allreduce_plan(n, W, _lib.ETP_F32, out)
+            per, body, tail, _ = (int(x) for x in out)
+            res = [r.clone() for r in ranks]
+            for r in range(W):                                   # reduce-scatter + local scale
+                res[r][r * per:(r + 1) * per] = sum(x[r * per:(r + 1) * per] for x in ranks) / W
+            for r in range(W):                                   # all-gather
+                for q_ in range(W):
+                    res[r][q_ * per:(q_ + 1) * per] = res[q_][q_ * per:(q_ + 1) * per]
+                res[r][body:] = sum(x[body:] for x in ranks) / W     # tail all-reduce
+                assert torch.allclose(res[r], mean, atol=1e-6), (W, n, r)
+            L.etp_allreduce_plan(n, W, _lib.ETP_BF16, out)
+            per, body, _, staged = (int(x) for x in out)
+            st = [torch.cat([r.to(torch.bfloat16), torch.zeros(staged - n, dtype=torch.bfloat16)]) for r in ranks]
+            red = sum(x.float() for x in st).to(torch.bfloat16)      # what the gathered copy holds on every rank
+            assert red.numel() == per * W
+            got = red[:n].float() / W
+            assert (got - mean).abs().max().item() <= 3e-2 * max(1.0, mean.abs().max().item()), (W, n)
+
+
 def _native_decision_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

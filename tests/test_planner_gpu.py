@@ -111,9 +111,8 @@ def test_bf16_step_close_to_reference_golden(name):
     step = PlannerStep(model, batch)
     step.run_eager()
     compare_outputs(z, step_outputs(step), atol=5e-2)
-    from tests.golden_util import BF16_B1_SAMPLE_REL, BF16_B1_L2_REL
-    b1 = batch["txt_ids"].shape[0] == 1       # single-episode fixture: input-dependent common-mode error (golden_util.py, profiles/r05_b1_noise.txt)
-    ws, wl = compare_grads_bf16(z, grads_of(model), **(dict(sample_rel=BF16_B1_SAMPLE_REL, l2_rel=BF16_B1_L2_REL) if b1 else {}))
+    from tests.golden_util import fixture_bounds      # per-batch-size tiers: golden_util.bf16_bounds, profiles/r05_b1_noise.txt
+    ws, wl = compare_grads_bf16(z, grads_of(model), **fixture_bounds(batch["txt_ids"].shape[0]))
     print(name, "bf16 worst sample err / abs-max", ws, "worst |dL2| / L2", wl)
 
 
@@ -247,7 +246,7 @@ def test_micro_batched_step_equals_full_batch_step(dtype, rel):
 RATES = (0.1, 0.1, 0.1, 0.4)     # hidden, attention-probs, SAP head (vlnbert_init.py:58), drop_env (Policy_ViewSelection_ETP.py:102)
 
 
-def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3, bf16=False):
+def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3, bf16=False, B=8):
     """bf16=True: outputs to `atol`, gradients by the per-tensor relative bf16 bounds (rel is ignored)."""
     for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
         assert (got[k].float().cpu() - outs[k]).abs().max().item() < atol, k
@@ -256,7 +255,8 @@ def _assert_step_matches(outs, grads, got, mine, atol=2e-4, rel=2e-3, bf16=False
     assert (got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max().item() < atol
     assert abs(got["loss"].item() - outs["loss"].item()) < atol
     if bf16:
-        wr, wc = compare_full_bf16(mine, grads)
+        from tests.golden_util import full_bounds
+        wr, wc = compare_full_bf16(mine, grads, **full_bounds(B))
         print("bf16 worst rel-L2", wr, "worst cosine", wc)
         return
     for k, g in grads.items():
@@ -354,7 +354,7 @@ def test_bf16_train_mode_step_close_to_oracle_with_same_masks():
     step.run_eager()
     got = step_outputs(step)
     outs, grads = po.step_with_grads(P, cfg, batch, drop=po.DropSpec(*RATES, seed=(5 << 32) | 1))
-    _assert_step_matches(outs, grads, got, grads_of(model), atol=8e-2, bf16=True)
+    _assert_step_matches(outs, grads, got, grads_of(model), atol=8e-2, bf16=True, B=4)
     # ranged text backward (DP overlap schedule) recomputes the same masks
     ref = model.flat_grads.clone()
     s = model._engine.stream()

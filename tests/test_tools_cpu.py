@@ -45,7 +45,8 @@ def test_kernel_resource_policy_holds_for_the_built_objects():
     rows = kr.audit()
     assert len(rows) > 250 and not [r for r in rows if r["violation"]], [r["full"] for r in rows if r["violation"]]
     by = {r["name"]: r for r in rows}
-    for k in ("pano_embed_bwd_kernel<unsigned short, 3>", "pano_embed_fwd_kernel<unsigned short, 3>", "gmap_embed_bwd_kernel<float, 3, 7>"):
+    for k in ("pano_embed_bwd_kernel<unsigned short, 3, 0>", "pano_embed_bwd_kernel<unsigned short, 3, 1>", "pano_embed_bwd_kernel<unsigned short, 3, 2>",
+              "pano_embed_fwd_kernel<unsigned short, 3>", "gmap_embed_bwd_kernel<float, 3, 7>"):
         assert int(by[k]["agpr_count"]) == 0 and int(by[k]["vgpr_count"]) <= 256 and int(by[k]["private_segment_fixed_size"]) == 0, by[k]
     assert any(int(r["agpr_count"]) > 0 and r["mfma"] for r in rows)      # the parser does see AGPRs where they are allowed
     # the parser on a literal note

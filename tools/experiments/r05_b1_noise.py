@@ -10,8 +10,9 @@ cfg = po.PlannerConfig.r2r()
 P = po.init_params(cfg, seed=0)
 m = GlocalTextPathNavCMT(cfg.to_dict(), dtype=torch.bfloat16, device="cuda"); m.load_state_dict(P, strict=True); m.eval()
 print("library", os.environ.get("ETP_LIB", "default"))
-for seed in (1234,) + tuple(range(1, 16)):
-    batch = po.make_batch(cfg, seed=seed, B=1, L=20, V=17, G=9, ragged=False)
+B = int(os.environ.get('NOISE_B', '1'))
+for seed in ((1234,) + tuple(range(1, 16)) if B == 1 else tuple(range(1, 9))):
+    batch = po.make_batch(cfg, seed=seed, B=B, L=20, V=17, G=9, ragged=False)
     outs, ref = po.step_with_grads(P, cfg, batch)
     step = PlannerStep(m, batch, overlap=False); step.run_eager(); torch.cuda.synchronize()
     rel = []

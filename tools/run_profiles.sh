@@ -4,6 +4,7 @@
 # copy what is to be judged into profiles/ (names per round).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
+RND=${ETP_ROUND:-r05}            # prefix of the files copied into profiles/ (bench.py reads the newest round present)
 O=gpurun_out/evidence; mkdir -p $O
 T="timeout 420"
 # 1. observed bf16 parity of the benchmarked shapes and the fixtures (prints the worst tensors)
@@ -14,14 +15,14 @@ python __graft_entry__.py smoke 2>&1 | grep "^smoke" | tee $O/smoke.log
 # 2. kernel trace + stats of the bench command
 (cd /tmp && $T rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o r -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-optimizer --no-roofline > $R/$O/bench_under_rocprof.json 2> $R/$O/prof.err)
 python tools/timeline.py $O/prof/r_kernel_trace.csv --steps 20 > $O/timeline.txt 2>&1
-cp $O/prof/r_kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/bench_kernel_stats.csv profiles/r04_bench_kernel_stats.csv
+cp $O/prof/r_kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/bench_kernel_stats.csv profiles/${RND}_bench_kernel_stats.csv
 rm -rf $O/prof
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 P="--steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --no-roofline"
 (cd /tmp && $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pf -o p -- python $R/bench.py $P > /dev/null 2> $R/$O/pf.err)
 (cd /tmp && $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pw -o p -- python $R/bench.py $P > /dev/null 2> $R/$O/pw.err)
 python tools/pmc_traffic.py $O/pf/p_counter_collection.csv $O/pw/p_counter_collection.csv --cast-elems 36601856 --out $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
-cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json
+cp $O/pmc_traffic.json profiles/${RND}_pmc_traffic.json
 rm -rf $O/pf $O/pw
 # 4. SQ counters
 (cd /tmp && $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/ps -o p -- python $R/bench.py $P > /dev/null 2> $R/$O/ps.err)
