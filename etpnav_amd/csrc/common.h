@@ -73,20 +73,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // library erff -- the GELU epilogues run 64 of these per thread on a 128x128 tile.  Both functions share
 // q = exp(-x^2/2): erf(x/sqrt2) = sign(x) * (1 - poly(t) * q),  t = 1 / (1 + p |x| / sqrt2).
 __device__ __forceinline__ void gelu_parts(float x, float& phi_cdf, float& q) {
-#ifdef ETP_EPI_NOMATH        // measurement builds only (tools/build_variant.sh ... -DETP_EPI_NOMATH): what the erf arithmetic costs the epilogues
-  phi_cdf = 0.5f; q = 1.0f;
-  return;
-#endif
   // constants folded by hand (the compiler may not reassociate): p |x| / sqrt2 = 0.23164189 |x|; exp(-x^2/2) = exp2(-0.72134752 x^2)
   // v_rcp_f32 (1 ulp; the argument is in [1, ~5]).  __frcp_rn compiled to the IEEE division sequence (2 x v_div_scale, v_rcp, 4 FMAs,
   // v_div_fmas, v_div_fixup: ten instructions per element; round 5, found in the ISA after the epilogues measured VALU-bound)
-#ifdef ETP_GELU_IEEE         // measurement builds only: the round-4 forms
-  const float t = __frcp_rn(fmaf(0.3275911f, fabsf(x) * 0.70710678118654752440f, 1.0f));
-  q = __expf(-0.5f * x * x);
-#else
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
   q = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
-#endif
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -421,11 +421,6 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 1 : 2)) void kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef ETP_MM32_STAGGER      // measurement builds only: the second workgroup of a CU starts ETP_MM32_STAGGER x ~3.9 us late, so that its
-  // reduction (L2 -> LDS feed) overlaps the first one's epilogue (HBM / VALU) instead of both doing the same phase together
-  if (BM * BN == 128 * 128 && blockIdx.x >= 256)
-    for (int i = 0; i < ETP_MM32_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, g.M / BM, g.N / BN, g.xcd_map, tm, tn);
   tile<TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),

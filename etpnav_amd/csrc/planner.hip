@@ -22,11 +22,6 @@
 
 namespace etp {
 
-#ifdef ETP_OLD_GELU        // measurement builds only: the round-4 pair (saved pre-activation, erf arithmetic in the backward epilogue)
-#define ETP_ACT_GELU_SAVEGRAD ETP_ACT_GELU
-#define ETP_ACT_MUL_Z ETP_ACT_GELU_BWD
-#endif
-
 struct AttnP { int qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
 struct FfnP { int i_w, i_b, o_w, o_b, ln_g, ln_b; };
 struct TxtLayerP { AttnP att; FfnP ffn; };
@@ -647,7 +642,7 @@ static int ffn_fwd(const Ctx& c, const FfnP& p, const Act& x, FfnStash& f, int M
   return ln_fwd_s(c.dt, f.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), f.y.f, lp(f.y, c.dt), f.st, M, H, eps, c.st);
 }
 static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f, int M, float* g, const BwdWs& w, int mode,
-                   int layer, const float* g_in = nullptr) {
+                   int layer, const float* g_in = nullptr, int flush_behind = 0) {
   const int H = c.H, I = c.I;
   etp_planner* pl = c.pl;
   const Drop dh = hid(c, mode, layer, SITE_FFN_O);
@@ -655,8 +650,13 @@ static int ffn_bwd(const Ctx& c, const FfnP& p, const Act& x, const FfnStash& f,
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, f.h, I, p.o_w, p.o_b, M, H, I));
   ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.dI, I, M, H, I, ETP_ACT_MUL_Z, f.z, I, nullptr, 0));               // dI = dz
+  // the PREVIOUS layer's weight gradients (held back at the end of that layer) + this layer's FFN-down one start behind this launch:
+  // the 480-workgroup, two-per-CU dgrad above then finds the chip free instead of queueing behind 432 resident leaf workgroups
+  if (flush_behind == 1) ETP_TRY(flush_side(c));
   ETP_TRY(linear_wgrad(c, w.dI, I, x.t, H, p.i_w, p.i_b, M, I, H));
-  return linear_dgrad_s(c, w.dI, I, p.i_w, g, M, I, H, w.t1.f);                                               // g = dx
+  ETP_TRY(linear_dgrad_s(c, w.dI, I, p.i_w, g, M, I, H, w.t1.f));                                             // g = dx
+  if (flush_behind == 2) ETP_TRY(flush_side(c));      // variant: behind the whole FFN half (this layer's FFN pair rides along)
+  return ETP_OK;
 }
 
 // ======================================================================================
@@ -865,7 +865,17 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     if (l >= layer_hi || l < layer_lo) continue;
     stamp_mark(c.st, 2200 + 10 * l);
     // the top layer reads the incoming gradient in place (dout) and leaves dL/dx in the running buffer g
-    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr));
+    // Round 5: a layer's four weight gradients are NOT forked at the end of the layer.  There the 432 leaf workgroups took
+    // every slot of the chip just before the next layer's FFN dgrad -- a 480-workgroup, two-per-CU grid -- which then ran 64.6 us in the
+    // step against 27.9 us alone (profiles/r05_chain_vs_isolated.txt), 9 x 37 us.  They are held back and go out right BEHIND that dgrad
+    // (1, the default): the leaf work then shares the chip with the FFN-up dgrad, LayerNorm, out-projection and attention backward, whose
+    // one-per-CU 74-KB workgroups and small kernels leave room beside it.  Same-box A/B (profiles/r05_ab_runs.json): 4.12 / 4.13 ->
+    // 4.06 / 4.06 ms; behind the whole FFN half (2): 4.14 against 4.10 (1) and 4.18 (0) on a second box.  Only where that dgrad IS one
+    // resident round (at most 512 tiles of 128 x 128: configs 2 and 5): at config 4's 8192 rows it is three rounds anyway and holding
+    // the leaf work back costs 1.4 % (10.77 against 10.62 ms).  ETP_FLUSH_DELAY=0 / 1 / 2 forces a mode.
+    static const int delay_env = [] { const char* e = getenv("ETP_FLUSH_DELAY"); return e ? atoi(e) : -1; }();
+    const int delay = delay_env >= 0 ? delay_env : (((long)(M / 128) * (c.I / 128) <= 512) ? 1 : 0);
+    ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr, delay));
     stamp_mark(c.st, 2200 + 10 * l + 1);
     // the LAST layer of the backward: its two FFN weight gradients go out now instead of with the attention ones at the end of
     // the layer -- nothing runs behind this layer that could hide them (the step's end waits for the weight-gradient stream)
@@ -877,6 +887,7 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
     // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work
     static const int every = [] { const char* e = getenv("ETP_FLUSH_EVERY"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+    if (delay && l != layer_lo) continue;             // held back: goes out behind the next layer's FFN dgrad
     if (every == 1 || (layer_hi - 1 - l) % every == every - 1 || l == layer_lo) ETP_TRY(flush_side(c));
   }
   if (layer_lo == 0)

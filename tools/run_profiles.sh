@@ -7,10 +7,11 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 RND=${ETP_ROUND:-r05}            # prefix of the files copied into profiles/ (bench.py reads the newest round present)
 O=gpurun_out/evidence; mkdir -p $O
 T="timeout 420"
-# 1. observed bf16 parity of the benchmarked shapes and the fixtures (prints the worst tensors)
-$T python -m pytest tests/test_baseline_shapes_gpu.py tests/test_planner_gpu.py -q -s --tb=short -k "bf16" 2>&1 | grep -E "bf16 worst|passed|failed|Error|^E " | cut -c1-260 > $O/parity_bf16_observed.txt
-tail -3 $O/parity_bf16_observed.txt
-$T python -m pytest tests/test_mm32_gpu.py -q --tb=short 2>&1 | tail -2
+# 1. observed bf16 parity of the benchmarked shapes and the fixtures (prints the worst tensors).  SKIP_PARITY=1: taken from the -s log
+#    of the full GPU suite instead (the same tests run there)
+[ -n "$SKIP_PARITY" ] || $T python -m pytest tests/test_baseline_shapes_gpu.py tests/test_planner_gpu.py -q -s --tb=short -k "bf16" 2>&1 | grep -E "bf16 worst|passed|failed|Error|^E " | cut -c1-260 > $O/parity_bf16_observed.txt
+[ -n "$SKIP_PARITY" ] || tail -3 $O/parity_bf16_observed.txt
+[ -n "$SKIP_PARITY" ] || $T python -m pytest tests/test_mm32_gpu.py -q --tb=short 2>&1 | tail -2
 python __graft_entry__.py smoke 2>&1 | grep "^smoke" | tee $O/smoke.log
 # 2. kernel trace + stats of the bench command
 (cd /tmp && $T rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o r -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-optimizer --no-roofline > $R/$O/bench_under_rocprof.json 2> $R/$O/prof.err)
@@ -30,7 +31,7 @@ python tools/pmc_sq.py $O/ps/p_counter_collection.csv --out $O/gemm_counters.jso
 rm -rf $O/ps
 # 5. device-side phases and the chain intervals
 $T python tools/gemm_phase_probe.py > $O/gemm_phases.txt 2> $O/gemm_phases.err
-$T python tools/chain_waits.py --steps 24 --out $O/chain_waits.txt > /dev/null 2> $O/chain_waits.err
+[ -n "$SKIP_CHAIN" ] || $T python tools/chain_waits.py --steps 24 --out $O/chain_waits.txt > /dev/null 2> $O/chain_waits.err
 # 6. the bench line (reads the two files copied into profiles/ above) and the other workloads
 $T python bench.py > $O/bench.json 2> $O/bench.err
 for wl in c4 c5 sap; do $T python bench.py --workload $wl --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err; done
