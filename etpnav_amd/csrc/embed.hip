@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void pano_embed_fwd_kernel(const T* __restrict
 // 226 of them AGPRs (tools/kernel_resources.py) -- the register class DESIGN.md §3.6 bans outside the matrix-core kernels -- and one
 // wavefront per SIMD.  A first rewrite moved eight accumulators into per-wavefront LDS regions (108 KB): no AGPRs, but its sums then
 // deviated from run to run whenever other kernels' workgroups shared the CU (race screen of tests/test_variants_gpu.py; clean with the
-// CU's whole LDS to itself, which cost the step 0.1 ms; profiles/r05_lds_neighbour.txt).  Now each launch rebuilds the row's branch sum
+// CU's whole LDS to itself, which cost the step 0.1 ms; profiles/r05_pano_embed_race.txt).  Now each launch rebuilds the row's branch sum
 // and carries only its own accumulators in registers:
 //   PART 0  the outer LayerNorm: gamma_out, beta_out, sum(de), nav_emb[0]            (4 rows; sum(de) serves type1, the three inner
 //           biases and nav_emb[0] + nav_emb[1]: they all receive the same column sum of the branch-sum gradient `de`)

@@ -1,6 +1,6 @@
 // round 5: reproducer for the cross-workgroup LDS corruption behind DESIGN.md §3.6 (round 4's "AGPR" corruption) and this round's
 // pano_embed_bwd finding: a kernel that keeps long-lived, lane-private data in a LARGE dynamic LDS allocation returns wrong sums when
-// workgroups of OTHER kernels share its CU, and is exact when it owns the CU's LDS (profiles/r05_lds_neighbour.txt).
+// workgroups of OTHER kernels share its CU, and is exact when it owns the CU's LDS (profiles/r05_pano_embed_race.txt; this reproducer came out NEGATIVE: 0 corrupted runs in every cell).
 //
 //   victim    256 threads, `vbytes` of dynamic LDS: every lane read-modify-writes (+1) its own 16-byte slots ITER times, then counts the
 //             slots that do not hold ITER.  No barrier, no sharing between lanes: any mismatch was written by somebody else.
