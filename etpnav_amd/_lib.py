@@ -185,3 +185,15 @@ def ptr(t) -> int:
         return None
     assert t.is_contiguous(), "C ABI needs contiguous tensors"
     return t.data_ptr()
+
+
+def force_gemm_tile(tile: str = "") -> None:
+    """Tuning aid: force a tile class of gemm.hip's kernels for the following launches ("" / "auto" = the library's own choice).
+    The mm32 family is consulted BEFORE gemm.hip's tile choice (csrc/gemm_mm32.hip::mm32_class), so forcing a gemm.hip class
+    also switches mm32 off -- otherwise an eligible bf16 product would silently keep running the mm32 kernel."""
+    tile = "" if tile == "auto" else tile
+    os.environ["ETP_GEMM_TILE"] = tile
+    if tile:
+        os.environ["ETP_MM32"] = "0"
+    else:
+        os.environ.pop("ETP_MM32", None)

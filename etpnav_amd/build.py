@@ -81,6 +81,13 @@ def audit_resources(verbose: bool = True):
     if bad:
         raise RuntimeError("kernel resource policy violated (tools/kernel_resources.py):\n" +
                            "\n".join(f"  {r['src']}: {r['full']}: {r['violation']}" for r in bad))
+    # the LDS-DMA statements write M0 behind the compiler's back: check the ISA it produced around them
+    nk, ni, m0bad = kr.m0_audit()
+    if verbose:
+        print(f"LDS-DMA M0 audit: {ni} global_load_lds in {nk} kernels, {len(m0bad)} violations", flush=True)
+    if m0bad:
+        raise RuntimeError("M0 discipline around global_load_lds violated (tools/kernel_resources.py::m0_scan):\n" +
+                           "\n".join(f"  {src}: {k}: {t}" for src, k, t in m0bad[:20]))
 
 
 if __name__ == "__main__":

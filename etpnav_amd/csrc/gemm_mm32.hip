@@ -102,7 +102,8 @@ __device__ __forceinline__ DmaOp dma_setup(const bf16_t* base, long ld, int row0
 // read; hidden here it stays in flight and is retired by our own counted s_waitcnt vmcnt + s_barrier.  M0 (LDS byte address of
 // the piece, wave-uniform) is written in the statement that consumes it.  M0 is neither saved nor declared clobbered: it is a
 // reserved register on this target (hipcc rejects it on a clobber list and writes it itself immediately in front of each
-// instruction of its own that reads it), and these kernels contain no compiler-generated M0 use to share a value with.
+// instruction of its own that reads it), and these kernels contain no compiler-generated M0 use to share a value with --
+// a property of the ISA, checked after every build (tools/kernel_resources.py::m0_audit).
 __device__ __forceinline__ void glds(unsigned voff, const char* sbase, unsigned lds_addr) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"

@@ -63,3 +63,62 @@ def test_kernel_resource_policy_holds_for_the_built_objects():
 """
     (k,) = kr.parse(note)
     assert k["agpr_count"] == "8" and k["private_segment_fixed_size"] == "16" and k["vgpr_spill_count"] == "1" and k["name"] == "_ZN3etp3fooEv"
+
+
+def test_lds_dma_m0_discipline_scanner():
+    """tools/kernel_resources.py::m0_scan (ADVICE r4): the LDS-DMA statements write M0 from inline asm the compiler cannot be told about;
+    the build checks the ISA around every global_load_lds.  Here: the scanner accepts the two statement forms of the product (glds of
+    gemm_mm32.hip, glds16 of gemm_tiles.h with its save / restore) and rejects each way the assumption can break; on the built objects
+    the audit finds the DMA instructions and no violation."""
+    import pytest
+    from etpnav_amd import build as b
+    from tools import kernel_resources as kr
+    good = """
+0000000000001000 <_ZN3etp4mm326kernelEv>:
+	s_add_i32 s5, s60, 0x1000                                  // 000000001000: 8105FF3C
+	s_mov_b32 m0, s5                                           // 000000001008: BEFC0005
+	s_nop 0                                                    // 00000000100C: BF800000
+	global_load_lds_dwordx4 v68, s[0:1]                        // 000000001010: DDF48000
+	s_mov_b32 s1, m0                                           // 000000001018: BE81007C
+	s_mov_b32 m0, s0                                           // 00000000101C: BEFC0000
+	s_nop 0                                                    // 000000001020: BF800000
+	global_load_lds_dwordx4 v2, off                            // 000000001024: DDF48000
+	s_mov_b32 m0, s1                                           // 00000000102C: BEFC0001
+	s_endpgm                                                   // 000000001030: BF810000
+
+0000000000002000 <_ZN3etp9no_dma_m0Ev>:
+	s_mov_b32 m0, s3                                           // 000000002000: BEFC0003
+	s_movrels_b32 s4, s8                                       // 000000002004: BE840008
+	s_endpgm                                                   // 000000002008: BF810000
+"""
+    stats, bad = kr.m0_scan(good)
+    assert stats == {"_ZN3etp4mm326kernelEv": 2} and bad == []              # kernels without LDS-DMA are not this check's business
+    head = "0000000000001000 <k>:\n"
+    dma = "\ts_mov_b32 m0, s5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v68, s[0:1]\n"
+    for broken, what in [
+            (head + "\ts_mov_b32 m0, s5\n\ts_add_i32 s5, s5, 4\n\tglobal_load_lds_dwordx4 v68, s[0:1]\n", "not directly behind"),
+            (head + dma + "\ts_mov_b32 m0, s9\n\tv_add_f32 v0, v1, v2\n", "neither consumed"),
+            (head + dma + "\ts_movrels_b32 s4, s8\n", "implicit M0 use"),
+            (head + dma + "\ts_set_gpr_idx_on s3, gpr_idx(SRC0)\n", "implicit M0 use"),
+            (head + dma + "\tv_readlane_b32 s4, v3, m0\n", "compiler-generated M0 use"),
+            (head + dma + "\ts_mov_b32 s7, m0\n\tv_add_f32 v0, v1, v2\n", "M0 read outside"),
+            (head + dma + "\tbuffer_load_dword v1, s[4:7], 0 offen lds\n", "implicit M0 use")]:
+        _, bad = kr.m0_scan(broken)
+        assert any(what in t for _, _, t in bad), (what, bad)
+    objs = [os.path.join(b.HERE, "build", s.replace(".hip", ".o")) for s in b.SOURCES]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("objects not built here")
+    nk, ni, m0bad = kr.m0_audit()
+    assert nk > 50 and ni > 1000 and not m0bad, m0bad[:5]
+
+
+def test_forcing_a_gemm_tile_class_switches_the_mm32_family_off(monkeypatch):
+    """_lib.force_gemm_tile: mm32_class is consulted before gemm.hip's tile choice, so a forced gemm.hip class must come
+    with ETP_MM32=0 or eligible bf16 products keep running the mm32 kernel; "auto" hands both choices back to the library."""
+    from etpnav_amd import _lib
+    monkeypatch.setenv("ETP_GEMM_TILE", "")
+    monkeypatch.delenv("ETP_MM32", raising=False)
+    _lib.force_gemm_tile("64s3")
+    assert os.environ["ETP_GEMM_TILE"] == "64s3" and os.environ["ETP_MM32"] == "0"
+    _lib.force_gemm_tile("auto")
+    assert os.environ["ETP_GEMM_TILE"] == "" and "ETP_MM32" not in os.environ

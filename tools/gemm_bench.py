@@ -62,7 +62,7 @@ if __name__ == "__main__" and not os.environ.get("GEMM_GROUP_ONLY"):
     for kind, M, N, K in shapes:
         row = f"{kind:6} {M:5d} {N:5d} {K:5d} "
         for tl in tiles:
-            os.environ["ETP_GEMM_TILE"] = "" if tl == "auto" else tl
+            _lib.force_gemm_tile(tl)         # forcing a gemm.hip class also switches the mm32 family off
             if kind == "wgrad":
                 best = None
                 for ks in (1, 2, 4, 8):

@@ -49,7 +49,7 @@ def make(kind, M, N, K):
 
 
 def time_variant(kind, M, N, K, variant, iters=24):
-    os.environ["ETP_GEMM_TILE"] = "" if variant == "auto" else variant
+    _lib.force_gemm_tile(variant)            # forcing a gemm.hip class also switches the mm32 family off
     sets = [make(kind, M, N, K) for _ in range(NSETS)]
     s = torch.cuda.current_stream().cuda_stream
     for d, _ in sets:
@@ -73,7 +73,7 @@ def ksweep_cold_vs_warm():
             for K in (128, 768, 3072):
                 out[f"nsets{nsets}:fwd_s:{M}x768x{K}"] = round(time_variant("fwd_s", M, 768, K, "64s3"), 2)
                 out[f"nsets{nsets}:fwd:{M}x768x{K}"] = round(time_variant("fwd", M, 768, K, "64s3"), 2)
-    os.environ["ETP_GEMM_TILE"] = ""
+    _lib.force_gemm_tile("")
     print(json.dumps(out, indent=1))
 
 
@@ -108,7 +108,7 @@ def main():
         kv = ("64s3", "ws3", "128s2") + (("256s2",) if os.environ.get("SWEEP_256") else ())
         out["ksweep"][str(K)] = {v: round(time_variant("fwd_s", 2560, 768, K, v), 2) for v in kv}
         print("ksweep", K, out["ksweep"][str(K)], file=sys.stderr, flush=True)
-    os.environ["ETP_GEMM_TILE"] = ""
+    _lib.force_gemm_tile("")
     print(json.dumps(out, indent=1))
 
 

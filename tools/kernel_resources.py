@@ -9,6 +9,10 @@ reads the code-object metadata (`.agpr_count`, `.private_segment_fixed_size`, `.
 embedded in each build object (llvm-objcopy --dump-section .hip_fatbin -> clang-offload-bundler --unbundle -> llvm-readelf --notes)
 and applies that policy; `etpnav_amd.build.build()` runs it after every build and fails the build on a violation.
 
+Second check (round 5): the LDS-DMA statements write M0 from inline asm without being able to declare it; `m0_audit`
+disassembles the objects and verifies, per kernel, that every M0 write feeds the DMA right behind it (or is the restore right
+behind one) and that the compiler generated no M0 use of its own there.
+
 The reference has no native code; this guards the MI355X-side replacement of its autograd kernels (vilmodel_cmt.py throughout).
 """
 import argparse
@@ -30,13 +34,110 @@ FIELDS = ("agpr_count", "vgpr_count", "sgpr_count", "private_segment_fixed_size"
           "group_segment_fixed_size", "uses_dynamic_stack")
 
 
-def code_object_notes(obj: str) -> str:
+def _with_code_object(obj: str, fn):
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(td, "copy.o")])
         subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
                                f"--targets={TARGET}", f"--output={co}"])
-        return subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+        return fn(co)
+
+
+def code_object_notes(obj: str) -> str:
+    return _with_code_object(obj, lambda co: subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True))
+
+
+def code_object_isa(obj: str) -> str:
+    return _with_code_object(obj, lambda co: subprocess.check_output(
+        [os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True))
+
+
+# ---- LDS-DMA / M0 audit (the glds() inline asm writes M0 without telling the compiler) --------------------------------
+# global_load_lds takes the LDS byte address of its piece from M0.  hipcc rejects M0 on a clobber list, so the asm statements of
+# gemm_mm32.hip (glds) and gemm_tiles.h (glds16) are only correct while (1) every M0 write sits directly in front of the DMA it
+# feeds (nothing but s_nop between), or is glds16's restore directly behind one, and (2) no instruction of the compiler's own in a
+# kernel with LDS-DMA reads or holds a value in M0 (relative moves, GPR-index mode, GWS, sendmsg, interpolation, buffer ... lds).
+# Both are properties of the ISA the build produced, so the build checks them.
+M0_IMPLICIT = ("s_movrel", "v_movrel", "s_set_gpr_idx", "ds_gws", "s_sendmsg", "v_interp", "ds_read_addtid", "ds_write_addtid")
+
+
+def m0_scan(isa: str):
+    """-> (stats, violations) of one disassembly: stats = {kernel: number of LDS-DMA instructions}."""
+    stats, bad = {}, []
+    kern, ins = None, []
+
+    def flush():
+        if kern is None or not any(m.startswith("global_load_lds") for m, _ in ins):
+            return
+        n = 0
+        for i, (m, ops) in enumerate(ins):
+            toks = re.split(r"[\s,]+", ops)
+            if m.startswith("global_load_lds"):
+                n += 1
+                j = i - 1
+                while j >= 0 and ins[j][0] == "s_nop":
+                    j -= 1
+                if j < 0 or not (ins[j][0] == "s_mov_b32" and ins[j][1].split(",")[0].strip() == "m0"):
+                    bad.append((kern, i, f"{m} {ops}: not directly behind its own 's_mov_b32 m0, ...'"))
+            elif "m0" in toks:
+                dst = ops.split(",")[0].strip()
+                if m == "s_mov_b32" and dst == "m0":                       # a write: feeds the next DMA, or restores behind one
+                    j = i + 1
+                    while j < len(ins) and ins[j][0] == "s_nop":
+                        j += 1
+                    feeds = j < len(ins) and ins[j][0].startswith("global_load_lds")
+                    restores = False                                       # glds16: save, write, (nop), DMA, restore FROM THE SAVE
+                    if i > 0 and ins[i - 1][0].startswith("global_load_lds"):
+                        j = i - 2
+                        while j >= 0 and ins[j][0] == "s_nop":
+                            j -= 1                                          # j = the write that fed the DMA
+                        src = ops.split(",")[1].strip() if "," in ops else ""
+                        restores = (j >= 1 and ins[j - 1][0] == "s_mov_b32" and
+                                    [t.strip() for t in ins[j - 1][1].split(",")] == [src, "m0"])
+                    if not (feeds or restores):
+                        bad.append((kern, i, f"{m} {ops}: an M0 write that is neither consumed by the next LDS-DMA nor a restore behind one"))
+                elif m == "s_mov_b32" and dst != "m0":                     # glds16's save
+                    nxt = ins[i + 1] if i + 1 < len(ins) else ("", "")
+                    if not (nxt[0] == "s_mov_b32" and nxt[1].split(",")[0].strip() == "m0"):
+                        bad.append((kern, i, f"{m} {ops}: M0 read outside the save / write / DMA / restore statement"))
+                else:
+                    bad.append((kern, i, f"{m} {ops}: compiler-generated M0 use in a kernel with LDS-DMA"))
+            elif m.startswith(M0_IMPLICIT) or (m.startswith("buffer_load") and " lds" in " " + ops):
+                bad.append((kern, i, f"{m} {ops}: implicit M0 use in a kernel with LDS-DMA"))
+        stats[kern] = n
+
+    for line in isa.splitlines():
+        mk = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if mk:
+            flush()
+            kern, ins = mk.group(1), []
+            continue
+        mi = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*(//.*)?$", line)
+        if mi and kern is not None:
+            ins.append((mi.group(1), mi.group(2)))
+    flush()
+    return stats, bad
+
+
+def m0_audit(objdir=None):
+    """-> (number of kernels with LDS-DMA, number of LDS-DMA instructions, violations [(src, kernel, text)])."""
+    from etpnav_amd import build as b
+    objdir = objdir or os.path.join(b.HERE, "build")
+    nk = ni = 0
+    bad = []
+    for src in b.SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        with open(obj, "rb") as f:
+            if b".hip_fatbin" not in f.read():
+                continue
+        isa = code_object_isa(obj)
+        if "global_load_lds" not in isa:
+            continue
+        stats, v = m0_scan(isa)
+        nk += len(stats)
+        ni += sum(stats.values())
+        bad += [(src, k, t) for k, _, t in v]
+    return nk, ni, bad
 
 
 def parse(notes: str):
@@ -119,14 +220,21 @@ def main():
     a = ap.parse_args()
     rows = audit()
     t = table(rows)
+    nk, ni, m0bad = m0_audit()
+    m0line = f"# LDS-DMA M0 audit: {ni} global_load_lds in {nk} kernels, {len(m0bad)} violations (every M0 write sits in front of its DMA or restores behind one; no compiler-generated M0 use)\n"
+    lines = t.split("\n")
+    lines.insert(3, m0line.rstrip("\n"))
+    t = "\n".join(lines)
     if a.write:
         with open(a.write, "w") as f:
             f.write(t)
     bad = [r for r in rows if r["violation"]]
-    print(t if not a.write else f"{len(rows)} kernels, {len(bad)} violations -> {a.write}")
+    print(t if not a.write else f"{len(rows)} kernels, {len(bad)} violations; M0 audit {ni} DMA instructions, {len(m0bad)} violations -> {a.write}")
+    for src, k, txt in m0bad[:40]:
+        print(f"M0 VIOLATION {src}: {k}: {txt}")
     for r in bad:
         print(f"VIOLATION {r['src']}: {r['full']}: {r['violation']} (agpr {r['agpr_count']}, scratch {r['private_segment_fixed_size']})")
-    if a.strict and bad:
+    if a.strict and (bad or m0bad):
         sys.exit(1)
 
 

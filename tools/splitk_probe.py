@@ -17,7 +17,7 @@ L = _lib.lib()
 
 
 def time_split(kind, M, N, K, tile, ks, iters=24):
-    os.environ["ETP_GEMM_TILE"] = tile
+    _lib.force_gemm_tile(tile)
     sets = [gs.make(kind, M, N, K) for _ in range(gs.NSETS)]
     for d, _ in sets:
         d.ksplit = ks
@@ -48,5 +48,5 @@ for kind, M, N, K in [("fwd_s", 2560, 768, 3072), ("dg_s", 2560, 768, 3072), ("d
             row[f"{tile},ks{ks}"] = str(e)[:80]
     out[f"{kind}:{M}x{N}x{K}"] = row
     print(kind, M, N, K, row, file=sys.stderr, flush=True)
-os.environ["ETP_GEMM_TILE"] = ""
+_lib.force_gemm_tile("")
 print(json.dumps(out, indent=1))
