@@ -181,15 +181,27 @@ def param_shapes(cfg: PlannerConfig) -> Dict[str, tuple]:
     return s
 
 
+_INIT_MEMO: Dict[tuple, Dict[str, Tensor]] = {}
+_INIT_MEMO_SETS = 3          # <= 3 x 0.6 .. 1.1 GB of host memory
+
+
 def init_params(cfg: PlannerConfig, seed: int = 0, dtype=torch.float32,
                 perturb: bool = True) -> Dict[str, Tensor]:
     """BERT-style init (normal(0, .02) weights, zero bias, LN=(1,0)) — the
     transformers-4.12 ``init_weights`` the reference ctor calls
     (vilmodel_cmt.py:673).  With ``perturb`` biases / LN affine / sprel get small
     random values too so that parity tests exercise every term."""
+    shapes = param_shapes(cfg)
+    # the GPU suite asks for the same seeded 140 M-element set dozens of times (~2 s each): keep the last few sets and hand out
+    # clones, so no caller can see another's in-place edits or requires_grad flags
+    key = (tuple((n, tuple(sh)) for n, sh in shapes.items()), seed, dtype, perturb)
+    hit = _INIT_MEMO.get(key)
+    if hit is not None:
+        _INIT_MEMO[key] = _INIT_MEMO.pop(key)                # most recently used last
+        return {k: v.clone() for k, v in hit.items()}
     g = torch.Generator().manual_seed(seed)
     out: Dict[str, Tensor] = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in shapes.items():
         is_ln = ("LayerNorm" in name or "layer_norm" in name or ".norm" in name
                  or name.endswith("gmap_pos_embeddings.1.weight")
                  or name.endswith("gmap_pos_embeddings.1.bias")
@@ -210,6 +222,9 @@ def init_params(cfg: PlannerConfig, seed: int = 0, dtype=torch.float32,
                 if perturb:
                     t = 0.02 * torch.randn(shape, generator=g)
         out[name] = t.to(dtype)
+    _INIT_MEMO[key] = {k: v.clone() for k, v in out.items()}
+    while len(_INIT_MEMO) > _INIT_MEMO_SETS:
+        _INIT_MEMO.pop(next(iter(_INIT_MEMO)))
     return out
 
 
