@@ -16,7 +16,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from etpnav_amd.planner import GlocalTextPathNavCMT, default_config  # noqa: E402
 from etpnav_amd.step import PlannerStep  # noqa: E402
-from etpnav_amd.synthetic import make_batch  # noqa: E402
+from etpnav_amd.synthetic import make_batch, make_sap_batch  # noqa: E402
 
 RUNS = int(os.environ.get("RUNS", "10"))
 WLS = os.environ.get("WL", "c2,c5").split(",")
@@ -66,14 +66,28 @@ def rows_report(tag, x, ref):
 
 for key in WLS:
     w = dict(bench.WORKLOADS[key])
-    batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"], seed=1234)
+    if key == "sap":
+        batch = make_sap_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, 8, w["L"], w["T"], w["V"], seed=1234)
+    else:
+        batch = make_batch(cfg.vocab_size, cfg.image_feat_size, cfg.depth_feat_size, w["B"], w["L"], w["V"], w["G"], seed=1234)
     (r0, r1), M = run(True, 12288, 2, 2)
+    if os.environ.get("SAVE_REF"):              # reference of THIS library for a later process running another library
+        torch.save({"da": r0[0].cpu(), "dd": r0[1].cpu(), "g": {n: v.cpu() for n, v in r0[3].items()}}, os.environ["SAVE_REF"] + "." + key)
+        print(f"== {key}: reference saved"); continue
+    if os.environ.get("CMP_REF") and os.path.exists(os.environ["CMP_REF"] + "." + key):
+        z = torch.load(os.environ["CMP_REF"] + "." + key)
+        ge = max(float((r0[3][n].cpu() - z["g"][n]).abs().max() / z["g"][n].abs().max().clamp_min(1e-20)) for n in EMB)
+        print(f"== {key}: against the other library's reference (both alone): da bit-identical {bool((r0[0].cpu() == z['da']).all())}, "
+              f"dd bit-identical {bool((r0[1].cpu() == z['dd']).all())}, gradients within {ge:.1e}")
     same = bool((r0[0] == r1[0]).all() and (r0[1] == r1[1]).all())
     gref = r0[3]
     gdev = max(float((r1[3][n] - gref[n]).abs().max() / gref[n].abs().max().clamp_min(1e-20)) for n in EMB)
     print(f"== {key}: M = {M} rows; reference (alone) twice: da/dd bit-identical {same}, gradients within {gdev:.1e}  (t = {time.time() - t_start:.1f} s)", flush=True)
-    for tag, overlap, prio in [("three streams", True, "1"), ("panorama stream only (overlap='s2')", "s2", "1"),
-                               ("weight-gradient stream only (overlap='aux')", "aux", "1"), ("three streams, no priorities", True, "0")]:
+    modes = [("three streams", True, "1"), ("panorama stream only (overlap='s2')", "s2", "1"),
+             ("weight-gradient stream only (overlap='aux')", "aux", "1"), ("three streams, no priorities", True, "0")]
+    if os.environ.get("MODES"):
+        modes = [modes[int(i)] for i in os.environ["MODES"].split(",")]
+    for tag, overlap, prio in modes:
         if time.time() - t_start > float(os.environ.get("BUDGET_S", "100")):
             print(tag, "skipped (time budget)")
             continue
