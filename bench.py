@@ -57,11 +57,13 @@ def flops_per_step(w, cfg):
     return 3.0 * (lang + pano + xl + head)
 
 
-def cpu_baseline(w, cfg_kwargs, budget_s=24.0, train=True):
-    """Time the CPU oracle (test infrastructure; the checker, not the product) on a BOUNDED sample of the same
-    workload: full 36-view x 80-token x 16-node episodes, but only as many episodes per step as keep the whole leg near
-    budget_s of CPU time (steps/s is then scaled by sample_batch / batch -- per-episode work is independent).  Protocol of
-    SURVEY.md §8(d): 1 warm-up + >= 5 timed fwd+bwd steps, MEDIAN, model.train() and model.eval() variants, cores stated."""
+def cpu_baseline(w, cfg_kwargs, budget_s=36.0, train=True):
+    """Time the CPU oracle (test infrastructure; the checker, not the product) on the same workload within ~budget_s of CPU
+    time.  The mode the bench line is quoted in (train unless --mode eval) gets 80 % of the budget and runs the FULL batch when 1
+    warm-up + 5 timed steps of it fit (configuration 2 on the GPU box's cores: ~3.7 s per step) -- `value` is then a measurement
+    of the stated workload, not a scaled sample; otherwise, and for the other mode, the largest
+    power-of-two share of the episodes that fits (same L / V / G; rate scaled by sample / batch, per-episode work is independent).
+    Protocol of SURVEY.md §8(d): 1 warm-up + timed fwd+bwd steps, MEDIAN, model.train() and model.eval() variants, cores stated."""
     from oracle import planner_oracle as po
     ocfg = po.PlannerConfig.rxr(**cfg_kwargs) if w["task"] == "rxr" else po.PlannerConfig.r2r(**cfg_kwargs)
     try:
@@ -77,20 +79,26 @@ def cpu_baseline(w, cfg_kwargs, budget_s=24.0, train=True):
             v.grad = None
         po.planner_step(P, ocfg, b, drop=drop)["loss"].backward()
 
-    probe_b = min(2, w["B"])
+    probe_b = min(4, w["B"])
     pb = po.make_batch(ocfg, B=probe_b, L=w["L"], V=w["V"], G=w["G"], seed=1234)
     one(pb, None)                                  # warm-up (allocator, thread pool)
     t0 = time.time()
     one(pb, None)
-    per_ep = (time.time() - t0) / probe_b
-    n_timed = 5
-    sb = w["B"]
-    while sb > probe_b and per_ep * sb * (2 * n_timed + 2) > budget_s:
-        sb //= 2
-    batch = po.make_batch(ocfg, B=sb, L=w["L"], V=w["V"], G=w["G"], seed=1234)
-    scale = sb / w["B"]
-    res = {}
-    for mode in ("train", "eval"):
+    per_ep = (time.time() - t0) / probe_b          # small batches run the CPU GEMMs less efficiently: an upper estimate, so the
+                                                   # leg spends less than budget_s (configuration 2 on the GPU box: ~27 s)
+
+    def share(seconds, steps):                     # largest power-of-two share of the batch whose `steps` steps fit `seconds`
+        sb = w["B"]
+        while sb > 1 and per_ep * sb * steps > seconds:
+            sb //= 2
+        return sb
+
+    primary = "train" if train else "eval"
+    plan = {primary: (share(0.8 * budget_s, 6), 5)}
+    plan["eval" if train else "train"] = (share(0.2 * budget_s, 4), 3)
+    res, desc = {}, {}
+    for mode, (sb, n_timed) in plan.items():
+        batch = po.make_batch(ocfg, B=sb, L=w["L"], V=w["V"], G=w["G"], seed=1234)
         drop = po.TorchDrop(0.1, 0.1, 0.1, 0.0) if mode == "train" else None   # policy.train(): nn.Dropout at every reference site
         one(batch, drop)                           # 1 warm-up
         ts = []
@@ -99,16 +107,17 @@ def cpu_baseline(w, cfg_kwargs, budget_s=24.0, train=True):
             one(batch, drop)
             ts.append(time.time() - t0)
         ts.sort()
-        res[mode] = scale / ts[len(ts) // 2]
-    primary = "train" if train else "eval"
+        res[mode] = (sb / w["B"]) / ts[len(ts) // 2]
+        desc[mode] = (f"{mode}: median of {n_timed} timed fwd+bwd steps after 1 warm-up of " +
+                      (f"the full batch of {sb} episodes (measured, not scaled)" if sb == w["B"] else
+                       f"{sb} of the {w['B']} episodes per step (same L/V/G), rate scaled by {sb}/{w['B']}"))
     return {"value": res[primary], "unit": "steps/s", "cores": cores, "kind": "port", "mode": primary,
-            "train_value": res["train"], "eval_value": res["eval"],
+            "train_value": res["train"], "eval_value": res["eval"], "full_batch": plan[primary][0] == w["B"],
             "reference_module_timing": "profiles/r03_cpu_reference.json (the real vilmodel_cmt.py timed with the same protocol in "
                                        "the build container; /root/reference does not exist on the GPU box, so this leg times the "
                                        "oracle port)",
-            "sample": f"median of {n_timed} timed fwd+bwd steps (after 1 warm-up) of {sb} of the {w['B']} episodes per step (same "
-                      f"L/V/G), rate scaled by {sb}/{w['B']}; fp32 torch CPU oracle (oracle/planner_oracle.py), train (dropout on) "
-                      f"and eval variants, {cores} threads of {avail} available"}
+            "sample": f"{desc[primary]}; {desc['eval' if train else 'train']}; fp32 torch CPU oracle (oracle/planner_oracle.py), "
+                      f"{cores} threads of {avail} available"}
 
 
 def newest_profile(suffix, round_no=None):

@@ -64,13 +64,22 @@ class GraphMapLite:
         self.has_real_pos, self.merge_ghost, self.ghost_aug, self.loc_noise = has_real_pos, merge_ghost, ghost_aug, loc_noise
         self.rng = rng if rng is not None else np.random
 
-    def _localize(self, qpos, kpos_dict):                   # graph_utils.py:146-158
-        min_dis, min_vp = 10000, None
-        for kvp, kpos in kpos_dict.items():
-            dis = float(((np.asarray(qpos) - np.asarray(kpos)) ** 2).sum() ** 0.5)
-            if dis < min_dis:
-                min_dis, min_vp = dis, kvp
-        return None if min_dis > self.loc_noise else min_vp
+    def _nearest(self, queries: np.ndarray, keys: Dict[str, np.ndarray]) -> List[Optional[str]]:
+        """For every query position the key within ``loc_noise`` of it that is nearest (first in insertion order among equals), or
+        None -- the rule of GraphMap._localize (graph_utils.py:146-158) for ALL queries against all keys in one distance matrix
+        instead of a Python loop per pair."""
+        if not len(keys) or not len(queries):
+            return [None] * len(queries)
+        names = list(keys.keys())
+        K = np.asarray([keys[k] for k in names], dtype=np.float64).reshape(len(names), 3)
+        Q = np.asarray(queries, dtype=np.float64).reshape(-1, 3)
+        d2 = ((Q[:, None, :] - K[None, :, :]) ** 2).sum(-1)
+        j = d2.argmin(1)                                     # argmin returns the FIRST minimum, as the reference's strict `<` does
+        best = d2[np.arange(len(Q)), j] ** 0.5
+        return [names[jj] if dd <= self.loc_noise and dd < 10000 else None for jj, dd in zip(j.tolist(), best.tolist())]
+
+    def _localize(self, qpos, kpos_dict):                   # single-query form (kept: the trainer side calls it, graph_utils.py:146)
+        return self._nearest(np.asarray(qpos, dtype=np.float64).reshape(1, 3), kpos_dict)[0]
 
     def identify_node(self, cur_pos, cur_heading, cand_ang, cand_dis):      # :160-166 + estimate_cand_pos :61-71
         cur_vp = str(len(self.node_pos))
@@ -94,46 +103,56 @@ class GraphMapLite:
             self.ghost_real_pos.pop(vp)
 
     def update_graph(self, prev_vp, step_id, cur_vp, cur_pos, cur_embeds, cand_vp, cand_pos, cand_embeds, cand_real_pos):
-        """graph_utils.py:177-257 minus the two networkx calls at the end."""
+        """The bookkeeping of GraphMap.update_graph (graph_utils.py:177-257) without its two networkx all-pairs calls (the device
+        computes the shortest paths, csrc/graph.hip), organised around what depends on what:
+          1. the visited node and its edge to the previous one;
+          2. every candidate against the VISITED nodes at once (their positions do not change during the call): a match is an edge;
+          3. the remaining candidates, in order, against the ghosts (sequential by nature: each may create or move a ghost);
+          4. the position jitter of the ghosts."""
+        cur_pos = np.asarray(cur_pos, dtype=np.float64)
         if prev_vp is not None:
             self._add_edge(prev_vp, cur_vp, _dist(self.node_pos[prev_vp], cur_pos))
-        self.node_pos[cur_vp] = np.asarray(cur_pos, dtype=np.float64)
-        self.node_embeds[cur_vp] = cur_embeds
-        self.node_stepId[cur_vp] = step_id
-        for i, (cvp, cpos, cembeds) in enumerate(zip(cand_vp, cand_pos, cand_embeds)):
-            cpos = np.asarray(cpos, dtype=np.float64)
-            localized_nvp = self._localize(cpos, self.node_pos)
-            if localized_nvp is not None:
-                self._add_edge(cur_vp, localized_nvp, _dist(cur_pos, self.node_pos[localized_nvp]))
-                continue
-            localized_gvp = self._localize(cpos, self.ghost_mean_pos) if self.merge_ghost else None
-            if localized_gvp is None:
-                gvp = f"g{self.ghost_cnt}"
-                self.ghost_cnt += 1
-                self.ghost_pos[gvp] = [cpos]
-                self.ghost_mean_pos[gvp] = cpos
-                self.ghost_embeds[gvp] = [[int(cembeds)] if _is_row(cembeds) else cembeds, 1]
-                self.ghost_fronts[gvp] = [cur_vp]
-                if self.has_real_pos:
-                    self.ghost_real_pos[gvp] = [cand_real_pos[i]]
+        self.node_pos[cur_vp], self.node_embeds[cur_vp], self.node_stepId[cur_vp] = cur_pos, cur_embeds, step_id
+        n = min(len(cand_vp), len(cand_pos), len(cand_embeds))
+        cand_xyz = np.asarray([np.asarray(p, dtype=np.float64) for p in cand_pos[:n]], dtype=np.float64).reshape(n, 3)
+        on_node = self._nearest(cand_xyz, self.node_pos)
+        for i in range(n):
+            if on_node[i] is not None:
+                self._add_edge(cur_vp, on_node[i], _dist(cur_pos, self.node_pos[on_node[i]]))
             else:
-                gvp = localized_gvp
-                self.ghost_pos[gvp].append(cpos)
-                self.ghost_mean_pos[gvp] = np.mean(self.ghost_pos[gvp], axis=0)
-                if _is_row(cembeds):
-                    self.ghost_embeds[gvp][0].append(int(cembeds))       # device-store mode: remember the rows, sum later
-                else:
-                    self.ghost_embeds[gvp][0] = self.ghost_embeds[gvp][0] + cembeds
-                self.ghost_embeds[gvp][1] += 1
-                self.ghost_fronts[gvp].append(cur_vp)
-                if self.has_real_pos:
-                    self.ghost_real_pos[gvp].append(cand_real_pos[i])
+                self._absorb(cur_vp, cand_xyz[i], cand_embeds[i], cand_real_pos[i] if self.has_real_pos else None)
+        self._jitter_ghosts()
+
+    def _absorb(self, front_vp, pos, embeds, real_pos):
+        """One candidate that is no visited node: it joins the ghost it localises to (merge_ghost) or becomes a new ghost."""
+        gvp = self._localize(pos, self.ghost_mean_pos) if self.merge_ghost else None
+        if gvp is None:
+            gvp = f"g{self.ghost_cnt}"
+            self.ghost_cnt += 1
+            self.ghost_pos[gvp], self.ghost_mean_pos[gvp], self.ghost_fronts[gvp] = [pos], pos, [front_vp]
+            # device-store mode keeps the ROWS of the embedding store (summed on the device later); tensor mode the running sum
+            self.ghost_embeds[gvp] = [[int(embeds)] if _is_row(embeds) else embeds, 1]
+            if self.has_real_pos:
+                self.ghost_real_pos[gvp] = [real_pos]
+            return
+        self.ghost_pos[gvp].append(pos)
+        self.ghost_mean_pos[gvp] = np.mean(self.ghost_pos[gvp], axis=0)
+        acc = self.ghost_embeds[gvp]
+        if _is_row(embeds):
+            acc[0].append(int(embeds))
+        else:
+            acc[0] = acc[0] + embeds
+        acc[1] += 1
+        self.ghost_fronts[gvp].append(front_vp)
+        if self.has_real_pos:
+            self.ghost_real_pos[gvp].append(real_pos)
+
+    def _jitter_ghosts(self):                                # graph_utils.py:245-252
         self.ghost_aug_pos = {k: np.array(v, dtype=np.float64) for k, v in self.ghost_mean_pos.items()}
-        if self.ghost_aug != 0:                              # :246-252
+        if self.ghost_aug != 0:
             for gvp, gpos in self.ghost_aug_pos.items():
                 noise = self.rng.normal(loc=(0, 0, 0), scale=(self.ghost_aug, 0, self.ghost_aug), size=(3,))
-                noise = np.clip(noise, -self.ghost_aug, self.ghost_aug)
-                self.ghost_aug_pos[gvp] = gpos + noise
+                self.ghost_aug_pos[gvp] = gpos + np.clip(noise, -self.ghost_aug, self.ghost_aug)
 
     def get_node_embeds(self, vp):                           # :272-276 (tensor mode only)
         if not vp.startswith("g"):

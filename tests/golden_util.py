@@ -150,6 +150,7 @@ def compare_full_bf16(mine, ref, skip_prefix="__input__", rel=None, cos_min=None
     (tests/test_baseline_shapes_gpu.py: set from the observed worst tensors, profiles/r04_parity_bf16_observed.txt)."""
     BF16_FULL_REL_, BF16_COS_MIN_ = (BF16_FULL_REL if rel is None else rel), (BF16_COS_MIN if cos_min is None else cos_min)
     worst_r, worst_c = (0.0, ""), (1.0, "")
+    via_floor = []
     for k, g in ref.items():
         if k.startswith(skip_prefix):
             continue
@@ -157,11 +158,15 @@ def compare_full_bf16(mine, ref, skip_prefix="__input__", rel=None, cos_min=None
         nb, d = float(b.norm()), float((a - b).norm())
         floor = BF16_NAMED_FLOOR.get(k, BF16_ABS_FLOOR)
         assert d <= BF16_FULL_REL_ * nb + floor, f"grad {k}: ||err|| {d:.3e} > {BF16_FULL_REL_} * ||ref|| {nb:.3e} + {floor}"
+        if d > BF16_FULL_REL_ * nb:        # within the bound only thanks to the absolute floor: say so
+            via_floor.append(f"{k} (||err|| {d:.2e} = {d / max(nb, 1e-30):.1%} of ||ref|| {nb:.2e}, floor {floor:g})")
         if nb > 1e-3:
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
             assert cos >= BF16_COS_MIN_, f"grad {k}: cosine {cos:.5f} < {BF16_COS_MIN_}"
             worst_c = min(worst_c, (cos, k))
             worst_r = max(worst_r, (d / nb, k))
+    if via_floor:
+        print("bf16: tensors inside the bound only through the absolute floor:", "; ".join(via_floor))
     return worst_r, worst_c
 
 

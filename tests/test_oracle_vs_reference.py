@@ -69,3 +69,46 @@ def test_graph_assembly_randomised_against_the_real_classes(seed):
     assert np.array_equal(got["gmap_visited_masks"], ref["gmap_visited_masks"][0].numpy())
     assert np.abs(got["gmap_pos_fts"] - ref["gmap_pos_fts"][0].numpy()).max() < 2e-6
     assert np.abs(got["gmap_pair_dists"] - ref["gmap_pair_dists"][0].numpy()).max() < 2e-6
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_graph_map_lite_with_real_positions_and_ghost_jitter_against_the_real_class(seed):
+    """The two GraphMap options the rollout driver above leaves off: has_real_pos (training keeps the simulator's positions of the
+    candidates per ghost, graph_utils.py:213-214,225-226,236-237) and ghost_aug (position jitter from np.random, :245-252).  Both
+    classes are driven with the same candidates and the same numpy seed; every dict of the graph must agree."""
+    import numpy as np
+    from oracle.make_golden_graph import load_reference_graph_utils
+    from etpnav_amd.graph_inputs import GraphMapLite
+    gu = load_reference_graph_utils()
+    out = []
+    for cls in (gu.GraphMap, GraphMapLite):
+        rng = np.random.RandomState(seed)
+        np.random.seed(1000 + seed)                          # the jitter draws from the global generator in both classes
+        g = cls(True, 0.5, bool(seed % 2), 0.3)              # has_real_pos, loc_noise, merge_ghost, ghost_aug
+        pos, heading, prev = np.array([0.3, 0.2, -0.4]), 1.0, None
+        for k in range(6):
+            n = rng.randint(2, 6)
+            cur_vp, cand_vp, cand_pos = g.identify_node(pos, heading, list(rng.uniform(0, 6.28, n)), list(rng.uniform(0.3, 2.0, n)))
+            real = [p + rng.normal(0, 0.05, 3) for p in cand_pos]
+            g.update_graph(prev, k + 1, cur_vp, pos, float(k), cand_vp, cand_pos, [float(10 * k + i) for i in range(n)], real)
+            prev = cur_vp
+            if k == 5:
+                break        # compare right after an update (the reference leaves a deleted ghost in ghost_aug_pos until the next one)
+            ghosts = list(g.ghost_pos.keys())
+            gv = ghosts[rng.randint(len(ghosts))]
+            pos, heading = np.array(g.ghost_real_pos[gv][0], dtype=np.float64), rng.uniform(0, 6.28)
+            g.delete_ghost(gv)
+        out.append(g)
+    a, b = out
+    edges_a = {tuple(sorted((u, v))): w for u, v, w in a.graph_nx.edges(data="weight")}
+    assert edges_a.keys() == b.edges.keys() and all(abs(edges_a[k] - b.edges[k]) < 1e-12 for k in edges_a)
+    assert list(a.node_pos) == list(b.node_pos) and a.node_stepId == b.node_stepId and a.ghost_cnt == b.ghost_cnt
+    for name in ("ghost_mean_pos", "ghost_aug_pos"):
+        da, db = getattr(a, name), getattr(b, name)
+        assert list(da) == list(db), name
+        assert all(np.allclose(da[k], db[k], atol=1e-12) for k in da), name
+    for name in ("ghost_pos", "ghost_real_pos"):
+        da, db = getattr(a, name), getattr(b, name)
+        assert list(da) == list(db) and all(np.allclose(np.asarray(da[k]), np.asarray(db[k]), atol=1e-12) for k in da), name
+    assert a.ghost_fronts == b.ghost_fronts
+    assert {k: (float(v[0]), v[1]) for k, v in a.ghost_embeds.items()} == {k: (float(v[0]), v[1]) for k, v in b.ghost_embeds.items()}

@@ -122,3 +122,16 @@ def test_forcing_a_gemm_tile_class_switches_the_mm32_family_off(monkeypatch):
     assert os.environ["ETP_GEMM_TILE"] == "64s3" and os.environ["ETP_MM32"] == "0"
     _lib.force_gemm_tile("auto")
     assert os.environ["ETP_GEMM_TILE"] == "" and "ETP_MM32" not in os.environ
+
+
+def test_bench_cpu_baseline_leg_measures_the_full_batch_when_it_fits():
+    """bench.py's `cpu_baseline` (the oracle timed beside the GPU path): the quoted mode runs the whole batch when
+    1 warm-up + 5 timed steps fit the leg's budget and says so; a budget that cannot hold the batch falls back to a scaled share and
+    says that instead."""
+    import bench
+    w = dict(task="r2r", B=4, L=8, V=6, G=5, image_feat_size=768)
+    r = bench.cpu_baseline(w, dict(image_feat_size=768), budget_s=60.0, train=True)
+    assert r["full_batch"] and r["mode"] == "train" and r["value"] == r["train_value"] > 0 and r["eval_value"] > 0
+    assert "the full batch of 4 episodes (measured, not scaled)" in r["sample"] and r["kind"] == "port" and r["cores"] >= 1
+    r = bench.cpu_baseline(w, dict(image_feat_size=768), budget_s=1e-3, train=False)
+    assert not r["full_batch"] and r["mode"] == "eval" and "1 of the 4 episodes per step" in r["sample"] and r["value"] == r["eval_value"] > 0
