@@ -6,7 +6,8 @@ float32, compression='gzip', default libver) -- the fixture that pins etpnav_amd
 
 The values are coarse (multiples of 1/8 with long runs) so that gzip keeps the file small; 14 keys make the root group's B-tree
 span several symbol nodes; the 768-wide key is split into several chunks by h5py's automatic chunking (a chunk B-tree with more
-than one entry, edge chunks included); one key uses shuffle + fletcher32 on top of gzip, one is contiguous, one float16.
+than one entry, edge chunks included); one key uses shuffle + fletcher32 on top of gzip, one is contiguous, one float16; the
+feature datasets carry the two string attributes the reference's extractors set (the reader must step over attribute messages).
 """
 import os
 
@@ -34,6 +35,9 @@ def main():
         for k, v in data.items():
             f.create_dataset(k, v.shape, dtype="float32", compression="gzip")      # extract_rgb_features.py:123
             f[k][...] = v
+            scan, vp = k.split("_")
+            f[k].attrs["scanId"] = scan                                            # :125-126 (extract_depth_features.py:119-120):
+            f[k].attrs["viewpointId"] = vp                                         # attribute messages in every dataset's header
         data["extra_shuffled"] = coarse(rng, (36, 40))
         f.create_dataset("extra_shuffled", data=data["extra_shuffled"], compression="gzip", shuffle=True, fletcher32=True, chunks=(10, 16))
         data["extra_contiguous"] = coarse(rng, (5, 7))

@@ -178,3 +178,43 @@ def test_warmup_linear_schedule_matches_the_reference_function():
     o = Opt()
     sch = WarmupLinearLR(o, 5e-5, 100, 1000)
     assert sch.step(50) == pytest.approx(2.5e-5) and o.lr == pytest.approx(2.5e-5)
+
+
+def test_hdf5_reader_on_a_file_with_thousands_of_keys_written_by_the_real_h5py(tmp_path):
+    """The real feature files hold ~10 000 "{scan}_{viewpoint}" datasets, each with the two string attributes of
+    extract_rgb_features.py:125-126: the root group's B-tree then has internal levels, its local heap and symbol nodes are many.
+    Written here by the REAL h5py of the image's second interpreter (/opt/conda/bin/python3.9 -- the system interpreter has none;
+    skipped where neither exists), read by etpnav_amd.hdf5_lite: every key found, sampled datasets bit for bit."""
+    import subprocess
+    from etpnav_amd import hdf5_lite
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py in this image")
+    path, exp = str(tmp_path / "many.hdf5"), str(tmp_path / "expected.npz")
+    script = f"""
+import h5py, numpy as np
+rng = np.random.default_rng(2)
+exp = {{}}
+with h5py.File({path!r}, 'w') as f:
+    for i in range(4000):
+        scan, vp = f"s{{i % 61:02d}}x", f"{{i:05d}}abcdef"
+        key = scan + "_" + vp
+        data = rng.standard_normal((4, 8)).astype(np.float32)
+        f.create_dataset(key, data.shape, dtype='float32', compression='gzip')
+        f[key][...] = data
+        f[key].attrs['scanId'] = scan
+        f[key].attrs['viewpointId'] = vp
+        if i % 250 == 0:
+            exp[key] = data
+np.savez({exp!r}, **exp)
+"""
+    subprocess.run([py, "-c", script], check=True)
+    f = hdf5_lite.File(path)
+    keys = list(f.keys())
+    assert len(keys) == 4000 and len(set(keys)) == 4000
+    want = np.load(exp)
+    for k in want.files:
+        assert np.array_equal(f[k], want[k]), k
+    fs = ft.FeatureStore(path, None, in_memory=False)
+    k0 = want.files[3]
+    assert np.array_equal(fs.get_scanvp_feature(*k0.split("_"))[0], want[k0])
