@@ -18,6 +18,8 @@ the image's /opt/conda/bin/python3.9, the one interpreter here that has h5py).  
 """
 from __future__ import annotations
 
+import mmap
+import os
 import struct
 import zlib
 from typing import Dict, List, Tuple
@@ -97,8 +99,19 @@ class File:
 
     def __init__(self, path: str):
         self.path = path
+        # The real feature files are gigabytes: map the file instead of reading it (pages come in as datasets are decoded, are
+        # shared between data-loader workers through the page cache, and nothing is copied at open).
         with open(path, "rb") as fh:
-            self.buf = fh.read()                                      # feature files are read whole once (to_device) or per key
+            if os.fstat(fh.fileno()).st_size == 0:
+                raise Hdf5Unsupported(f"{path}: empty file")
+            self.buf = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        try:
+            self._open()
+        except (IndexError, struct.error) as e:                          # a structure that points outside the file
+            raise Hdf5Unsupported(f"{path}: damaged or truncated file ({e})") from e
+
+    def _open(self):
+        path = self.path
         base = self._find_superblock()
         ver = self.buf[base + 8]
         if ver not in (0, 1):
@@ -125,9 +138,18 @@ class File:
         self._index: Dict[str, int] = {}
         heap_data = self._heap_data(heap)
         for name_off, header in self._group_entries(btree):
-            end = self.buf.index(b"\0", heap_data + name_off)
+            end = self.buf.find(b"\0", heap_data + name_off)
+            if end < 0:
+                raise Hdf5Unsupported(f"{path}: unterminated link name in the root group's heap")
             self._index[self.buf[heap_data + name_off:end].decode()] = header
         self._cache: Dict[str, Dataset] = {}
+
+    # a File travels to data-loader workers by path (a mapping cannot be pickled); the worker maps the file again
+    def __getstate__(self):
+        return {"path": self.path}
+
+    def __setstate__(self, state):
+        self.__init__(state["path"])
 
     # ---- public ----
     def keys(self) -> List[str]:
@@ -138,11 +160,18 @@ class File:
 
     def dataset(self, key: str) -> Dataset:
         if key not in self._cache:
-            self._cache[key] = Dataset(self, key, self._index[key])      # KeyError for an unknown key, as h5py
+            header = self._index[key]                                    # KeyError for an unknown key, as h5py
+            try:
+                self._cache[key] = Dataset(self, key, header)
+            except (IndexError, struct.error) as e:                      # a structure that points outside the file
+                raise Hdf5Unsupported(f"{self.path}: {key}: damaged or truncated file ({e})") from e
         return self._cache[key]
 
     def __getitem__(self, key: str) -> np.ndarray:
-        return self.dataset(key).read()
+        try:
+            return self.dataset(key).read()
+        except (IndexError, struct.error) as e:
+            raise Hdf5Unsupported(f"{self.path}: {key}: damaged or truncated file ({e})") from e
 
     # ---- primitives ----
     def _read(self, addr: int, n: int) -> bytes:

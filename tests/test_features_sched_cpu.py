@@ -218,3 +218,42 @@ np.savez({exp!r}, **exp)
     fs = ft.FeatureStore(path, None, in_memory=False)
     k0 = want.files[3]
     assert np.array_equal(fs.get_scanvp_feature(*k0.split("_"))[0], want[k0])
+
+
+def test_hdf5_reader_maps_the_file_travels_by_path_and_fails_loudly_on_damage(tmp_path):
+    """hdf5_lite.File maps the file (the real ones are gigabytes), pickles as its path (data-loader workers), and refuses damaged input
+    with a reason instead of returning numbers: truncated file, empty file, no HDF5 signature, a corrupted compressed chunk."""
+    import mmap
+    import pickle
+    import shutil
+    import zlib
+    from etpnav_amd import hdf5_lite
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    src = os.path.join(gold, "feats_small.hdf5")
+    want = np.load(os.path.join(gold, "feats_small_expected.npz"))
+    f = hdf5_lite.File(src)
+    assert isinstance(f.buf, mmap.mmap)
+    g = pickle.loads(pickle.dumps(f))
+    assert g.path == f.path and g.keys() == f.keys() and np.array_equal(g["scanW_vp0"], want["scanW_vp0"])
+    raw = open(src, "rb").read()
+    cut = str(tmp_path / "cut.hdf5")
+    open(cut, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(hdf5_lite.Hdf5Unsupported):
+        h = hdf5_lite.File(cut)
+        for k in h.keys():
+            h[k]
+    open(str(tmp_path / "empty.hdf5"), "wb").close()
+    with pytest.raises(hdf5_lite.Hdf5Unsupported, match="empty"):
+        hdf5_lite.File(str(tmp_path / "empty.hdf5"))
+    open(str(tmp_path / "text.hdf5"), "wb").write(b"not an hdf5 file" * 100)
+    with pytest.raises(hdf5_lite.Hdf5Unsupported):
+        hdf5_lite.File(str(tmp_path / "text.hdf5"))
+    # flip bytes inside the first compressed chunk of the wide dataset: zlib (or the shape check) must object
+    ds = f.dataset("scanW_vp0")
+    size, mask, offs, addr = next(iter(f._chunks(ds.layout[1], 2)))
+    bad = bytearray(raw)
+    a = f.base_addr + addr
+    bad[a + 8:a + 24] = bytes(16)
+    open(str(tmp_path / "bad.hdf5"), "wb").write(bytes(bad))
+    with pytest.raises((zlib.error, ValueError)):
+        hdf5_lite.File(str(tmp_path / "bad.hdf5"))["scanW_vp0"]
