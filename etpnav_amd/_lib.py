@@ -187,13 +187,50 @@ def ptr(t) -> int:
     return t.data_ptr()
 
 
+def set_option(name: str, value=None) -> None:
+    """One run-time switch of the library (csrc/options.h; `etp_option_set`).  ``value`` None / "" = unset.  The library reads the
+    environment (ETP_<NAME>) only once, at its first lookup: after that a switch changes through this call, not through os.environ."""
+    v = None if value is None or value == "" else str(value).encode()
+    check(lib().etp_option_set(name.encode(), v), f"etp_option_set({name})")
+
+
+def get_option(name: str):
+    buf = ctypes.create_string_buffer(64)
+    n = lib().etp_option_get(name.encode(), buf, 64)
+    if n < 0:
+        raise EtpError(f"unknown library switch {name!r}")
+    return buf.value.decode() if n > 0 else None
+
+
+def options() -> Dict[str, str]:
+    """every switch of the library that is set, however it got there (environment at load, or set_option)"""
+    L = lib()
+    n = L.etp_option_list(None, 0)
+    buf = ctypes.create_string_buffer(n + 1)
+    L.etp_option_list(buf, n + 1)
+    return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+
+
+class option:
+    """``with _lib.option("MM32", 64): ...`` -- set a switch and restore what was there (tests, A/B legs)."""
+
+    def __init__(self, name: str, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
 def force_gemm_tile(tile: str = "") -> None:
     """Tuning aid: force a tile class of gemm.hip's kernels for the following launches ("" / "auto" = the library's own choice).
     The mm32 family is consulted BEFORE gemm.hip's tile choice (csrc/gemm_mm32.hip::mm32_class), so forcing a gemm.hip class
     also switches mm32 off -- otherwise an eligible bf16 product would silently keep running the mm32 kernel."""
     tile = "" if tile == "auto" else tile
-    os.environ["ETP_GEMM_TILE"] = tile
-    if tile:
-        os.environ["ETP_MM32"] = "0"
-    else:
-        os.environ.pop("ETP_MM32", None)
+    set_option("GEMM_TILE", tile)
+    set_option("MM32", "0" if tile else None)

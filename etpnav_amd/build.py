@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libetpnav_hip.so")
 SOURCES = ["gemm.hip", "gemm_mm32.hip", "attn.hip", "attn_rows.hip", "norm.hip", "embed.hip", "optim.hip", "graph.hip", "planner.hip", "capi.hip", "graphrec.hip", "comm.hip"]
-HEADERS = ["common.h", "kernels.h", "launch.h", "gemm_shared.h", "gemm_tiles.h", os.path.join("..", "..", "include", "etpnav_hip.h")]
+HEADERS = ["common.h", "kernels.h", "launch.h", "options.h", "gemm_shared.h", "gemm_tiles.h", os.path.join("..", "..", "include", "etpnav_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -munsafe-fp-atomics: fp32 atomicAdd lowers to the hardware global_atomic_add_f32 / ds_add_f32 instead of a CAS loop
 # (all our atomic targets are ordinary coarse-grained device allocations).

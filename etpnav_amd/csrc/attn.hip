@@ -833,8 +833,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const AttnKArgs a, i
 
 // ---- host side -----------------------------------------------------------------------------------------
 static bool fused_enabled() {
-  const char* e = getenv("ETP_ATTN_FUSED");
-  return !(e && e[0] == '0');
+  return opt_on(OPT_ATTN_FUSED, true);
 }
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc) {
   if (!fused_enabled()) return false;
@@ -848,24 +847,16 @@ bool attn_fused_ok(int dt, const AttnBuf& a, long ldc) {
 
 template <typename T, int BQ, int BKV> static int launch_fwd(const AttnKArgs& k, int blocks, hipStream_t st) {
   constexpr int smem = AttnFwdLds<T, BQ, BKV>::TOTAL;
-  static bool attr = false;
   auto kern = attn_fwd_kernel<T, BQ, BKV>;
-  if (!attr) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   ETP_LAUNCH(kern, dim3(blocks), dim3(256), smem, st, k);
   ETP_CHECK_LAUNCH("attn_fwd");
   return ETP_OK;
 }
 template <typename T, int BQ, int BKV> static int launch_bwd(const AttnKArgs& k, int blocks, hipStream_t st) {
   constexpr int smem = AttnBwdLds<T, BQ, BKV>::TOTAL;
-  static bool attr = false;
   auto kern = attn_bwd_kernel<T, BQ, BKV>;
-  if (!attr) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   ETP_LAUNCH(kern, dim3(blocks), dim3(256), smem, st, k);
   ETP_CHECK_LAUNCH("attn_bwd");
   return ETP_OK;
@@ -883,7 +874,7 @@ static AttnKArgs make_args(int nh, const AttnBuf& a, float alpha) {
 // streaming kernels: bf16, a query or key axis beyond the resident-tile kernels, no pairwise-distance bias (that only exists
 // on the graph self-attention, G <= 128), room for lse + D (2 floats per row) in the probability buffer
 bool attn_flash_ok(int dt, const AttnBuf& a, long ldc) {
-  static const bool on = [] { const char* e = getenv("ETP_ATTN_FLASH"); return !(e && e[0] == '0'); }();
+  const bool on = opt_on(OPT_ATTN_FLASH, true);
   if (!on || !fused_enabled() || dt != ETP_BF16) return false;
   if (a.Lq <= 128 && a.Lk <= 128) return false;
   if (a.dist != nullptr || a.Lq < 1 || a.Lk < 1 || a.ldS < 4) return false;
@@ -892,13 +883,9 @@ bool attn_flash_ok(int dt, const AttnBuf& a, long ldc) {
   return true;
 }
 static int flash_attr() {
-  static bool done = false;
-  if (done) return ETP_OK;
-  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
-  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FlashLds::TOTAL));
-  ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<FBKV2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    FlashLdsT<FBKV2>::TOTAL));
-  done = true;
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(flash_fwd_kernel), FlashLds::TOTAL));      // per device (launch.h)
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dq_kernel), FlashLds::TOTAL));
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<FBKV2>), FlashLdsT<FBKV2>::TOTAL));
   return ETP_OK;
 }
 int attn_flash_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
@@ -935,7 +922,7 @@ int attn_fused_fwd(int dt, int nh, const AttnBuf& a, void* P, void* ctx, long ld
   k.nq = (a.Lq + 63) / 64;                        // 64 queries per workgroup
   int blocks = a.B * nh * k.nq;
   if (dt == ETP_BF16) {     // key tile = 64 / 96 / 128 columns: the 80-token instruction takes the 96 one, not a 128 pad
-    static const bool q96 = [] { const char* e = getenv("ETP_ATTN_Q96"); return !(e && e[0] == '0'); }();
+    const bool q96 = opt_on(OPT_ATTN_Q96, true);
     if (q96 && a.Lq > 64 && a.Lq <= 96 && a.Lk > 64 && a.Lk <= 96) {
       // the 80-token self-attention: ONE 96-query workgroup per (batch, head) instead of a full and a quarter-full 64-query
       // one (K/V staged once, half the workgroups)

@@ -399,20 +399,15 @@ __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
 
 template <int NKT, bool HAS_DIST> int launch_rows_fwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
   const int smem = 2 * NKT * 16 * TQ + NKT * 16 * 4 + (threads / 64) * 16 * TP;
-  ETP_LAUNCH((rows_fwd_kernel<NKT, HAS_DIST>), dim3(blocks), dim3(threads), smem, st, k);
+  ETP_LAUNCH_ROW(ROWF_ATTN_FWD, (rows_fwd_kernel<NKT, HAS_DIST>), dim3(blocks), dim3(threads), smem, st, k);
   ETP_CHECK_LAUNCH("attn_rows_fwd");
   return ETP_OK;
 }
 template <int NKT, bool HAS_DIST> int launch_rows_bwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
   const BwdLds L(((k.Lq + 15) >> 4) * 16, NKT * 16);
-  static bool attr = false;
   auto kern = rows_bwd_kernel<NKT, HAS_DIST>;
-  if (!attr) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      BwdLds(128, NKT * 16).total));
-    attr = true;
-  }
-  ETP_LAUNCH(kern, dim3(blocks), dim3(threads), L.total, st, k);
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BwdLds(128, NKT * 16).total));
+  ETP_LAUNCH_ROW(ROWF_ATTN_BWD, kern, dim3(blocks), dim3(threads), L.total, st, k);
   ETP_CHECK_LAUNCH("attn_rows_bwd");
   return ETP_OK;
 }
@@ -455,7 +450,7 @@ RowArgs make_row_args(int nh, const AttnBuf& a, void* P, float alpha, Drop drop)
 
 // bf16, both axes <= 128, 16-byte aligned operands; the probability buffer must hold Lq fp32 per (batch, head)
 bool attn_rows_ok(int dt, const AttnBuf& a, long ldc) {
-  static const bool on = [] { const char* e = getenv("ETP_ATTN_ROWS"); return !(e && e[0] == '0'); }();
+  const bool on = opt_on(OPT_ATTN_ROWS, true);
   if (!on || dt != ETP_BF16) return false;
   if (a.Lq > 128 || a.Lk > 128 || a.Lq < 1 || a.Lk < 1 || a.ldS < 2) return false;
   if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || ldc % 8) return false;
@@ -468,7 +463,7 @@ bool attn_rows_ok(int dt, const AttnBuf& a, long ldc) {
 // the attention kernels cost in the step (results are wrong in that mode); see ETP_SKIP_LN in norm.hip.
 static bool skip_attn(const char* what) {
 #ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
-  static const char* e = getenv("ETP_SKIP_ATTN");
+  const char* e = opt_str(OPT_SKIP_ATTN);
   return e && strstr(e, what) != nullptr;
 #else
   (void)what;

@@ -3,11 +3,145 @@
 
 #include <vector>
 
+#include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
+
 #include "kernels.h"
+#include "options.h"
 
 namespace etp {
 
 static thread_local std::string g_last_error;
+
+// ---- per-device launch attributes (launch.h) ----------------------------------------------------------------------------------
+static std::mutex g_attr_mu;
+static std::vector<std::pair<std::pair<const void*, int>, int>> g_attr_set;     // ((kernel, device), bytes)
+hipError_t ensure_dyn_lds(const void* kern, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  for (auto& it : g_attr_set)
+    if (it.first.first == kern && it.first.second == dev) {
+      if (it.second >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) it.second = bytes;
+      return e;
+    }
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) g_attr_set.push_back({{kern, dev}, bytes});
+  return e;
+}
+int cu_lds_bytes() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 160 * 1024;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 160 * 1024;
+  v = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (v <= 0) v = 160 * 1024;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+unsigned row_launch_lds(const void* kern, int family, unsigned smem) {
+  if (!(opt_int(OPT_ROW_EXCLUSIVE, ROWF_DEFAULT) & family)) return smem;
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> stat;       // static LDS of each kernel seen (the same on every device)
+  int st_bytes = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& it : stat) if (it.first == kern) st_bytes = it.second;
+    if (st_bytes < 0) {
+      hipFuncAttributes fa;
+      st_bytes = hipFuncGetAttributes(&fa, kern) == hipSuccess ? (int)fa.sharedSizeBytes : 0;
+      stat.push_back({kern, st_bytes});
+    }
+  }
+  const int want = cu_lds_bytes() - st_bytes;
+  if (want <= (int)smem) return smem;
+  const hipError_t e = ensure_dyn_lds(kern, want);
+  if (e != hipSuccess) { set_launch_error(e); return smem; }
+  return (unsigned)want;
+}
+
+// ---- run-time switches (options.h) -------------------------------------------------------------------------------------------
+static const char* const kOptNames[OPT_COUNT] = {
+    "MM32", "MM32_GROUP", "GEMM_TILE", "GROUP_TILE", "GEMM_WIDE", "GEMM_SMALL", "GEMM_XCD", "ATTN_FUSED", "ATTN_FLASH", "ATTN_Q96",
+    "ATTN_ROWS", "LNBWD_GRID", "LNBWD_TWO_STAGE", "LN_TICKET", "WGRAD_GROUP", "FLUSH_DELAY", "FLUSH_EVERY", "ROW_EXCLUSIVE",
+    "GROUP_ORDER", "GELU_TABLE",
+#ifdef ETP_EXPERIMENTS
+    "SKIP_LN", "SKIP_ATTN", "SKIP_WGRAD",
+#endif
+};
+// two value slots per switch: a setter writes the slot that is NOT published and then flips the index, so a concurrent reader never
+// sees a half-written string (readers hold no lock; setters are serialised)
+static char g_opt_val[OPT_COUNT][2][32];
+static std::atomic<int> g_opt_slot[OPT_COUNT];      // -1 unset, else the published slot
+static std::once_flag g_opt_once;
+static std::mutex g_opt_mu;
+static void opt_store(int i, const char* v) {
+  if (!v || !v[0]) { g_opt_slot[i].store(-1, std::memory_order_release); return; }
+  const int cur = g_opt_slot[i].load(std::memory_order_acquire), nxt = cur == 0 ? 1 : 0;
+  strncpy(g_opt_val[i][nxt], v, sizeof(g_opt_val[i][nxt]) - 1);
+  g_opt_val[i][nxt][sizeof(g_opt_val[i][nxt]) - 1] = 0;
+  g_opt_slot[i].store(nxt, std::memory_order_release);
+}
+static void opt_init() {
+  std::call_once(g_opt_once, [] {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      g_opt_slot[i].store(-1);
+      const std::string env = std::string("ETP_") + kOptNames[i];
+      opt_store(i, getenv(env.c_str()));
+    }
+  });
+}
+const char* opt_str(Opt o) {
+  opt_init();
+  const int s = g_opt_slot[o].load(std::memory_order_acquire);
+  return s < 0 ? nullptr : g_opt_val[o][s];
+}
+int opt_int(Opt o, int dflt) {
+  const char* s = opt_str(o);
+  return s ? atoi(s) : dflt;
+}
+static int opt_index(const char* name) {
+  if (!name) return -1;
+  if (!strncmp(name, "ETP_", 4)) name += 4;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(name, kOptNames[i])) return i;
+  return -1;
+}
+int opt_set(const char* name, const char* value) {
+  opt_init();
+  const int i = opt_index(name);
+  if (i < 0) return -1;
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  opt_store(i, value);
+  return 0;
+}
+int opt_get(const char* name, char* out, int cap) {
+  const int i = opt_index(name);
+  if (i < 0) return -1;
+  const char* v = opt_str((Opt)i);
+  const int n = v ? (int)strlen(v) : 0;
+  if (out && cap > 0) { strncpy(out, v ? v : "", cap - 1); out[cap - 1] = 0; }
+  return n;
+}
+int opt_list(char* out, int cap) {
+  opt_init();
+  std::string s;
+  for (int i = 0; i < OPT_COUNT; ++i) {
+    const char* v = opt_str((Opt)i);
+    if (v) s += std::string(kOptNames[i]) + "=" + v + "\n";
+  }
+  if (out && cap > 0) { strncpy(out, s.c_str(), cap - 1); out[cap - 1] = 0; }
+  return (int)s.size();
+}
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
@@ -42,6 +176,13 @@ extern "C" {
 
 const char* etp_version(void) { return "etpnav_hip 0.1.0 (gfx950)"; }
 const char* etp_last_error(void) { return g_last_error.c_str(); }
+
+int etp_option_set(const char* name, const char* value) {
+  if (opt_set(name, value) != 0) return fail(ETP_ERR_INVALID, std::string("etp_option_set: unknown switch ") + (name ? name : "(null)"));
+  return ETP_OK;
+}
+int etp_option_get(const char* name, char* out, int cap) { return opt_get(name, out, cap); }
+int etp_option_list(char* out, int cap) { return opt_list(out, cap); }
 
 static int desc_to_args(const etp_gemm_desc* d, GemmArgs& g) {
   ETP_REQUIRE(d && d->A && d->B && d->C, "null descriptor/operand");

@@ -6,6 +6,7 @@
 
 #include "../../include/etpnav_hip.h"
 #include "launch.h"
+#include "options.h"
 
 namespace etp {
 

@@ -834,7 +834,7 @@ int text_embed_bwd(int dtype, const float* dy, const int64_t* ids, const float* 
   ETP_REQUIRE(B > 0 && L > 0 && H % 256 == 0, "bad dims");
   (void)dtype;
   const int M = B * L, grid = L < 1024 ? L : 1024;      // one workgroup per position (segment sum of its gradient over the batch)
-  ETP_DISPATCH_H(H, ETP_LAUNCH((text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
+  ETP_DISPATCH_H(H, ETP_LAUNCH_ROW(ROWF_TEXT_BWD, (text_embed_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dy, ids, word, pos, type0, gamma, stats, dword, dpos, dtype0, dgamma, dbeta, M, L, drop));
   ETP_CHECK_LAUNCH("text_embed_bwd");
   return ETP_OK;
 }
@@ -855,12 +855,8 @@ static int launch_pano_embed_bwd(int grid, size_t smem, hipStream_t st, const fl
                                  void* dd, int M, Drop drop) {
   void (*kern)(const float*, const TT*, const TT*, const float*, const int64_t*, const float*, PanoEmbedParams, PanoEmbedGrads, TT*, TT*,
                int, Drop) = pano_embed_bwd_kernel<TT, NCH, PART>;
-  static bool attr_set = false;       // more than 64 KB of dynamic LDS needs the attribute once per instantiation
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
-  ETP_LAUNCH(kern, dim3(grid), dim3(256), smem, st, dy, (const TT*)a, (const TT*)d, loc, nav, stats, p, g, (TT*)da, (TT*)dd, M, drop);
+  ETP_LAUNCH_ROW(ROWF_PANO_BWD, kern, dim3(grid), dim3(256), (unsigned)smem, st, dy, (const TT*)a, (const TT*)d, loc, nav, stats, p, g,
+                 (TT*)da, (TT*)dd, M, drop);
   ETP_CHECK_LAUNCH("pano_embed_bwd");
   return ETP_OK;
 }
@@ -870,11 +866,12 @@ int pano_embed_bwd(int dtype, const float* dy, const void* a, const void* d, con
                    hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 96);   // ~3 rows per wave; each block flushes 16*H global atomics
-  // The launches ask for the CU's WHOLE LDS (160 KB; they use 12 KB): no workgroup of another kernel can then share the CU.  Every
-  // form of this backward that shared SIMDs with other kernels' wavefronts returned sums that moved from run to run (race screen of
-  // tests/test_variants_gpu.py, profiles/r05_pano_embed_race.txt): the round-4 kernel was only stable because its 482 registers kept
-  // each SIMD to itself.  The mechanism is open; the exclusivity is now explicit instead of a side effect of AGPRs.
-  const size_t smem = 160 * 1024;
+  // The launches use 12 KB of LDS and ASK for the CU's whole LDS (ROWF_PANO_BWD in the ROW_EXCLUSIVE mask, launch.h; the size comes
+  // from the device's properties and the attribute is set per device): no workgroup of another kernel can then share the CU.
+  // Every form of this backward that shared SIMDs with other kernels' wavefronts returned sums that moved from run to run (race
+  // screen of tests/test_variants_gpu.py, profiles/r05_pano_embed_race.txt): the round-4 kernel was only stable because its 482
+  // registers kept each SIMD to itself.  The mechanism is open; the exclusivity is explicit.
+  const size_t smem = 4 * (size_t)H * sizeof(float);
   if (dtype == ETP_BF16) {
     ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<bf16_t, NCH, 0>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
     ETP_DISPATCH_H(H, ETP_TRY((launch_pano_embed_bwd<bf16_t, NCH, 1>(grid, smem, st, dy, a, d, loc, nav, stats, p, g, da, dd, M, drop))));
@@ -906,7 +903,7 @@ int gmap_embed_bwd(int dtype, const float* dx, const int64_t* step_ids, const fl
   (void)dtype;
   const int grid = row_grid(M, 64);
   const size_t smem = 4 * (size_t)H * sizeof(float);
-  ETP_DISPATCH_H(H, ETP_LAUNCH((gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M));
+  ETP_DISPATCH_H(H, ETP_LAUNCH_ROW(ROWF_GMAP_BWD, (gmap_embed_bwd_kernel<float, NCH, 7>), dim3(grid), dim3(256), smem, st, dx, step_ids, pos, w_pos, b_pos, gamma, stats, d_step_emb, d_w_pos, d_b_pos, dgamma, dbeta, M));
   ETP_CHECK_LAUNCH("gmap_embed_bwd");
   return ETP_OK;
 }
@@ -926,8 +923,8 @@ int sap_tail_bwd(int dtype, const float* dlogits, const void* r, const float* ga
                  float* dw2, float* db2, int M, int H, hipStream_t st, Drop drop) {
   ETP_REQUIRE(M > 0 && H % 256 == 0, "bad dims");
   const int grid = row_grid(M, 64);
-  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
-  else { ETP_DISPATCH_H(H, ETP_LAUNCH((sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
+  if (dtype == ETP_BF16) { ETP_DISPATCH_H(H, ETP_LAUNCH_ROW(ROWF_SAP_BWD, (sap_tail_bwd_kernel<bf16_t, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const bf16_t*)r, gamma, beta, w2, stats, visited, valid, (bf16_t*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
+  else { ETP_DISPATCH_H(H, ETP_LAUNCH_ROW(ROWF_SAP_BWD, (sap_tail_bwd_kernel<float, NCH>), dim3(grid), dim3(256), 0, st, dlogits, (const float*)r, gamma, beta, w2, stats, visited, valid, (float*)dz, dgamma, dbeta, dw2, db2, M, drop)); }
   ETP_CHECK_LAUNCH("sap_tail_bwd");
   return ETP_OK;
 }

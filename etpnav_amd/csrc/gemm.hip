@@ -440,14 +440,10 @@ static int launch_one(const GemmArgs& g_in, int nbatch, hipStream_t st) {
   using GB = TileGeom<T, TB, BN, PAD>;
   constexpr int smem_loop = (STAGES == 0 ? 2 : STAGES) * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
   constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
-  static bool attr_set = false;
   void (*kern)(const GemmArgs);
   if constexpr (STAGES == 0) kern = gemm_kernel<T, TC, TA, TB, BM, BN>;
   else kern = gemm_dma_kernel<T, TC, TA, TB, BM, BN, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   const int tiles = ((g_in.M + BM - 1) / BM) * ((g_in.N + BN - 1) / BN);
   dim3 grid(tiles, nbatch * g_in.ksplit, 1);
   GemmArgs g = g_in;
@@ -480,7 +476,7 @@ static bool dma_ok(int bk, int K, int ksplit) {
   // LDS-DMA main loop needs whole 128-byte slabs in every split of the reduction
   bool dma = (K % bk == 0) && (K >= 2 * bk);
   if (ksplit > 1) dma = dma && (K % ksplit == 0) && ((K / ksplit) % bk == 0);
-  const char* force = getenv("ETP_GEMM_TILE");
+  const char* force = opt_str(OPT_GEMM_TILE);
   if (force && strchr(force, 'r')) dma = false;
   return dma;
 }
@@ -510,12 +506,12 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
   // K = 3072 in a single-stream step), but in the real three-stream step the 64x64 class wins, 4.30 vs 4.35 ms per step in
   // three same-box A/B pairs (profiles/r03_ab_runs.json groups c1, c8): its 48-KiB, ~130-register workgroups pack beside the
   // leaf kernels' workgroups where one 96-KiB 128x64 workgroup per CU does not.  ETP_GEMM_WIDE=1 enables it.
-  static const int wide_on = [] { const char* e = getenv("ETP_GEMM_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();
+  const bool wide_on = opt_int(OPT_GEMM_WIDE, 0) == 1;
   if (!wide_on) wide = false;
   const bool dma = dma_ok(BK, g.K, g.ksplit);
   int stages = (big || huge) ? 2 : (wide ? 4 : 3);
   if (!huge && !big && !wide && t64 <= 320 && g.K >= 4 * BK) stages = 4;
-  const char* force = getenv("ETP_GEMM_TILE");   // tuning aid (tools/gemm_sweep.py): "128", "64", "w" + optional "s2".."s4", "64r"
+  const char* force = opt_str(OPT_GEMM_TILE);   // tuning aid (tools/gemm_sweep.py): "128", "64", "w" + optional "s2".."s4", "64r"
   if (force && force[0]) {
     huge = force[0] == '2';                        // "256", "256s3"
     if (force[0] == '1' || force[0] == '6') { big = force[0] == '1'; wide = false; }
@@ -537,7 +533,7 @@ static int launch_tiles(const GemmArgs& g, int nbatch, hipStream_t st) {
     // wavefront count, profiles/r04_gemm_phases.txt), not by bytes: halving the tile rows doubles the workgroups that share
     // the reduction's work at (nearly) the same time per slab.  A row-major only (its 32-row slab is four 1-KiB DMA pieces).
     // ETP_GEMM_SMALL=0 switches the class off (A/B runs), ETP_GEMM_TILE=32 forces it.
-    static const int small_on = [] { const char* e = getenv("ETP_GEMM_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool small_on = opt_on(OPT_GEMM_SMALL, true);
     const bool forced = force && force[0];
     const bool take = forced ? force[0] == '3' : (small_on && nbatch == 1 && g.ksplit == 1 && t64 <= 128 && g.M >= 32 && g.K >= 4 * BK);
     if (take) return launch_one<T, TC, TA, TB, 32, 64, 4>(g, nbatch, st);
@@ -589,7 +585,7 @@ static int prepare_args(int dtype, int c_dtype, int ta, int tb, const GemmArgs& 
   ETP_REQUIRE(dtype != ETP_F32 || c_dtype == ETP_F32, "fp32 operands need an fp32 C");
   g = g0;
   {
-    static const int xcd_on = [] { const char* e = getenv("ETP_GEMM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool xcd_on = opt_on(OPT_GEMM_XCD, true);
     g.xcd_map = xcd_on;
   }
   {  // the vectorised epilogue needs 8-column chunks to stay in-bounds and 16-byte aligned
@@ -624,12 +620,8 @@ static int launch_group_one(GemmGroup& grp, hipStream_t st) {
   using GB = TileGeom<T, TB, BN, 0>;
   constexpr int smem_loop = STAGES * (GA::BYTES + GB::BYTES), smem_c = BM * (BN + 4) * 4;
   constexpr int smem = smem_loop > smem_c ? smem_loop : smem_c;
-  static bool attr_set = false;
   void (*kern)(const GemmGroup) = gemm_group_kernel<T, TC, TA, TB, BM, BN, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   int tiles = 0;
   double flops = 0, bytes = 0;
   for (int i = 0; i < grp.n; ++i) {
@@ -683,7 +675,7 @@ static int launch_group_tiles(GemmGroup& grp, hipStream_t st) {
   for (int i = 0; i < grp.n; ++i) all_huge = all_huge && grp.g[i].M >= 256 && grp.g[i].N >= 128;
   bool huge = false;
   int stages = (big || huge) ? 2 : 3;
-  const char* force = getenv("ETP_GROUP_TILE");          // tuning aid: "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"
+  const char* force = opt_str(OPT_GROUP_TILE);          // tuning aid: "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"
   if (force && force[0]) {
     huge = force[0] == '2' && all_huge;
     big = force[0] == '1' && all_big;

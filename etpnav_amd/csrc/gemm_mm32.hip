@@ -460,12 +460,8 @@ template <int BM, int BN, int STAGES> constexpr int smem_bytes() {
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 static int launch(const GemmArgs& g_in, hipStream_t st) {
   constexpr int smem = smem_bytes<BM, BN, STAGES>();
-  static bool attr_set = false;
   void (*kern)(const GemmArgs) = kernel<TC, TA, TB, BM, BN, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   const int tiles = (g_in.M / BM) * (g_in.N / BN);
   GemmArgs g = g_in;
   char nm[96];
@@ -484,12 +480,8 @@ static int launch(const GemmArgs& g_in, hipStream_t st) {
 template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
 static int launch_group(GemmGroup& grp, hipStream_t st) {
   constexpr int smem = smem_bytes<BM, BN, STAGES>();
-  static bool attr_set = false;
   void (*kern)(const GemmGroup) = group_kernel<TC, TA, TB, BM, BN, STAGES>;
-  if (!attr_set) {
-    ETP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   int tiles = 0;
   double flops = 0, bytes = 0;
   for (int i = 0; i < grp.n; ++i) {
@@ -533,8 +525,7 @@ static int launch_class(const GemmArgs& g, int cls, hipStream_t st) {
 // ETP_MM32=0 switches the family off (A/B runs against gemm.hip's kernels); ETP_MM32=128 / 64 forces that class for every
 // eligible product whatever the tile count (tests).
 static int mm32_mode() {
-  const char* e = getenv("ETP_MM32");
-  return e ? atoi(e) : 1;
+  return opt_int(OPT_MM32, 1);
 }
 int mm32_class(const GemmArgs& g, int nbatch) {
   const int mode = mm32_mode();
@@ -580,8 +571,7 @@ bool mm32_group_ok(const GemmGroup& grp) {
 // 512 tokens 18.1 / 24.6, 1152: 29.0 / 34.4, 2560: 51.4 / 61.8, 8192: 148.8 / 143.5 -- only the 8192-token reductions of
 // BASELINE config 4 take it.  ETP_MM32_GROUP=128 / 256 forces a class (tests, A/B runs).
 static int mm32_group_class(const GemmGroup& grp) {
-  const char* e = getenv("ETP_MM32_GROUP");
-  const int force = e ? atoi(e) : 0;
+  const int force = opt_int(OPT_MM32_GROUP, 0);
   if (force == 128) return 128;
   long t = 0;
   int kmin = 1 << 30;

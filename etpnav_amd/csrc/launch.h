@@ -25,6 +25,23 @@ hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t s);
 bool ktime_active();
 void ktime_begin(const void* fn, dim3 grid, dim3 block, hipStream_t st);
 void ktime_end(hipStream_t st);
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel -- per DEVICE: the attribute lives on the
+// device's copy of the function (a process-wide `static bool attr_set` left the second device of a process without it).
+// Cached per (kernel, current device); a larger request than the cached one is set again.
+hipError_t ensure_dyn_lds(const void* kern, int bytes);
+// LDS bytes of one CU of the current device (hipDeviceProp.maxSharedMemoryPerMultiProcessor; 160 KB on gfx950): what a launch asks
+// for when it must have the CU to itself
+int cu_lds_bytes();
+// Row-kernel families that can be launched with the CU to themselves (a workgroup that asks for the CU's whole LDS
+// shares it with no other kernel's wavefronts).  The switch ROW_EXCLUSIVE is a bit mask over these families; default
+// ROWF_DEFAULT.  tests/test_neighbours_gpu.py runs every family with its bit off beside the 128x128 GEMM tile classes.
+enum RowFamily {
+  ROWF_PANO_BWD = 1, ROWF_GMAP_BWD = 2, ROWF_TEXT_BWD = 4, ROWF_SAP_BWD = 8, ROWF_LN_BWD = 16, ROWF_LN_FWD = 32, ROWF_ATTN_BWD = 64,
+  ROWF_ATTN_FWD = 128,
+  ROWF_DEFAULT = ROWF_PANO_BWD
+};
+// dynamic LDS bytes to launch `kern` with: `smem` itself, or (CU LDS - the kernel's static LDS) when the family's bit is set
+unsigned row_launch_lds(const void* kern, int family, unsigned smem);
 hipError_t launch_status();                                  // error of the last launch (eager: hipGetLastError)
 void set_launch_error(hipError_t e);
 
@@ -55,3 +72,5 @@ inline void launch_kernel(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigne
 }  // namespace etp
 
 #define ETP_LAUNCH(kern, grid, block, smem, st, ...) ::etp::launch_kernel(kern, grid, block, smem, st, __VA_ARGS__)
+#define ETP_LAUNCH_ROW(family, kern, grid, block, smem, st, ...) \
+  ::etp::launch_kernel(kern, grid, block, ::etp::row_launch_lds(reinterpret_cast<const void*>(kern), family, smem), st, __VA_ARGS__)

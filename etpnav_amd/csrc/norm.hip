@@ -298,12 +298,12 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
   else atomicAdd(dbeta + col - H, v);
 }
 
-#define ETP_LN_DISPATCH(KERN, T, GRID, ...)                                                                         \
+#define ETP_LN_DISPATCH(FAM, KERN, T, GRID, ...)                                                                        \
   switch (H / 256) {                                                                                                 \
-    case 1: ETP_LAUNCH((KERN<T, 1>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 2: ETP_LAUNCH((KERN<T, 2>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 3: ETP_LAUNCH((KERN<T, 3>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
-    case 4: ETP_LAUNCH((KERN<T, 4>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 1: ETP_LAUNCH_ROW(FAM, (KERN<T, 1>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 2: ETP_LAUNCH_ROW(FAM, (KERN<T, 2>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 3: ETP_LAUNCH_ROW(FAM, (KERN<T, 3>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
+    case 4: ETP_LAUNCH_ROW(FAM, (KERN<T, 4>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); break;                     \
     default: return fail(ETP_ERR_INVALID, "layer norm: hidden size must be 256, 512, 768 or 1024");                 \
   }
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void ln_part_reduce_kernel(const float* __rest
 // like ETP_SKIP_WGRAD in planner.hip.
 static bool skip_ln(const char* what) {
 #ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
-  static const char* e = getenv("ETP_SKIP_LN");
+  const char* e = opt_str(OPT_SKIP_LN);
   return e && strstr(e, what) != nullptr;
 #else
   (void)what;
@@ -326,8 +326,8 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
   ETP_REQUIRE(M > 0 && H % 256 == 0 && (y || yt), "bad arguments");
   if (skip_ln("fwd")) return ETP_OK;
   const int grid = (int)std::min<long>((M + 3) / 4, 4096);
-  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_fwd_s_kernel, bf16_t, grid, x, gamma, beta, y, (bf16_t*)yt, stats, M, eps) }
-  else { ETP_LN_DISPATCH(ln_fwd_s_kernel, float, grid, x, gamma, beta, y, (float*)yt, stats, M, eps) }
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ROWF_LN_FWD, ln_fwd_s_kernel, bf16_t, grid, x, gamma, beta, y, (bf16_t*)yt, stats, M, eps) }
+  else { ETP_LN_DISPATCH(ROWF_LN_FWD, ln_fwd_s_kernel, float, grid, x, gamma, beta, y, (float*)yt, stats, M, eps) }
   ETP_CHECK_LAUNCH("ln_fwd_s");
   return ETP_OK;
 }
@@ -335,7 +335,7 @@ int ln_fwd_s(int dtype, const float* x, const float* gamma, const float* beta, f
 // of rows, at most LN_BWD_MAX_BLOCKS blocks (one row per wavefront up to 4096 rows: 640 blocks at M = 2560; round 4, was 512 / two rows per wavefront)
 static int ln_bwd_blocks(int M) {
   const int groups = (M + 3) / 4;
-  static const int cap = [] { const char* e = getenv("ETP_LNBWD_GRID"); return e ? std::max(1, atoi(e)) : LN_BWD_MAX_BLOCKS; }();
+  const int cap = std::max(1, opt_int(OPT_LNBWD_GRID, LN_BWD_MAX_BLOCKS));
   const int rounds = (groups + cap - 1) / cap;
   return (groups + rounds - 1) / rounds;
 }
@@ -349,8 +349,8 @@ int ln_bwd_s(int dtype, const float* dy, const float* x, const float* stats, con
   // without a slab buffer the blocks flush 2*H atomics each: keep their number low (128, the round-1 setting)
   const int grid = part ? ln_bwd_blocks(M) : (int)std::min<long>((M + 3) / 4, 128);
   if (dgamma == nullptr) part = nullptr;
-  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, part, M, drop) }
-  else { ETP_LN_DISPATCH(ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, part, M, drop) }
+  if (dtype == ETP_BF16) { ETP_LN_DISPATCH(ROWF_LN_BWD, ln_bwd_s_kernel, bf16_t, grid, dy, x, stats, gamma, add, dx, (bf16_t*)dxt, dgamma, dbeta, part, M, drop) }
+  else { ETP_LN_DISPATCH(ROWF_LN_BWD, ln_bwd_s_kernel, float, grid, dy, x, stats, gamma, add, dx, (float*)dxt, dgamma, dbeta, part, M, drop) }
   ETP_CHECK_LAUNCH("ln_bwd_s");
   return ETP_OK;
 }

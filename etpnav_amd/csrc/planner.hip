@@ -387,7 +387,7 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
   // MEASUREMENT ONLY (tools/r03_call4.sh): ETP_SKIP_WGRAD=1 drops every weight-gradient product, i.e. leaves the dependent chain
   // alone on the GPU -- the step time then shows what the leaf work costs the chain (the gradients are wrong in that mode)
 #ifdef ETP_EXPERIMENTS       // measurement builds only (tools/build_variant.sh ... -DETP_EXPERIMENTS): never in the shipped library
-  static const bool skip = [] { const char* e = getenv("ETP_SKIP_WGRAD"); return e && e[0] == '1'; }();
+  const bool skip = opt_int(OPT_SKIP_WGRAD, 0) == 1;
   if (skip) return ETP_OK;
 #endif
   GemmArgs g = base_args();
@@ -396,7 +396,7 @@ static int linear_wgrad(const Ctx& c, const void* dY, long ldy, const void* X, l
   // matrix-region gradients may be first-touch stores (etp_planner_set_grad_overwrite); tables (the tied MLM decoder adds
   // into the word-embedding gradient) always accumulate
   const bool store = c.pl->grad_overwrite && c.pl->params[wi].region == 0;
-  static const bool group_on = [] { const char* e = getenv("ETP_WGRAD_GROUP"); return !(e && e[0] == '0'); }();
+  const bool group_on = opt_on(OPT_WGRAD_GROUP, true);
   if (c.wq && group_on && gemm_uses_dma(c.dt, M, 1)) {
     // grouped path: whole token reduction in one tile pass (no split-K: the group as a whole fills the chip), bias
     // gradient fused as column sums of the dY tile
@@ -592,7 +592,7 @@ static BwdWs plan_ws(Bump& b, int dt, long M, int Bn, int nh, int Lq, int ldS, i
 static int ln_bwd_chain(const Ctx& c, const float* dy, const float* x, const float* stats, int gi, int bi, const float* add,
                         float* dx, void* dxt, int M, const Drop& d, float* part) {
   etp_planner* pl = c.pl;
-  static const bool two_stage = [] { const char* e = getenv("ETP_LNBWD_TWO_STAGE"); return !(e && e[0] == '0'); }();
+  const bool two_stage = opt_on(OPT_LNBWD_TWO_STAGE, true);
   if (!two_stage) part = nullptr;
   ETP_TRY(ln_bwd_s(c.dt, dy, x, stats, pl->pf(gi), add, dx, dxt, pl->gf(gi), pl->gf(bi), M, c.H, c.st, d, part));
   if (!part) return ETP_OK;
@@ -873,7 +873,7 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // 4.06 / 4.06 ms; behind the whole FFN half (2): 4.14 against 4.10 (1) and 4.18 (0) on a second box.  Only where that dgrad IS one
     // resident round (at most 512 tiles of 128 x 128: configs 2 and 5): at config 4's 8192 rows it is three rounds anyway and holding
     // the leaf work back costs 1.4 % (10.77 against 10.62 ms).  ETP_FLUSH_DELAY=0 / 1 / 2 forces a mode.
-    static const int delay_env = [] { const char* e = getenv("ETP_FLUSH_DELAY"); return e ? atoi(e) : -1; }();
+    const int delay_env = opt_int(OPT_FLUSH_DELAY, -1);
     const int delay = delay_env >= 0 ? delay_env : (((long)(M / 128) * (c.I / 128) <= 512) ? 1 : 0);
     ETP_TRY(ffn_bwd(c, p->txt[l].ffn, t.att[l].y, t.ffn[l], M, g, wf, MODE_TXT, l, l == p->cfg.n_l - 1 ? dout : nullptr, delay));
     stamp_mark(c.st, 2200 + 10 * l + 1);
@@ -886,7 +886,7 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
     // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work
-    static const int every = [] { const char* e = getenv("ETP_FLUSH_EVERY"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+    const int every = std::max(1, opt_int(OPT_FLUSH_EVERY, 1));
     if (delay && l != layer_lo) continue;             // held back: goes out behind the next layer's FFN dgrad
     if (every == 1 || (layer_hi - 1 - l) % every == every - 1 || l == layer_lo) ETP_TRY(flush_side(c));
   }

@@ -44,6 +44,15 @@ typedef void* etp_stream_t; /* hipStream_t */
 const char* etp_version(void);
 const char* etp_last_error(void);
 
+/* Run-time switches of the library (tile-class forcing for tests and A/B runs, schedule variants).  They are read from the
+ * environment ONCE, at the first lookup (ETP_<NAME>), and afterwards change only through these calls -- no launch path calls
+ * getenv (rounds 1-5 did, three times per GEMM launch).  `name` with or without the ETP_ prefix; value NULL or "" = unset.
+ * The reference has no counterpart (its switches are Python config keys, vlnce_baselines/config/default.py); the names are listed
+ * in csrc/options.h and every line bench.py prints carries the ones that are set (config.env_overrides). */
+int etp_option_set(const char* name, const char* value);
+int etp_option_get(const char* name, char* out, int cap);   /* length of the value (0 = unset), -1 = unknown switch */
+int etp_option_list(char* out, int cap);                     /* "NAME=value\n" per set switch; returns the length needed */
+
 /* ------------------------------------------------------------------------------------------------------
  * Per-operator entry points (one per implicit device op of SURVEY.md §2.1)
  * ---------------------------------------------------------------------------------------------------- */

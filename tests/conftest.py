@@ -20,3 +20,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def etp_opt():
+    """etp_opt(name, value): set a switch of the library (csrc/options.h) for the rest of the test; restored afterwards.  (Rounds
+    1-5 used monkeypatch.setenv: the library called getenv on every launch.  It reads the environment once now.)"""
+    from etpnav_amd import _lib
+    saved = {}
+
+    def setter(name, value):
+        name = name[4:] if name.startswith("ETP_") else name
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    yield setter
+    for name, old in saved.items():
+        _lib.set_option(name, old)

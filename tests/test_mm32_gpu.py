@@ -43,9 +43,9 @@ def btol(K):
 @pytest.mark.parametrize("cls", ["128", "64"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("K", [128, 192, 256, 320, 384, 768])
-def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, monkeypatch):
+def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, etp_opt):
     """Plain products (fp32 and bf16 C), reductions of 2, 3, 5 and 12 slabs: ring fill / drain paths of both ring depths."""
-    monkeypatch.setenv("ETP_MM32", cls)
+    etp_opt("ETP_MM32", cls)
     M, N = (384, 256) if cls == "128" else (256, 192)
     As, Bs, ref = operands(M, N, K, ta, tb, 11 * K + ta + 2 * tb)
     C = torch.full((M, N), float("nan"), device=DEV)
@@ -61,10 +61,10 @@ def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, monkeypatch):
 
 @pytest.mark.parametrize("cls", ["128", "64"])
 @pytest.mark.parametrize("tb", [0, 1])
-def test_mm32_epilogues(cls, tb, monkeypatch):
+def test_mm32_epilogues(cls, tb, etp_opt):
     """bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU / ReLU backward, ReLU, accumulate,
     alpha -- the epilogues of linear_fwd / linear_fwd_s / linear_dgrad(_s) in planner.hip."""
-    monkeypatch.setenv("ETP_MM32", cls)
+    etp_opt("ETP_MM32", cls)
     M, N, K = (512, 384, 256) if cls == "128" else (384, 320, 192)
     As, Bs, raw = operands(M, N, K, 0, tb, 5 + tb)
     bias = torch.randn(N, device=DEV)
@@ -102,14 +102,14 @@ def test_mm32_epilogues(cls, tb, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(2560, 2304, 768, 0, 0), (2560, 3072, 768, 0, 1), (2560, 768, 3072, 0, 0), (2560, 768, 2304, 0, 1),
                                    (3072, 768, 2560, 1, 1), (2304, 3072, 256, 1, 1), (1152, 3072, 768, 0, 0)])
-def test_mm32_planner_shapes_agree_with_the_16x16_kernels(shape, monkeypatch):
+def test_mm32_planner_shapes_agree_with_the_16x16_kernels(shape, etp_opt):
     """The text-layer products of configuration 2 at their real extents through the DEFAULT class choice: the new family
     against gemm.hip's kernels on the same operands (fp32 C: same products, different summation order)."""
     M, N, K, ta, tb = shape
     As, Bs, ref = operands(M, N, K, ta, tb, M + N + K)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("ETP_MM32", mode)
+        etp_opt("ETP_MM32", mode)
         C = torch.full((M, N), float("nan"), device=DEV)
         run_gemm(As, Bs, C, M, N, K, ta, tb, BF, c_dtype=F32)
         out[mode] = C
@@ -138,10 +138,10 @@ def wgrad_desc(dY, X, dW, db, out_mode):
 
 
 @pytest.mark.parametrize("mode", ["1", "0"])
-def test_mm32_grouped_text_layer_weight_gradients(mode, monkeypatch):
+def test_mm32_grouped_text_layer_weight_gradients(mode, etp_opt):
     """The four weight gradients of one text layer (M = 2560 tokens) as ONE grid with the fused bias gradients (column sums of
     dY): stores and accumulates, against fp32 torch; mode 0 runs the same call through gemm.hip's grouped kernel."""
-    monkeypatch.setenv("ETP_MM32", mode)
+    etp_opt("ETP_MM32", mode)
     torch.manual_seed(3)
     Mt, H, I = 2560, 768, 3072
     specs = [(3 * H, H), (H, H), (I, H), (H, I)]                        # (out features N, in features K) of qkv, out, ffn-up, ffn-down
@@ -163,7 +163,7 @@ def test_mm32_grouped_text_layer_weight_gradients(mode, monkeypatch):
 
 
 @pytest.mark.parametrize("Mt", [128, 192, 320, 1152, 2560])
-def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, monkeypatch):
+def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, etp_opt):
     """The 256x128 class of the grouped weight gradient (128x64 per wavefront, one workgroup per CU, ring of three slabs), forced
     for every token count: reductions of 2 .. 40 slabs, stores and accumulates, fused bias gradients, against fp32 torch and --
     bit for bit across three runs and within fp32 summation-order noise -- against the 128x128 class."""
@@ -174,7 +174,7 @@ def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, monkeypatch):
     Xs = [torch.randn(Mt, k, device=DEV).to(T) for _, k in specs]
     out = {}
     for cls in ("256", "128"):
-        monkeypatch.setenv("ETP_MM32_GROUP", cls)
+        etp_opt("ETP_MM32_GROUP", cls)
         for out_mode in (0, 1):
             first = None
             for it in range(3 if cls == "256" else 1):
@@ -201,11 +201,11 @@ def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, monkeypatch):
 
 
 @pytest.mark.parametrize("cls", ["128", "64"])
-def test_mm32_race_screen_under_uneven_load(cls, monkeypatch):
+def test_mm32_race_screen_under_uneven_load(cls, etp_opt):
     """12 runs of the same products while a bandwidth-heavy copy loop on a second stream perturbs the DMA timing on every other
     run: outputs must be bit-identical across runs (a stale or early LDS read shows as a run that differs) and match the
     reference.  Reductions of 2, 3, 5 and 24 slabs; NT, NN and TN."""
-    monkeypatch.setenv("ETP_MM32", cls)
+    etp_opt("ETP_MM32", cls)
     side = torch.cuda.Stream()
     noise_a = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
     noise_b = torch.empty_like(noise_a)

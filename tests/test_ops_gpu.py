@@ -133,12 +133,12 @@ def test_gemm_epilogues(dtype):
 
 @pytest.mark.parametrize("tile", ["256s2", "256s3", "128s2", "128s3", "ws4", "ws3", "64s3", "64s4"])
 @pytest.mark.parametrize("tb", [0, 1])
-def test_gemm_tile_classes_with_epilogues(tile, tb, monkeypatch):
+def test_gemm_tile_classes_with_epilogues(tile, tb, etp_opt):
     """Every LDS-DMA tile class of round 3 -- 256x128 (eight wavefronts), 128x128, 128x64 and 64x64 (four), each with its ring
     depths -- forced through ETP_GEMM_TILE on ragged shapes (partial tiles in both directions, reductions shorter and longer
     than the ring), NT and NN storage, with the epilogues the planner uses:
     bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU backward, dropout."""
-    monkeypatch.setenv("ETP_GEMM_TILE", tile)
+    etp_opt("ETP_GEMM_TILE", tile)
     dtype, t = _lib.ETP_BF16, torch.bfloat16
     for (M, N, K) in [(300, 200, 128), (130, 72, 192), (257, 136, 768), (64, 64, 1024), (520, 392, 256)]:
         torch.manual_seed(M + N + K + tb)
@@ -164,13 +164,13 @@ def test_gemm_tile_classes_with_epilogues(tile, tb, monkeypatch):
 
 
 @pytest.mark.parametrize("tile", ["64s3", "64s4", "ws2", "ws3", "ws4", "128s2", "128s3", "256s2", "256s3"])
-def test_gemm_race_screen_under_uneven_load(tile, monkeypatch):
+def test_gemm_race_screen_under_uneven_load(tile, etp_opt):
     """The round-3 main loop changed the synchronisation structure (one barrier BETWEEN a slab's k-steps, the whole ring in
     flight, counted vmcnt): cdna_hip_programming.md asks for a multi-run race screen of such edits, under UNEVEN load.  Every
     tile class / ring depth runs the same products 12 times while a bandwidth-heavy copy loop on a second stream perturbs the
     DMA timing; a stale or early LDS read would show as a run that differs from the others.  Outputs must be bit-identical
     across runs and match the fp32 reference; reductions of 2, 3, 5 and 24 slabs cover the ring's fill / drain paths."""
-    monkeypatch.setenv("ETP_GEMM_TILE", tile)
+    etp_opt("ETP_GEMM_TILE", tile)
     dtype, t = _lib.ETP_BF16, torch.bfloat16
     side = torch.cuda.Stream()
     noise_a = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
@@ -484,10 +484,10 @@ def _desc(A, B, C, M, N, K, ta, tb, dtype, c_dtype, out_mode=0):
 
 @pytest.mark.parametrize("dtype", [_lib.ETP_F32, _lib.ETP_BF16])
 @pytest.mark.parametrize("tile", ["", "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"])
-def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
+def test_gemm_group_weight_gradients(dtype, tile, etp_opt):
     """Seven TN products of different shapes / reduction lengths (an x-layer's weight gradients: token counts 512 and 2560,
     ragged 200-wide output) in ONE grid == the same products one by one; store and accumulate modes; every tile class."""
-    monkeypatch.setenv("ETP_GROUP_TILE", tile)
+    etp_opt("ETP_GROUP_TILE", tile)
     torch.manual_seed(3)
     t = tdt(dtype)
     shapes = [(768, 768, 512), (1536, 768, 2560), (768, 768, 512), (2304, 768, 512), (200, 136, 512), (3072, 768, 512),
@@ -512,10 +512,10 @@ def test_gemm_group_weight_gradients(dtype, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("tile", ["", "256s2", "256s3", "128s2"])
-def test_gemm_group_text_layer_weight_gradients_large_tiles(tile, monkeypatch):
+def test_gemm_group_text_layer_weight_gradients_large_tiles(tile, etp_opt):
     """The four weight gradients of a text layer (the dominant launch of a step) as ONE grouped grid with every tile class
     that fits them -- 256x128 tiles make it 216 workgroups, one per CU -- against fp32 matmuls; tokens = 640 (10 slabs)."""
-    monkeypatch.setenv("ETP_GROUP_TILE", tile)
+    etp_opt("ETP_GROUP_TILE", tile)
     torch.manual_seed(5)
     dtype, t = _lib.ETP_BF16, torch.bfloat16
     shapes = [(2304, 768, 640), (768, 768, 640), (3072, 768, 640), (768, 3072, 640)]

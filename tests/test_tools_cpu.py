@@ -112,16 +112,40 @@ def test_lds_dma_m0_discipline_scanner():
     assert nk > 50 and ni > 1000 and not m0bad, m0bad[:5]
 
 
-def test_forcing_a_gemm_tile_class_switches_the_mm32_family_off(monkeypatch):
+def test_forcing_a_gemm_tile_class_switches_the_mm32_family_off():
     """_lib.force_gemm_tile: mm32_class is consulted before gemm.hip's tile choice, so a forced gemm.hip class must come
-    with ETP_MM32=0 or eligible bf16 products keep running the mm32 kernel; "auto" hands both choices back to the library."""
+    with MM32=0 or eligible bf16 products keep running the mm32 kernel; "auto" hands both choices back to the library.  Round 6: the
+    switches live in the library's own table (csrc/options.h, `etp_option_set`), not in os.environ."""
     from etpnav_amd import _lib
-    monkeypatch.setenv("ETP_GEMM_TILE", "")
-    monkeypatch.delenv("ETP_MM32", raising=False)
-    _lib.force_gemm_tile("64s3")
-    assert os.environ["ETP_GEMM_TILE"] == "64s3" and os.environ["ETP_MM32"] == "0"
-    _lib.force_gemm_tile("auto")
-    assert os.environ["ETP_GEMM_TILE"] == "" and "ETP_MM32" not in os.environ
+    old = {k: _lib.get_option(k) for k in ("GEMM_TILE", "MM32")}
+    try:
+        _lib.set_option("GEMM_TILE", None); _lib.set_option("MM32", None)
+        _lib.force_gemm_tile("64s3")
+        assert _lib.get_option("GEMM_TILE") == "64s3" and _lib.get_option("MM32") == "0"
+        assert _lib.options()["GEMM_TILE"] == "64s3"
+        _lib.force_gemm_tile("auto")
+        assert _lib.get_option("GEMM_TILE") is None and _lib.get_option("MM32") is None
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+
+
+def test_library_switch_table_rejects_unknown_names_and_restores():
+    """etp_option_set / etp_option_get (include/etpnav_hip.h): unknown names are an error, the ETP_ prefix is optional, values are
+    truncated to 31 characters, `with _lib.option(...)` restores the previous value."""
+    import pytest
+    from etpnav_amd import _lib
+    with pytest.raises(_lib.EtpError):
+        _lib.set_option("NO_SUCH_SWITCH", "1")
+    with pytest.raises(_lib.EtpError):
+        _lib.get_option("NO_SUCH_SWITCH")
+    before = _lib.get_option("MM32_GROUP")
+    with _lib.option("ETP_MM32_GROUP", 256):
+        assert _lib.get_option("MM32_GROUP") == "256"
+        with _lib.option("MM32_GROUP", "x" * 100):
+            assert _lib.get_option("MM32_GROUP") == "x" * 31
+        assert _lib.get_option("MM32_GROUP") == "256"
+    assert _lib.get_option("MM32_GROUP") == before
 
 
 def test_bench_cpu_baseline_leg_measures_the_full_batch_when_it_fits():

@@ -7,6 +7,6 @@ from tools.mm32_probe import group_time
 out = {}
 for Mt in (2560, 1152, 512, 8192):
     for cls in ("128", "256"):
-        os.environ["ETP_MM32_GROUP"] = cls
+        _lib.set_option("MM32_GROUP", cls)
         out[f"tokens{Mt}:{cls}"] = round(group_time(Mt=Mt, iters=24), 2)
 print(json.dumps(out, indent=1))

@@ -79,7 +79,7 @@ if __name__ == "__main__" and not os.environ.get("GEMM_GROUP_ONLY"):
 def run_group(tokens, shapes, tile, iters=20, nsets=4, store=True):
     """One grouped TN launch (etp_gemm_group) over `shapes` = [(N_out, K_in)] with `tokens` rows; nsets rotating operand sets
     keep the operands L2-cold (MALL-warm), like a real backward pass where every dY was just written by another kernel."""
-    os.environ["ETP_GROUP_TILE"] = tile
+    _lib.set_option("GROUP_TILE", tile)
     t = torch.bfloat16
     sets = []
     for _ in range(nsets):
