@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     // mask byte of this 64-element block: bit 0 = weight decay applies, bit 1 = FROZEN (requires_grad = False:
     // vilmodel_cmt.py:675-682 fix_lang_embedding / fix_pano_embedding) -- p / m / v / shadow are left alone, the gradient is
     // still zeroed
-    const uint8_t mb = decay_mask == nullptr ? (uint8_t)1 : decay_mask[e0 >> 6];
+    // Values (header changelog): 0 no decay, 1 decay, 2 frozen, 3 frozen (decay bit irrelevant); every OTHER non-zero
+    // byte keeps the pre-round-5 meaning "decay" (callers that pass 0xFF / true-as-255), never "frozen"
+    const uint8_t mraw = decay_mask == nullptr ? (uint8_t)1 : decay_mask[e0 >> 6];
+    const uint8_t mb = mraw > 3 ? (uint8_t)1 : mraw;
     if (!skipped && !(mb & 2)) {
       float4 pv = ntload(p + e0);
       float4 mv = ntload(m + e0);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   int nf = 0;
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    if (mask != nullptr && (mask[(i * 4) >> 6] & 2)) continue;      // frozen block: no .grad in the reference, not in the norm
+    if (mask != nullptr && (mask[(i * 4) >> 6] == 2 || mask[(i * 4) >> 6] == 3)) continue;      // frozen block: no .grad in the reference, not in the norm
     const float4 x = *reinterpret_cast<const float4*>(g + i * 4);
     s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     nf += !isfinite(x.x) + !isfinite(x.y) + !isfinite(x.z) + !isfinite(x.w);

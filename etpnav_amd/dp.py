@@ -432,10 +432,16 @@ def planner_buckets_layered(model, text_groups: int = 3):
     if frozen:
         head = subtract_spans(ranges[:1], frozen) if first_non_text < eng.n_matrix else []
         if first_non_text < eng.n_matrix and len(head) != 1:
-            # bucket 0 must stay ONE range (its index is part of the step's announcement protocol): take the hull of what is left;
-            # the frozen gaps inside it hold zeros on every rank (never written), so reducing them is harmless
+            # bucket 0 must stay ONE range (its index is part of the step's announcement protocol): take the hull of what is left.
+            # The frozen gaps inside the hull are reduced along with it: slots the backward never writes hold the zeros the arena
+            # was allocated with; slots it does write although their parameter is frozen (fix_pano_embedding alone: the panorama
+            # backward still produces the img_embeddings.* gradients on its way to token_type_embeddings(1)) carry real values.
+            # Either way the optimizer's frozen bit drops them (etp_adamw_step mask values 2 / 3) -- wasted bytes, never an update.
             head = [(head[0][0], head[-1][1])] if head else [(first_non_text, first_non_text)]
-        ranges = head + ranges[1:] + subtract_spans(tail, frozen)
+        # `ranges[0]` is the non-text bucket only when there is one (first_non_text < n_matrix); without it the list starts with
+        # text group 0, which must stay (the slice used to drop it)
+        rest = ranges[1:] if first_non_text < eng.n_matrix else ranges
+        ranges = head + rest + subtract_spans(tail, frozen)
         if subtract_spans([(word_off, word_end)], frozen) == []:
             word = None
         return ranges, word, groups

@@ -30,6 +30,35 @@ SIGNATURE = b"\x89HDF\r\n\x1a\n"
 UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
+
+def fletcher32(data: bytes) -> int:
+    """H5_checksum_fletcher32 (HDF5 H5checksum.c): two running sums over BIG-endian 16-bit words, each folded with end-around carry
+    (x = (x & 0xffff) + (x >> 16)), an odd trailing byte counted as its high half; result (sum2 << 16) | sum1.  Vectorised: with
+    the fold the sums are residues modulo 65535 in which a non-zero multiple of 65535 reads 0xffff, so
+    sum1 = fold(sum w_i), sum2 = fold(sum (n - i) w_i)."""
+    n = len(data)
+    w = np.frombuffer(data[:n - (n & 1)], dtype=">u2").astype(np.uint64)
+    if n & 1:
+        w = np.concatenate([w, np.array([data[-1] << 8], dtype=np.uint64)])
+    m = w.size
+    if m == 0:
+        return 0
+    # sum2 = sum (m - i) w_i.  Reducing a weight modulo 65535 does not change the residue; whether the folded value reads 0 or
+    # 0xffff depends only on whether the exact sum is zero, i.e. whether any word is non-zero (all terms are non-negative)
+    wt = np.arange(m, 0, -1, dtype=np.uint64) % np.uint64(65535)
+    s1 = int(w.sum())
+    s2 = 0
+    for a in range(0, m, 1 << 20):                                    # products < 2^32, 2^20 per block: exact in uint64
+        s2 += int((w[a:a + (1 << 20)] * wt[a:a + (1 << 20)]).sum())
+    nonzero = s1 != 0
+
+    def fold(x: int) -> int:
+        r = x % 65535
+        return r if r else (65535 if nonzero else 0)
+
+    return (fold(s2) << 16) | fold(s1)
+
+
 class Hdf5Unsupported(ValueError):
     pass
 
@@ -84,10 +113,23 @@ class Dataset:
                     m = a.size // es
                     raw = a[:m * es].reshape(es, m).T.tobytes() + a[m * es:].tobytes()
                 elif fid == 3:                                        # fletcher32: checksum in the last four bytes
+                    if len(raw) < 4:
+                        raise Hdf5Unsupported(f"{self.name}: chunk at {addr} is shorter than its fletcher32 checksum")
+                    stored = int.from_bytes(raw[-4:], "little")
                     raw = raw[:-4]
+                    want = fletcher32(raw)
+                    # H5Zfletcher32.c also accepts the byte-swapped form of each half (files written by libraries <= 1.6.2)
+                    swapped = ((want & 0x00ff00ff) << 8) | ((want >> 8) & 0x00ff00ff)
+                    if stored not in (want, swapped):
+                        raise Hdf5Unsupported(f"{self.name}: fletcher32 mismatch in the chunk at {addr} "
+                                              f"(stored {stored:#010x}, computed {want:#010x}): corrupted file")
                 else:
                     raise Hdf5Unsupported(f"{self.name}: filter id {fid} is not supported (deflate, shuffle, fletcher32 are)")
-            chunk = np.frombuffer(raw[:int(np.prod(cdims)) * self.dtype.itemsize], dtype=self.dtype).reshape(cdims)
+            want_bytes = int(np.prod(cdims)) * self.dtype.itemsize
+            if len(raw) != want_bytes:                                # a damaged chunk that still inflates
+                raise Hdf5Unsupported(f"{self.name}: chunk at {addr} decodes to {len(raw)} bytes, its shape {tuple(cdims)} needs "
+                                      f"{want_bytes}: corrupted file")
+            chunk = np.frombuffer(raw, dtype=self.dtype).reshape(cdims)
             sel_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, self.shape))
             sel_in = tuple(slice(0, so.stop - so.start) for so in sel_out)
             out[sel_out] = chunk[sel_in]
@@ -181,6 +223,8 @@ class File:
         return self.buf[a:a + n]
 
     def _u(self, pos: int, n: int) -> int:
+        if pos < 0 or pos + n > len(self.buf):                      # a slice past EOF would decode fewer bytes into a wrong value
+            raise Hdf5Unsupported(f"{self.path}: truncated file (wanted {n} bytes at {pos})")
         return int.from_bytes(self.buf[pos:pos + n], "little")
 
     def _find_superblock(self) -> int:

@@ -528,7 +528,13 @@ class GlocalTextPathNavCMT(nn.Module):
         # fix_pano_embedding AND fix_lang_embedding: nothing behind this branch requires a gradient (token_type_embeddings(1),
         # :706-708, is frozen with the language side), so unless the features do, autograd must not enter it
         c = self.config
-        live = rgb_fts.requires_grad or not (_cfg_get(c, "fix_pano_embedding", False) and _cfg_get(c, "fix_lang_embedding", False))
+        if any(t is not None and t.requires_grad for t in (dep_fts, loc_fts)):
+            # the explicit backward produces d rgb_fts only (etp_pano_bwd); the reference feeds precomputed depth / angle features
+            # that never require a gradient (ss_trainer_ETP.py:836-839).  Refuse instead of returning None silently.
+            raise NotImplementedError("forward_panorama: gradients w.r.t. dep_fts / loc_fts are not provided by etp_pano_bwd "
+                                      "(only d rgb_fts); detach them")
+        feats_live = rgb_fts.requires_grad
+        live = feats_live or not (_cfg_get(c, "fix_pano_embedding", False) and _cfg_get(c, "fix_lang_embedding", False))
         anchor = self._anchor if live else self._anchor.detach()
         return _PanoFn.apply(anchor, eng, self._dropout(), rgb_fts.float().contiguous(), dep, loc_fts.float().contiguous(),
                              nav_types.long().contiguous(), view_lens.long().contiguous())

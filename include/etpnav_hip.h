@@ -213,6 +213,9 @@ int etp_scale_f32(float* p, int64_t n, float scale, etp_stream_t stream);
  * (planner parameters start on 64-element boundaries, so any per-parameter grouping such as optim/misc.py:12-22 fits),
  * bit 1 = FROZEN block (requires_grad = False: fix_lang_embedding / fix_pano_embedding, vilmodel_cmt.py:675-682;
  * LanguageEncoder :422-424): p / m / v / shadow are left untouched, the gradient is still zeroed.
+ * CHANGELOG (round 5 -> 6): until round 4 the byte meant "any non-zero value = decay".  The byte values are now 0 = no decay,
+ * 1 = decay, 2 / 3 = frozen; every other non-zero value (0xFF, a bool stored as 255, ...) still means "decay" and never "frozen", so
+ * the only value whose meaning changed for an old caller is exactly 2.
  * shadow (nullable): bf16 copy written for elements [0, n_shadow).  skip (nullable, device int32): non-zero -> leave
  * p/m/v/shadow untouched (GradScaler's skipped step); gradients are still zeroed when zero_grads != 0.
  * sumsq / skip are produced by etp_grad_sqnorm (both ACCUMULATE: zero them first).  n % 4 == 0, 16-byte aligned. */

@@ -257,3 +257,16 @@ def test_hdf5_reader_maps_the_file_travels_by_path_and_fails_loudly_on_damage(tm
     open(str(tmp_path / "bad.hdf5"), "wb").write(bytes(bad))
     with pytest.raises((zlib.error, ValueError)):
         hdf5_lite.File(str(tmp_path / "bad.hdf5"))["scanW_vp0"]
+    # a chunk that still inflates but whose payload changed: the fletcher32 filter of `extra_shuffled` must catch it (the
+    # checksum used to be stripped unverified).  The reader's checksum is the library's own: the undamaged golden file passes it.
+    ds = f.dataset("extra_shuffled")
+    assert [fid for fid, _ in ds.filters][-1] == 3
+    size, mask, offs, addr = next(iter(f._chunks(ds.layout[1], 2)))
+    a = f.base_addr + addr
+    assert hdf5_lite.fletcher32(raw[a:a + size - 4]) == int.from_bytes(raw[a + size - 4:a + size], "little")
+    bad = bytearray(raw)
+    bad[a + size - 1] ^= 0x10                                       # one bit of the stored checksum
+    open(str(tmp_path / "sum.hdf5"), "wb").write(bytes(bad))
+    with pytest.raises(hdf5_lite.Hdf5Unsupported, match="fletcher32 mismatch"):
+        hdf5_lite.File(str(tmp_path / "sum.hdf5"))["extra_shuffled"]
+    assert hdf5_lite.fletcher32(b"") == 0 and hdf5_lite.fletcher32(b"\x01") == 0x01000100 and hdf5_lite.fletcher32(b"\xff\xff") == 0xffffffff
