@@ -337,10 +337,12 @@ def main():
     comm_info = None
 
     def exposed_ms_of(red):
-        """mean device-side wait (ms, max over ranks) of the main stream for the reduction `red`, 6 steps after 2 unrecorded ones"""
+        """mean device-side wait (ms, max over ranks) of the main stream for the reduction `red`: 6 steps after 2 unrecorded ones
+        (gloo -- functional tests only, every step moves the arena through the host -- 2 after 1)"""
         Lc = _lib.lib()
+        n_leg, n_skip = (8, 2) if args.dist_backend == "nccl" else (3, 1)
         stamps = torch.zeros(2 * 8, dtype=torch.int64, device=f"cuda:{local_rank}")
-        for k in range(8):
+        for k in range(n_leg):
             if use_graph:
                 one_step()
                 continue
@@ -355,7 +357,7 @@ def main():
         barrier()
         st = stamps.cpu().view(8, 2)
         exposed = [(int(b) - int(a)) * 1e-5 for a, b in st.tolist() if a and b]            # 100 MHz ticks -> ms
-        t = torch.tensor([sum(exposed[2:]) / max(len(exposed[2:]), 1) if exposed else -1.0], device="cuda", dtype=torch.float64)
+        t = torch.tensor([sum(exposed[n_skip:]) / max(len(exposed[n_skip:]), 1) if exposed else -1.0], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return round(float(t.item()), 4)
 

@@ -23,6 +23,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
          "-Wno-return-type-c-linkage"]
 
 
+# Row kernels (everything that is not a GEMM / attention tile kernel) are compiled WITHOUT the SLP vectorizer, i.e. without packed-fp32
+# VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Round 6 (profiles/r06_neighbour_bisect.txt): the
+# panorama-embedding backward returned different results in 24 of 24 repetitions whenever wavefronts of a 128x128-tile GEMM shared its CU;
+# the same source compiled with -fno-slp-vectorize: 0 of 24, with unchanged register counts.  These kernels are HBM- / latency-bound: the
+# packed forms bought nothing measurable.  tools/kernel_resources.py::pk_audit fails the build if one of these objects contains a packed
+# fp32 instruction again.
+NO_PACKED_FP32 = ["embed.hip", "norm.hip", "optim.hip", "graph.hip"]
+PER_SOURCE_FLAGS = {s: ["-fno-slp-vectorize", "-fno-vectorize"] for s in NO_PACKED_FP32}
+
+
 def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
@@ -44,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         srcp = os.path.join(CSRC, src)
         if not force and _mtime(obj) >= max(_mtime(srcp), hdr_t):
             return obj
-        cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *PER_SOURCE_FLAGS.get(src, []), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -81,6 +91,19 @@ def audit_resources(verbose: bool = True):
     if bad:
         raise RuntimeError("kernel resource policy violated (tools/kernel_resources.py):\n" +
                            "\n".join(f"  {r['src']}: {r['full']}: {r['violation']}" for r in bad))
+    npk = kr.pk_audit([s.replace(".hip", ".o") for s in NO_PACKED_FP32])
+    if verbose:
+        print(f"packed-fp32 audit: {sum(npk.values())} v_pk_*_f32 instructions in {', '.join(NO_PACKED_FP32)} (allowed: {kr.PK_ALLOW} per "
+              f"object)", flush=True)
+    over = {k: v for k, v in npk.items() if v > kr.PK_ALLOW}
+    if over:
+        raise RuntimeError(f"packed fp32 instructions in row-kernel objects (build.py NO_PACKED_FP32; DESIGN.md §3.6): {over}")
+    sel = {k: v for k, v in kr.pk_opsel_audit().items() if v}
+    if verbose:
+        print(f"packed-fp32 op_sel audit: {sum(sel.values())} instructions with a low-half operand select in the library "
+              f"(v_pk_*_f32 ... op_sel:[.,1]: wrong results beside another kernel's MFMAs, profiles/r06_pk_opsel_repro.txt)", flush=True)
+    if sel:
+        raise RuntimeError(f"packed fp32 instructions with op_sel low-half selects (DESIGN.md §3.6): {sel}")
     # the LDS-DMA statements write M0 behind the compiler's back: check the ISA it produced around them
     nk, ni, m0bad = kr.m0_audit()
     if verbose:

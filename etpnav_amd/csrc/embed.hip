@@ -229,17 +229,22 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
 //   a = rgb.Wi^T + bi and d = dep.Wd^T + bd come from the MFMA GEMM; the K=4 angle projection is done here.
 //   stats[row] = {mean,rstd} x {a, d, loc-proj, sum}
 // --------------------------------------------------------------------------------------
-template <int NCH> __device__ __forceinline__ void loc_project(Row<NCH>& t, const float* loc4, const float* w_loc,
-                                                               const float* bias_loc, int lane) {
+// CHUNKWISE: a scheduling fence behind every 256-column chunk keeps only that chunk's 4 x float4 of w_loc in flight (the backward
+// launches carry up to six accumulator rows: with all twelve float4 hoisted to the front the PART 2 launch spilled two registers once
+// the packed-fp32 forms were gone, round 6)
+template <int NCH, bool CHUNKWISE = false>
+__device__ __forceinline__ void loc_project(Row<NCH>& t, const float* loc4, const float* w_loc, const float* bias_loc, int lane) {
   const float l0 = loc4[0], l1 = loc4[1], l2 = loc4[2], l3 = loc4[3];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int c = 0; c < NCH; ++c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int col = c * 256 + lane * 4 + e;
       const float4 w = *reinterpret_cast<const float4*>(w_loc + col * 4);
       t.v[c][e] = bias_loc[col] + l0 * w.x + l1 * w.y + l2 * w.z + l3 * w.w;
     }
+    if constexpr (CHUNKWISE) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <typename T, int NCH>
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void pano_embed_bwd_kernel(const float* __r
       row_affine<NCH>(t, x, p.g_dep, p.b_dep, lane);
       row_add<NCH>(e, t);
     }
-    loc_project<NCH>(x, loc + (long)row * 4, p.w_loc, p.bias_loc, lane);
+    loc_project<NCH, PART == 2>(x, loc + (long)row * 4, p.w_loc, p.bias_loc, lane);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll

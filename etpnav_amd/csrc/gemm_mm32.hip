@@ -160,28 +160,42 @@ template <int FM, int FN> struct Frags { bf16x8_t a[FM], b[FN]; };
 // wavefronts' own read + MFMA stream, not the DMA, sets most of the loop time.  A 128x64 wavefront tile reads 6 KiB for
 // 8 MFMAs (96 B/clk per CU) and the 256x128 tile moves 25 % fewer L2 bytes per FLOP, but its single wavefront per SIMD
 // exposes every LDS latency: it only wins on reductions of >= 4096 rows (mm32_group_class below).
-template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+//
+// KS = 2 (round 6): INTRA-WORKGROUP split of the reduction.  Eight wavefronts; wave group 0 (waves 0-3) reduces the
+// first half of K, wave group 1 (waves 4-7) the second half of the SAME output tile, each through its own ring, and the two fp32
+// accumulator tiles meet in LDS in the epilogue (no atomics, no workspace, no second launch).  For the grids that are one workgroup
+// per CU (the 240-tile N = 768 products of the 2560 text rows) this puts a second wavefront on every SIMD and doubles the slabs in
+// flight: those loops were latency-bound at one wavefront per SIMD (0.41 us per 24.6-KB slab = 60 GB/s per CU, MFMA busy 12.6 %,
+// profiles/r05_gemm_phases.txt / r05_gemm_counters.txt).  Both groups run the same number of hand-overs, so the workgroup-wide
+// s_barrier of the loop stays matched (K % 128 == 0, K / 2 >= 128).
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES, int KS = 1>
 __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const bf16_t* B, TC* C, int tm, int tn, char* smem, int rec) {
   using GA = Op<TA, BM>;
   using GB = Op<TB, BN>;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
+  constexpr int NTH = 256 * KS;
+  static_assert(KS == 1 || (KS == 2 && !TA), "the split-reduction tile is for the row-major-A chain products");
   constexpr int NPA = GA::NPW, NPB = GB::NPW, NP = NPA + NPB;          // DMA pieces per wavefront per slab
   constexpr int NMMA = FM * FN;                                        // MFMAs per k16-step
   static_assert((FM == 2 && (FN == 1 || FN == 2)) || (FM == 4 && FN == 2), "wavefront tiles: 64x64, 64x32 or 128x64");
   static_assert(STAGES == 2 || STAGES == 3, "ring of two or three slabs");
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kgrp = KS == 2 ? (wave_all >> 2) : 0;                       // which half of the reduction this wave group owns
+  const int wave = wave_all & 3;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = tm * BM, n0 = tn * BN;
   PhaseProbe probe;
   probe_begin(probe, g);
-  const int nk = g.K >> 6;                                              // host guarantees K % 64 == 0, K >= 128
+  const int nk = (g.K >> 6) / KS;                                       // host guarantees K % (64 KS) == 0, K / KS >= 128
+  const int k0 = kgrp * nk * 64;
 
-  DmaOp da = dma_setup<TA, BM>(A, g.lda, m0, 0, wave, lane);
-  DmaOp db = dma_setup<TB, BN>(B, g.ldb, n0, 0, wave, lane);
-  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  DmaOp da = dma_setup<TA, BM>(A, g.lda, m0, k0, wave, lane);
+  DmaOp db = dma_setup<TB, BN>(B, g.ldb, n0, k0, wave, lane);
+  const unsigned lds_wg = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned lds0 = lds_wg + (unsigned)(kgrp * STAGES * STAGE);     // this wave group's ring
   const unsigned piece0 = lds0 + (unsigned)wave * 1024u;                // LDS address of this wavefront's piece 0 in ring slot 0
 
   // piece i (0 .. NP-1) of the slab the DMA plans currently point at, into ring slot `slot`
@@ -209,14 +223,20 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  EpiPre<bf16_t, TC, BM, BN, 256> pre;
-  pre.valid = false;
-  pre.bias_valid = false;
-  if (g.vec_epilogue && g.bias != nullptr) {                            // the thread's 8 bias values travel under the reduction
-    const int colc = n0 + (tid % (BN / 8)) * 8;
-    pre.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
-    pre.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
-    pre.bias_valid = true;
+  EpiPre<bf16_t, TC, BM, BN, NTH> pre;
+  if constexpr (KS == 2) {
+    // 512 threads: two 8-column chunks per thread and 256 registers per wavefront -- residual / old C / activation operand and the
+    // bias are fetched now and travel under the reduction (the four-wavefront tiles fetch them behind it: no registers to spare)
+    epi_prefetch<bf16_t, TC, BM, BN, NTH>(pre, g, C, m0, n0, 0, tid);
+  } else {
+    pre.valid = false;
+    pre.bias_valid = false;
+    if (g.vec_epilogue && g.bias != nullptr) {                          // the thread's 8 bias values travel under the reduction
+      const int colc = n0 + (tid % (BN / 8)) * 8;
+      pre.b0 = *reinterpret_cast<const float4*>(g.bias + colc);
+      pre.b1 = *reinterpret_cast<const float4*>(g.bias + colc + 4);
+      pre.bias_valid = true;
+    }
   }
 
   // fragment read addresses relative to a ring slot
@@ -380,8 +400,8 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
   if (probe.on) probe.mt2 = __builtin_amdgcn_s_memtime();
 
   // epilogue operands that need registers (the activation-backward operand Z) are fetched now: the fragment sets are dead
-  ZPre<BM * (BN / 8) / 256> zp;
-  z_prefetch<bf16_t, TC, BM, BN, 256>(zp, g, m0, n0, tid);
+  ZPre<BM * (BN / 8) / NTH> zp;
+  z_prefetch<bf16_t, TC, BM, BN, NTH>(zp, g, m0, n0, tid);
 
   __syncthreads();                  // every wavefront is done reading the operand slabs before the C tile overwrites them
   if constexpr (TA) {
@@ -401,10 +421,42 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
       __syncthreads();
     }
   }
-  // accumulators -> LDS [BM][BN + 4] fp32.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  {
+#ifdef ETP_MM32_HALF_EPI
+  // EXPERIMENT BUILD ONLY (tools/experiments/r06_neighbour_bisect.sh): the 128x128 tile stages its fp32 accumulators
+  // in two 64-row halves (33 792 B, inside the 64-KB ring) instead of one 67 584-B tile -- one of the two things the 128x128 classes
+  // of both GEMM families share and the classes that do not disturb a co-resident row kernel lack.
+  if constexpr (BM == 128 && BN == 128 && KS == 1) {
     constexpr int CP = BN + 4;
     float* ct = reinterpret_cast<float*>(smem);
+    const int col = lane & 31, rh = 4 * (lane >> 5);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half) {
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[(a * 32 + (r & 3) + 8 * (r >> 2) + rh) * CP + wc * WN + b * 32 + col] = acc[a][b][r];
+      }
+      __syncthreads();
+      EpiPre<bf16_t, TC, 64, BN, NTH> pre_h;
+      pre_h.valid = false; pre_h.bias_valid = pre.bias_valid; pre_h.b0 = pre.b0; pre_h.b1 = pre.b1;
+      ZPre<64 * (BN / 8) / NTH> zp_h;
+      zp_h.valid = false;
+      gemm_epilogue_staged<bf16_t, TC, 64, BN, NTH, 1>(smem, g, C, m0 + 64 * half, n0, 0, tid, pre_h, zp_h);
+      __syncthreads();
+    }
+    probe_end(probe, g, rec, nk);
+    return;
+  }
+#endif
+  // accumulators -> LDS [BM][BN + 4] fp32 (KS = 2: one such tile per wave group, summed by the staged epilogue's reads).
+  // 32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  {
+    constexpr int CP = BN + 4;
+    float* ct = reinterpret_cast<float*>(smem) + kgrp * (BM * CP);
     const int col = lane & 31, rh = 4 * (lane >> 5);
 #pragma unroll
     for (int a = 0; a < FM; ++a)
@@ -415,17 +467,17 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
           ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + rh) * CP + wc * WN + b * 32 + col] = acc[a][b][r];
   }
   __syncthreads();
-  gemm_epilogue_staged<bf16_t, TC, BM, BN, 256>(smem, g, C, m0, n0, 0, tid, pre, zp);
+  gemm_epilogue_staged<bf16_t, TC, BM, BN, NTH, KS>(smem, g, C, m0, n0, 0, tid, pre, zp);
   probe_end(probe, g, rec, nk);
 }
 
-template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 1 : 2)) void kernel(const GemmArgs g) {
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES, int KS = 1>
+__global__ __launch_bounds__(256 * KS, (KS == 2 || BM * BN > 128 * 128) ? 1 : 2) void kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, g.M / BM, g.N / BN, g.xcd_map, tm, tn);
-  tile<TC, TA, TB, BM, BN, STAGES>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
-                                   reinterpret_cast<TC*>(g.C), tm, tn, smem, blockIdx.x);
+  tile<TC, TA, TB, BM, BN, STAGES, KS>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
+                                       reinterpret_cast<TC*>(g.C), tm, tn, smem, blockIdx.x);
 }
 
 // Grouped launch (the weight gradients of one transformer layer): same tile list order as gemm.hip's gemm_group_kernel.
@@ -452,26 +504,32 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 1 : 2)) void group_kern
                                    reinterpret_cast<TC*>(g.C), tm, tn, smem, bid);
 }
 
-template <int BM, int BN, int STAGES> constexpr int smem_bytes() {
-  constexpr int ring = STAGES * (BM + BN) * 128, ct = BM * (BN + 4) * 4;
+template <int BM, int BN, int STAGES, int KS = 1> constexpr int smem_bytes() {
+  constexpr int ring = KS * STAGES * (BM + BN) * 128, ct = KS * BM * (BN + 4) * 4;
+#ifdef ETP_MM32_HALF_EPI      // experiment build: the 128x128 tile stages its epilogue in two halves that fit the ring
+  if (BM == 128 && BN == 128 && KS == 1) return ring;
+#endif
+#ifdef ETP_MM32_PAD_LDS       // experiment build: ONE 128x128 workgroup per CU (the request leaves no room for a second one)
+  if (BM == 128 && BN == 128 && KS == 1) return 100 * 1024;
+#endif
   return ring > ct ? ring : ct;
 }
 
-template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES>
+template <typename TC, bool TA, bool TB, int BM, int BN, int STAGES, int KS = 1>
 static int launch(const GemmArgs& g_in, hipStream_t st) {
-  constexpr int smem = smem_bytes<BM, BN, STAGES>();
-  void (*kern)(const GemmArgs) = kernel<TC, TA, TB, BM, BN, STAGES>;
+  constexpr int smem = smem_bytes<BM, BN, STAGES, KS>();
+  void (*kern)(const GemmArgs) = kernel<TC, TA, TB, BM, BN, STAGES, KS>;
   ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
   const int tiles = (g_in.M / BM) * (g_in.N / BN);
   GemmArgs g = g_in;
   char nm[96];
-  snprintf(nm, sizeof(nm), "mm32<bf16,%s,%s%s,%dx%d,s%d>", sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN,
-           STAGES);
+  snprintf(nm, sizeof(nm), "mm32<bf16,%s,%s%s,%dx%d,s%d%s>", sizeof(TC) == 2 ? "bf16" : "f32", TA ? "T" : "N", TB ? "N" : "T", BM, BN,
+           STAGES, KS == 2 ? ",k2" : "");
   g.dbg = probe_slot(nm, tiles, g.M, g.N, g.K);
   ProfRec rec;
   const bool prof = prof_begin(nm, 2.0 * g.M * g.N * g.K,
                                ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * sizeof(TC), st, rec);
-  ETP_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, g);
+  ETP_LAUNCH(kern, dim3(tiles), dim3(256 * KS), smem, st, g);
   ETP_CHECK_LAUNCH("mm32");
   if (prof) prof_end(rec, st);
   return ETP_OK;
@@ -516,8 +574,13 @@ static bool eligible(const GemmArgs& g, int bm, int bn) {
 template <typename TC, bool TA, bool TB>
 static int launch_class(const GemmArgs& g, int cls, hipStream_t st) {
   if (cls == 128) return launch<TC, TA, TB, 128, 128, 2>(g, st);
+  if constexpr (!TA) {
+    if (cls == 264) return launch<TC, TA, TB, 128, 64, 3, 2>(g, st);   // split reduction, two rings of three (144 KB)
+    if (cls == 262) return launch<TC, TA, TB, 128, 64, 2, 2>(g, st);   // split reduction, two rings of two (96 KB: a 64-KB leaf workgroup fits beside it)
+  }
   return launch<TC, TA, TB, 128, 64, 3>(g, st);
 }
+static bool eligible_k2(const GemmArgs& g) { return eligible(g, 128, 64) && g.K % 128 == 0 && g.K >= 256; }
 
 }  // namespace mm32
 
@@ -532,11 +595,23 @@ int mm32_class(const GemmArgs& g, int nbatch) {
   if (!mode || nbatch != 1) return 0;
   if (mode == 128) return mm32::eligible(g, 128, 128) ? 128 : 0;
   if (mode == 64) return mm32::eligible(g, 128, 64) ? 64 : 0;
+  if (mode == 264 || mode == 262) return mm32::eligible_k2(g) ? mode : (mm32::eligible(g, 128, 64) ? 64 : 0);
   const long t128 = (long)(g.M / 128) * (g.N / 128);
   if (mm32::eligible(g, 128, 128) && t128 >= 320) return 128;
   // 128x64: the N = 768 products of the M = B*L rows (240 workgroups) and everything between them and the 128x128 class
   const long tw = (long)(g.M / 128) * (g.N / 64);
-  if (mm32::eligible(g, 128, 64) && tw >= 200) return 64;
+  // one workgroup per CU in ONE resident round (200 .. 256 tiles: the N = 768 products of the 2560 text rows): the split-reduction
+  // form (mm32::tile, KS = 2) puts a second wavefront on every SIMD.  Measured (profiles/r06_k2_bench.txt, r06_ab_runs.json): isolated
+  // launches 3 - 6 % faster with two rings of three (2560x768x3072: 18.5 -> 17.5 us), 20 % SLOWER with two rings of two, and the step
+  // +0.3 % with it (4.054 / 4.056 against 4.043 / 4.038 ms): these loops move 283 MB through the CUs in 13.3 us = 21 TB/s, the rate the
+  // feed bench reaches with nothing but the loads (profiles/r04a_feed_bench.txt) -- they are at the L2 -> CU feed, not waiting on
+  // latency, and a 144-KB workgroup displaces the leaf workgroup that shared its CU.  So: OFF by default; MM32_K2 = 264 / 262 turns the
+  // class on (tests force it through MM32 = 264 / 262).
+  if (mm32::eligible(g, 128, 64) && tw >= 200) {
+    const int k2 = opt_int(OPT_MM32_K2, 0);
+    if (k2 && tw <= 256 && mm32::eligible_k2(g)) return k2 == 262 ? 262 : 264;   // (storage classes with a transposed A keep the 64 class: launch_class)
+    return 64;
+  }
   return 0;
 }
 

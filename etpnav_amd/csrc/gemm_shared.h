@@ -157,7 +157,9 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN, NTH>& pre, co
 // Epilogue shared by every GEMM kernel, second half: the fp32 accumulator tile sits in LDS as [BM][BN + 4] (staged by the
 // caller, followed by a barrier); each thread combines whole 8-column chunks with bias / activation / dropout / residual /
 // old C and stores them as 16-byte vectors.
-template <typename T, typename TC, int BM, int BN, int NTH = 256>
+// NCT > 1: NCT such tiles lie behind one another ([NCT][BM][BN + 4]: the partial sums of an intra-workgroup split of the
+// reduction, gemm_mm32.hip KS = 2) and are added as they are read.
+template <typename T, typename TC, int BM, int BN, int NTH = 256, int NCT = 1>
 __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs& g, TC* C, int m0, int n0, int ks, int tid,
                                                      const EpiPre<T, TC, BM, BN, NTH>& pre, const ZPre<BM * (BN / 8) / NTH> zp) {
   constexpr int CP = BN + 4;
@@ -233,6 +235,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
         const float4 x0 = *reinterpret_cast<const float4*>(ct + lr * CP + lc);
         const float4 x1 = *reinterpret_cast<const float4*>(ct + lr * CP + lc + 4);
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+        for (int t = 1; t < NCT; ++t) {
+          const float4 y0 = *reinterpret_cast<const float4*>(ct + t * (BM * CP) + lr * CP + lc);
+          const float4 y1 = *reinterpret_cast<const float4*>(ct + t * (BM * CP) + lr * CP + lc + 4);
+          v[0] += y0.x; v[1] += y0.y; v[2] += y0.z; v[3] += y0.w; v[4] += y1.x; v[5] += y1.y; v[6] += y1.z; v[7] += y1.w;
+        }
       }
       if (has_bias) {
         float4 b0, b1;
@@ -314,7 +322,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
     const int lr = q / BN, lc = q % BN;
     const int row = m0 + lr, col = n0 + lc;
     if (row >= g.M || col >= g.N) continue;
-    float v = ct[lr * CP + lc] * g.alpha + ((g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f);
+    float v = ct[lr * CP + lc];
+#pragma unroll
+    for (int t = 1; t < NCT; ++t) v += ct[t * (BM * CP) + lr * CP + lc];
+    v = v * g.alpha + ((g.bias != nullptr && ks == 0) ? g.bias[col] : 0.f);
     if (g.act == ETP_ACT_GELU) {
       Elem<T>::st(Z + (long)row * g.ldz + col, v);
       v = gelu_erf(v);

@@ -51,13 +51,19 @@ template <typename T, bool TR, int ROWS, int PAD = 32> struct TileGeom {
 
 template <int N> struct Regs { uint4 v[N]; unsigned okmask; };
 
-// 16-byte-chunk XOR swizzle of unpadded transposed tiles ([k][rows], LDS-DMA layout): the four k-rows one
-// ds_read_b64_tr_b16 lane group touches land on disjoint bank ranges (2*(k&3)), and the two groups of a 32-lane
-// half (k and k+8) on different 128-byte halves of a 256-byte row (8*((k>>3)&1), only when the row has >= 16 chunks).
+// 16-byte-chunk XOR swizzle of unpadded transposed tiles ([k][rows], LDS-DMA layout).  One ds_read_b64_tr_b16 is served in two
+// groups of 32 lanes (MI355X_MICROARCH.md, LDS); with frag_load's lane -> address map a group reads EIGHT k-rows -- kr0 + {0..3} from
+// its first 16 lanes, kr0 + 8 + {0..3} from the other 16 (the second read of the pair: + 4) -- 32 contiguous bytes (two chunks) each,
+// all at the same column offset.  Bank of a byte address: (a / 4) mod 64.
+//   * 256-byte rows (128-row tiles, CPR = 16): every k-row starts at bank 0; the eight rows need eight different chunk pairs:
+//     pair index ^= (k & 3) | ((k >> 3) & 1) << 2.
+//   * 128-byte rows (64-row tiles, CPR = 8): even k-rows start at bank 0, odd ones at bank 32, so the four rows of one parity --
+//     k, k + 2, k + 8, k + 10 -- need four different chunk pairs: pair index ^= ((k >> 1) & 1) | ((k >> 3) & 1) << 1.
+//     Round 6: until round 5 this layout used (k & 3), under which k and k + 8 (and k + 2, k + 10) share their
+//     banks -- the 33-40 % SQ_LDS_BANK_CONFLICT of the NN 32x64 / 64x64 classes (profiles/r05_gemm_counters.txt).
 template <int CPR> __device__ __forceinline__ int tr_swz(int krow) {
-  int x = (krow & 3) << 1;
-  if constexpr (CPR >= 16) x ^= ((krow >> 3) & 1) << 3;
-  return x;
+  if constexpr (CPR >= 16) return ((krow & 3) << 1) ^ (((krow >> 3) & 1) << 3);
+  else return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
 }
 
 // global -> registers for one tile (zero-filled outside [rows_total) x [k_end)).

@@ -34,11 +34,14 @@ hipError_t ensure_dyn_lds(const void* kern, int bytes);
 int cu_lds_bytes();
 // Row-kernel families that can be launched with the CU to themselves (a workgroup that asks for the CU's whole LDS
 // shares it with no other kernel's wavefronts).  The switch ROW_EXCLUSIVE is a bit mask over these families; default
-// ROWF_DEFAULT.  tests/test_neighbours_gpu.py runs every family with its bit off beside the 128x128 GEMM tile classes.
+// ROWF_DEFAULT = none since round 6: the corruption the exclusivity of round 5 papered over was one packed-fp32 instruction form
+// (v_pk_mul_f32 ... op_sel:[0,1]) misbehaving beside another kernel's MFMAs, and the row kernels no longer contain packed fp32
+// (etpnav_amd/build.py NO_PACKED_FP32; build-time audit).  tests/test_neighbours_gpu.py runs every family SHARED beside the 128x128
+// GEMM tile classes; the mask stays as a switch.
 enum RowFamily {
   ROWF_PANO_BWD = 1, ROWF_GMAP_BWD = 2, ROWF_TEXT_BWD = 4, ROWF_SAP_BWD = 8, ROWF_LN_BWD = 16, ROWF_LN_FWD = 32, ROWF_ATTN_BWD = 64,
   ROWF_ATTN_FWD = 128,
-  ROWF_DEFAULT = ROWF_PANO_BWD
+  ROWF_DEFAULT = 0
 };
 // dynamic LDS bytes to launch `kern` with: `smem` itself, or (CU LDS - the kernel's static LDS) when the family's bit is set
 unsigned row_launch_lds(const void* kern, int family, unsigned smem);

@@ -10,6 +10,7 @@ namespace etp {
 enum Opt {
   OPT_MM32,             // 0: mm32 family off | 128 / 64 / 264: force a class for every eligible product (tests, A/B runs)
   OPT_MM32_GROUP,       // 128 / 256: force the grouped weight-gradient class
+  OPT_MM32_K2,          // 0: one-round 128x64 grids keep four wavefronts | 262 / 264: split-reduction form with rings of two / three
   OPT_GEMM_TILE,        // gemm.hip tile class: "128", "64", "32", "w", "256" + optional "s2".."s4", "r" = register-staged
   OPT_GROUP_TILE,       // gemm.hip grouped class: "256s2", "256s3", "128s2", "128s3", "64s3", "64s4"
   OPT_GEMM_WIDE,        // 1: gemm.hip's 128x64 class on

@@ -92,25 +92,63 @@ BF16_SAMPLE_REL, BF16_L2_REL, BF16_FULL_REL, BF16_ABS_FLOOR, BF16_COS_MIN = 1e-1
 BF16_B1_SAMPLE_REL, BF16_B1_L2_REL = 3.5e-1, 2e-1
 
 
-def bf16_bounds(B: int) -> dict:
-    """Per-batch-size tiers of the bf16 gradient bounds: the common-mode error above shrinks with the number of episodes whose rows are
-    summed (B = 1: 1 .. 26 % median; B = 3 .. 4: 3 .. 12 %, profiles/r05_b1_noise.txt second table); from B = 8 on the round-3 bounds hold
-    and the benchmarked shapes (B = 8 / 16 / 32) keep their own tighter ones (9 % / 0.995, tests/test_baseline_shapes_gpu.py).
+_GAP = None
+
+
+def autocast_gap():
+    """tests/golden/bf16_autocast_gap.json: the bf16-autocast-vs-fp32 gap of the REAL reference module on the CPU (generator:
+    tools/experiments/r06_autocast_gap.py; table and the same-seed lottery check: profiles/r06_autocast_gap.txt)."""
+    global _GAP
+    if _GAP is None:
+        import json
+        _GAP = json.load(open(os.path.join(GOLDEN_DIR, "bf16_autocast_gap.json")))
+    return _GAP
+
+
+def _tier_quantile(prefix: str, key: str, q: float) -> float:
+    vals = sorted(v[key] for k, v in autocast_gap()["seeds"].items() if k.startswith(prefix))
+    return vals[min(len(vals) - 1, max(0, int(round(q * (len(vals) - 1)))))]
+
+
+YARDSTICK_K = 2.0
+
+
+def bf16_bounds(B: int, fixture: str = None) -> dict:
+    """bf16 gradient bounds per batch-size tier, held against the YARDSTICK SURVEY.md §7 (i) names: the reference's own
+    bf16-autocast-vs-fp32 gap, measured on the real module for the 16 single-episode and 8 three-episode seeds of
+    profiles/r05_b1_noise.txt and for every fixture (profiles/r06_autocast_gap.txt).  What that table says:
+      * B = 1: the reference's gap is 2 .. 15 % (median over the tensors), up to 18 % on a tensor and 23 % on a sample, seed to seed --
+        and the SAME seed moves between 3 % and 20 % (28 % on a tensor) when the input changes by 1e-4 (lottery check, same file): the
+        per-seed value is not a property of the seed, so a fixture is bounded by the tier's distribution, not by its own draw;
+      * B = 3: 6 .. 11 % median, up to 19 %.
+    A bound = min(round-5 tier, YARDSTICK_K x max(the fixture's own gap, the tier's upper-quartile gap)), YARDSTICK_K = 2; the cosine
+    bound uses 1 - K^2 (1 - cos) (a relative error e costs e^2 / 2 of cosine).  For B = 1 this gives 34 % / 34 % / 0.95 against the
+    blanket 35 % / 35 % / 0.93 of round 5; from B = 2 on the round-5 tiers are already tighter than 2 x the yardstick and stay.
+    The HIP path's distribution over seeds is held to the yardstick's by tests/test_planner_gpu.py::
+    test_small_batch_bf16_error_distribution_matches_the_autocast_yardstick.
     Keys: sample_rel / l2_rel for compare_grads_bf16, rel / cos_min for compare_full_bf16."""
     if B <= 1:
-        return dict(sample_rel=BF16_B1_SAMPLE_REL, l2_rel=BF16_B1_L2_REL, rel=0.35, cos_min=0.93)
-    if B <= 4:
-        return dict(sample_rel=0.15, l2_rel=0.08, rel=0.18, cos_min=0.98)
-    return dict(sample_rel=BF16_SAMPLE_REL, l2_rel=BF16_L2_REL, rel=BF16_FULL_REL, cos_min=BF16_COS_MIN)
+        base, prefix = dict(sample_rel=BF16_B1_SAMPLE_REL, l2_rel=BF16_B1_L2_REL, rel=0.35, cos_min=0.93), "B1_"
+    elif B <= 4:
+        base, prefix = dict(sample_rel=0.15, l2_rel=0.08, rel=0.18, cos_min=0.98), "B3_"
+    else:
+        return dict(sample_rel=BF16_SAMPLE_REL, l2_rel=BF16_L2_REL, rel=BF16_FULL_REL, cos_min=BF16_COS_MIN)
+    fx = autocast_gap()["fixtures"].get(fixture, {}) if fixture else {}
+    k = YARDSTICK_K
+    rel = k * max(fx.get("max", 0.0), _tier_quantile(prefix, "max", 0.75))
+    smp = k * max(fx.get("worst_sample", 0.0), _tier_quantile(prefix, "worst_sample", 0.75))
+    cos = 1.0 - k * k * (1.0 - min(fx.get("min_cos", 1.0), _tier_quantile(prefix, "min_cos", 0.25)))
+    return dict(sample_rel=min(base["sample_rel"], smp), l2_rel=base["l2_rel"], rel=min(base["rel"], rel),
+                cos_min=max(base["cos_min"], cos))
 
 
-def fixture_bounds(B: int) -> dict:
-    b = bf16_bounds(B)
+def fixture_bounds(B: int, fixture: str = None) -> dict:
+    b = bf16_bounds(B, fixture)
     return dict(sample_rel=b["sample_rel"], l2_rel=b["l2_rel"])
 
 
-def full_bounds(B: int) -> dict:
-    b = bf16_bounds(B)
+def full_bounds(B: int, fixture: str = None) -> dict:
+    b = bf16_bounds(B, fixture)
     return dict(rel=b["rel"], cos_min=b["cos_min"])
 
 
@@ -191,3 +229,34 @@ def compare_rollout(z, outs, atol):
         assert float((got[fin] - ref[fin]).abs().max()) <= atol, f"step {t}: logits"
         e = float((o["gmap_embeds"].detach().float().cpu() - torch.from_numpy(z[f"out.gmap_embeds.{t}"])).abs().max())
         assert e <= atol, f"step {t}: gmap_embeds {e}"
+
+
+def compare_full_fp32(got, model_grads, outs, grads, tol=1e-3):
+    """BASELINE.json north_star's tolerance, full tensors: embeddings / logits / loss within `tol` absolute of the oracle, the -inf
+    pattern of the logits identical, every parameter gradient within `tol` absolute AND (1e-3 relative L2 or a 2e-6 absolute floor
+    for tensors that are zero in exact arithmetic).  `got`: txt_embeds / pano_embeds / gmap_embeds / global_logits / loss of the HIP
+    step, `outs` / `grads`: the oracle's.  Returns (worst outputs dict, (worst abs err, name), (worst relative L2, name))."""
+    worst = {}
+    pm = outs["pano_masks"]
+    for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
+        a, b = got[k].float().cpu(), outs[k]
+        if k == "pano_embeds":
+            a, b = a[pm], b[pm]                             # padded query rows are don't-care (SURVEY App. A8)
+        worst[k] = float((a - b).abs().max())
+        assert worst[k] <= tol, (k, worst[k])
+    fin = torch.isfinite(outs["global_logits"])
+    assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
+    worst["logits"] = float((got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max())
+    worst["loss"] = abs(got["loss"].item() - outs["loss"].item())
+    assert worst["logits"] <= tol and worst["loss"] <= tol, worst
+    wg, wr = (0.0, ""), (0.0, "")
+    for k, g in grads.items():
+        if k.startswith("__input__"):
+            continue
+        err = float((model_grads[k] - g).abs().max())
+        assert err <= tol, (k, err)
+        nr = float(g.norm())
+        rel = float((model_grads[k] - g).norm()) / nr if nr > 1e-6 else 0.0
+        assert rel <= 1e-3 or err <= 2e-6, (k, rel, err)
+        wg, wr = max(wg, (err, k)), max(wr, (rel, k))
+    return worst, wg, wr

@@ -40,11 +40,15 @@ def btol(K):
     return 3e-2 * math.sqrt(K) / 4
 
 
-@pytest.mark.parametrize("cls", ["128", "64"])
+@pytest.mark.parametrize("cls", ["128", "64", "264", "262"])     # 26x = the 128x64 tile with the reduction split over two wave groups
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("K", [128, 192, 256, 320, 384, 768])
+@pytest.mark.parametrize("K", [128, 192, 256, 320, 384, 768, 3072])
 def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, etp_opt):
     """Plain products (fp32 and bf16 C), reductions of 2, 3, 5 and 12 slabs: ring fill / drain paths of both ring depths."""
+    if cls in ("264", "262") and (ta or K % 128 or K < 256):
+        pytest.skip("the split-reduction form takes row-major A and whole 128-k pairs of slabs; other shapes fall back to class 64")
+    if K == 3072 and cls in ("128", "64") and (ta, tb) != (0, 0):
+        pytest.skip("long reduction: one storage class is enough for the unsplit classes")
     etp_opt("ETP_MM32", cls)
     M, N = (384, 256) if cls == "128" else (256, 192)
     As, Bs, ref = operands(M, N, K, ta, tb, 11 * K + ta + 2 * tb)
@@ -59,13 +63,13 @@ def test_mm32_storage_classes_match_fp32_reference(cls, ta, tb, K, etp_opt):
     assert (Cb.float() - ref).abs().max().item() <= btol(K), (cls, ta, tb, K)
 
 
-@pytest.mark.parametrize("cls", ["128", "64"])
+@pytest.mark.parametrize("cls", ["128", "64", "264", "262"])
 @pytest.mark.parametrize("tb", [0, 1])
 def test_mm32_epilogues(cls, tb, etp_opt):
     """bias + fp32 residual into an fp32 stream, bias + GELU with the saved pre-activation, GELU / ReLU backward, ReLU, accumulate,
     alpha -- the epilogues of linear_fwd / linear_fwd_s / linear_dgrad(_s) in planner.hip."""
     etp_opt("ETP_MM32", cls)
-    M, N, K = (512, 384, 256) if cls == "128" else (384, 320, 192)
+    M, N, K = (512, 384, 256) if cls == "128" else ((384, 320, 192) if cls == "64" else (384, 320, 384))
     As, Bs, raw = operands(M, N, K, 0, tb, 5 + tb)
     bias = torch.randn(N, device=DEV)
     R = torch.randn(M, N, device=DEV)
@@ -200,7 +204,7 @@ def test_mm32_grouped_weight_gradients_256x128_tiles(Mt, etp_opt):
             assert (a - b).abs().max().item() <= 1e-4 * math.sqrt(Mt), (out_mode, tuple(a.shape))
 
 
-@pytest.mark.parametrize("cls", ["128", "64"])
+@pytest.mark.parametrize("cls", ["128", "64", "264", "262"])
 def test_mm32_race_screen_under_uneven_load(cls, etp_opt):
     """12 runs of the same products while a bandwidth-heavy copy loop on a second stream perturbs the DMA timing on every other
     run: outputs must be bit-identical across runs (a stale or early LDS read shows as a run that differs) and match the
@@ -209,8 +213,10 @@ def test_mm32_race_screen_under_uneven_load(cls, etp_opt):
     side = torch.cuda.Stream()
     noise_a = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
     noise_b = torch.empty_like(noise_a)
-    for (M, N, K, ta, tb) in [(512, 384, 128, 0, 0), (384, 256, 192, 0, 1), (640, 768, 320, 1, 1), (768, 512, 1536, 0, 1),
-                              (1024, 1024, 1536, 1, 1)]:
+    shapes = [(512, 384, 128, 0, 0), (384, 256, 192, 0, 1), (640, 768, 320, 1, 1), (768, 512, 1536, 0, 1), (1024, 1024, 1536, 1, 1)]
+    if cls in ("264", "262"):          # the split form: 2, 3 and 24 slabs per wave group, both row-major-A storage classes
+        shapes = [(512, 384, 256, 0, 0), (384, 256, 384, 0, 1), (2560, 768, 3072, 0, 0), (2560, 768, 3072, 0, 1)]
+    for (M, N, K, ta, tb) in shapes:
         As, Bs, ref = operands(M, N, K, ta, tb, M + K)
         first = None
         for it in range(12):

@@ -111,9 +111,48 @@ def test_bf16_step_close_to_reference_golden(name):
     step = PlannerStep(model, batch)
     step.run_eager()
     compare_outputs(z, step_outputs(step), atol=5e-2)
-    from tests.golden_util import fixture_bounds      # per-batch-size tiers: golden_util.bf16_bounds, profiles/r05_b1_noise.txt
-    ws, wl = compare_grads_bf16(z, grads_of(model), **fixture_bounds(batch["txt_ids"].shape[0]))
+    from tests.golden_util import fixture_bounds      # per-batch-size tiers held against the reference's own autocast gap (golden_util.bf16_bounds)
+    ws, wl = compare_grads_bf16(z, grads_of(model), **fixture_bounds(batch["txt_ids"].shape[0], name))
     print(name, "bf16 worst sample err / abs-max", ws, "worst |dL2| / L2", wl)
+
+
+@pytest.mark.parametrize("B,seeds", [(1, (1, 2, 3, 4, 5, 6, 7, 8)), (3, (1, 2, 3, 4))])
+def test_small_batch_bf16_error_distribution_matches_the_autocast_yardstick(B, seeds):
+    """VERDICT r5 #5 / SURVEY.md §7 (i): at B <= 4 the bf16 gradient error is a lottery over the inputs -- for the reference's own
+    bf16 autocast as much as for this path (profiles/r06_autocast_gap.txt: the same seed moves between 3 % and 20 % when the input
+    changes by 1e-4) -- so a single fixture cannot tell a 10 % regression from an unlucky draw.  The DISTRIBUTION can: over the first
+    seeds of that study (the c1 / rollout per-sample shape L = 20, V = 17, G = 9), the median over the seeds of the per-tensor median
+    relative L2 error against the fp32 oracle must stay within 1.75 x the yardstick's median over the same seeds, and the worst seed
+    within 2 x the yardstick's worst seed.  (Round-5 library, same seeds: 1.35 x the median, 1.8 x the worst.)"""
+    from tests.golden_util import autocast_gap
+    ref = autocast_gap()["seeds"]
+    cfg = po.PlannerConfig.r2r()
+    P = po.init_params(cfg, seed=0)
+    model = build_model(cfg, P, torch.bfloat16)
+    med, mx = [], []
+    for seed in seeds:
+        batch = po.make_batch(cfg, seed=seed, B=B, L=20, V=17, G=9, ragged=False)
+        _, grads = po.step_with_grads(P, cfg, batch)
+        step = PlannerStep(model, batch, overlap=False)
+        step.run_eager()
+        torch.cuda.synchronize()
+        rel = []
+        for k, p in model.named_parameters():
+            r = grads[k].double().reshape(-1)
+            if float(r.abs().max()) < 1e-6:
+                continue
+            rel.append(float((p.grad.detach().double().cpu().reshape(-1) - r).norm()) / float(r.norm()))
+        t = torch.tensor(rel)
+        med.append(float(t.median()))
+        mx.append(float(t.quantile(0.9)))
+        step.close()
+    y_med = [ref[f"B{B}_seed{s}"]["median"] for s in seeds]
+    y_p90 = [ref[f"B{B}_seed{s}"]["p90"] for s in seeds]
+    mm, ym = float(torch.tensor(med).median()), float(torch.tensor(y_med).median())
+    print(f"B={B}: per-seed median rel-L2 {[round(x, 4) for x in med]} (yardstick {[round(x, 4) for x in y_med]}); median over seeds "
+          f"{mm:.4f} vs {ym:.4f} = {mm / ym:.2f} x; worst seed p90 {max(mx):.4f} vs {max(y_p90):.4f} = {max(mx) / max(y_p90):.2f} x")
+    assert mm <= 1.75 * ym, (mm, ym)
+    assert max(mx) <= 2.0 * max(y_p90), (max(mx), max(y_p90))
 
 
 def test_fp32_step_vs_oracle_fresh_inputs_and_graph_replay():

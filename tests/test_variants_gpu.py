@@ -203,32 +203,10 @@ def test_benchmarked_shape_b32_fp32_matches_oracle(mode):
     step = PlannerStep(model, batch, dropout=rates if mode == "train" else None, drop_seed=5)
     step.run_eager()
     got = step_outputs(step)
-    TOL = 1e-3
-    worst = {}
-    pm = outs["pano_masks"]
-    for k in ("txt_embeds", "pano_embeds", "gmap_embeds"):
-        a, b = got[k].float().cpu(), outs[k]
-        if k == "pano_embeds":
-            a, b = a[pm], b[pm]                             # padded query rows are don't-care
-        worst[k] = float((a - b).abs().max())
-        assert worst[k] <= TOL, (k, worst[k])
-    fin = torch.isfinite(outs["global_logits"])
-    assert torch.equal(torch.isfinite(got["global_logits"].cpu()), fin)
-    worst["logits"] = float((got["global_logits"].cpu()[fin] - outs["global_logits"][fin]).abs().max())
-    worst["loss"] = abs(got["loss"].item() - outs["loss"].item())
-    assert worst["logits"] <= TOL and worst["loss"] <= TOL, worst
-    wg, wr = (0.0, ""), (0.0, "")
     mine = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
     assert len(mine) == 307
-    for k, g in grads.items():
-        if k.startswith("__input__"):
-            continue
-        err = float((mine[k] - g).abs().max())
-        assert err <= TOL, (k, err)
-        nr = float(g.norm())
-        rel = float((mine[k] - g).norm()) / nr if nr > 1e-6 else 0.0
-        assert rel <= 1e-3 or err <= 2e-6, (k, rel, err)    # and relative to the tensor itself (near-zero tensors: absolute floor)
-        wg, wr = max(wg, (err, k)), max(wr, (rel, k))
+    from tests.golden_util import compare_full_fp32
+    worst, wg, wr = compare_full_fp32(got, mine, outs, grads, tol=1e-3)
     print(f"fp32 B=32 {mode}: outputs {worst}; worst gradient abs err {wg}, worst per-tensor relative L2 {wr}")
     step.close()
 

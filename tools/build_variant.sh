@@ -7,7 +7,8 @@ cd "$(dirname "$0")/.."
 D=etpnav_amd/build
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -munsafe-fp-atomics -Wno-return-type-c-linkage"
 base=$(basename $SRC .hip)
-/opt/rocm/bin/hipcc $F "$@" -c etpnav_amd/csrc/$SRC -o /tmp/${base}_variant_$$.o
+EXTRA=$(python -c "from etpnav_amd.build import PER_SOURCE_FLAGS; print(' '.join(PER_SOURCE_FLAGS.get('$SRC', [])))")
+/opt/rocm/bin/hipcc $F $EXTRA "$@" -c etpnav_amd/csrc/$SRC -o /tmp/${base}_variant_$$.o
 OBJS=""
 for o in $(python -c "from etpnav_amd.build import SOURCES; print(' '.join('etpnav_amd/build/' + s.replace('.hip', '.o') for s in SOURCES))"); do
   if [ "$(basename $o .o)" == "$base" ]; then OBJS="$OBJS /tmp/${base}_variant_$$.o"; else OBJS="$OBJS $o"; fi

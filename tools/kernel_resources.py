@@ -140,6 +140,39 @@ def m0_audit(objdir=None):
     return nk, ni, bad
 
 
+# packed-fp32 VALU instructions that the row-kernel objects may contain: none (etpnav_amd/build.py NO_PACKED_FP32 compiles them with
+# -fno-slp-vectorize -fno-vectorize)
+PK_ALLOW = 0
+PK_RE = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b")
+
+
+# The form that misbehaves beside another kernel's MFMAs (profiles/r06_pk_opsel_repro.txt): a packed fp32 instruction whose LOW result
+# takes the HIGH register of a source (op_sel:[..1..]).  No object of the library may contain one, GEMM and attention objects included
+# (their packed instructions use op_sel_hi only, which the reproducer shows clean).
+PK_OPSEL_RE = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b[^\n/]*\bop_sel:\[[01,]*1[01,]*\]")
+
+
+def pk_opsel_audit(objdir=None):
+    """-> {object file: number of packed fp32 instructions with a low-half operand select} over every object with device code."""
+    from etpnav_amd import build as b
+    objdir = objdir or os.path.join(b.HERE, "build")
+    out = {}
+    for src in b.SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        with open(obj, "rb") as f:
+            if b".hip_fatbin" not in f.read():
+                continue
+        out[src] = len(PK_OPSEL_RE.findall(code_object_isa(obj)))
+    return out
+
+
+def pk_audit(objs, objdir=None):
+    """-> {object file: number of v_pk_{fma,mul,add}_f32 instructions in its device code}."""
+    from etpnav_amd import build as b
+    objdir = objdir or os.path.join(b.HERE, "build")
+    return {o: len(PK_RE.findall(code_object_isa(os.path.join(objdir, o)))) for o in objs}
+
+
 def parse(notes: str):
     """-> list of dicts, one per kernel, from the amdhsa.kernels YAML in the note (flat `.key: value` lines per `- ` item)."""
     kernels, cur, in_args = [], None, False
