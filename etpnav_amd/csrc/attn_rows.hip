@@ -44,6 +44,12 @@ namespace {
 constexpr int TQ = 128;
 // pitch of the wave-private output strips [16][64]: 128-byte row + 16-byte pad (8-byte writes down 16 rows, conflict-free)
 constexpr int TP = 144;
+constexpr int PROJ_K = 768;                      // fused out-projection dgrad: the reduction (= hidden size of every planner the reference builds)
+constexpr int PROJ_SLAB_K = 128;                 // k-rows of W per slab, [128][64] bf16 = 16 KB
+constexpr int PROJ_RING = 3;                     // slabs resident (prefetch distance 2)
+#ifndef ETP_PROJ_FETCH_AT
+#define ETP_PROJ_FETCH_AT 2                      // Q / K / V global loads are issued this many slabs before the end of the prologue
+#endif
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * TQ + ((chunk ^ (row & 7)) << 4); }
 
 struct RowArgs {
@@ -57,6 +63,9 @@ struct RowArgs {
   const bf16_t* dO; long ldd;
   bf16_t *dQ, *dK, *dV; long lddq, lddk, lddv;
   float *d_sp_w, *d_sp_b;
+  // PROJ backward (rows_bwd_kernel<.., true>): dO is not read from memory but computed in the kernel's prologue as
+  // dO[b, q, h*64 : h*64+64] = dY[b*Lq + q, 0:Kp] . W[0:Kp, h*64 : h*64+64]   (dY = the `dO` pointer with row stride ldd)
+  const bf16_t* W; long ldw; int Kp;
 };
 
 __device__ __forceinline__ f32x4_t mma32(const uint4& a, const uint4& b, f32x4_t c) {
@@ -130,6 +139,38 @@ __device__ __forceinline__ void store_rows16(char* strip, const f32x4_t (&acc)[4
     if (row < rows_valid) *reinterpret_cast<uint4*>(g0 + (long)row * ld + part * 8) = v;
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// ---- pieces of the fused out-projection dgrad (rows_bwd_kernel<.., PROJ = true>) ----
+// one [128 k][64] slab of W (column block of this head) -> registers: 1024 16-byte pieces over the workgroup's threads
+template <int WN>
+__device__ __forceinline__ void proj_load_w(uint4 (&w)[WN], const bf16_t* __restrict__ Wg, long ldw, int s, int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int p = tid + j * nthr;
+    w[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (p < PROJ_SLAB_K * 8) w[j] = *reinterpret_cast<const uint4*>(Wg + (long)(s * PROJ_SLAB_K + (p >> 3)) * ldw + (p & 7) * 8);
+  }
+}
+// this lane's 8 consecutive k per k-step of its own dY row (B operand of the k=32 product), four steps per slab
+__device__ __forceinline__ void proj_load_y(uint4 (&y)[4], const bf16_t* __restrict__ Yr, int s, bool computing, bool qok) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (computing) v = *reinterpret_cast<const uint4*>(Yr + s * PROJ_SLAB_K + 32 * u);
+    v.x = qok ? v.x : 0u; v.y = qok ? v.y : 0u; v.z = qok ? v.z : 0u; v.w = qok ? v.w : 0u;
+    y[u] = v;
+  }
+}
+// registers -> slab in LDS, rows permuted inside every 32: k = 8g+e -> row 4g+e (e < 4), 16+4g+(e-4) (e >= 4)
+template <int WN>
+__device__ __forceinline__ void proj_commit_w(char* slab, const uint4 (&w)[WN], int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int p = tid + j * nthr, kk = p >> 3;
+    const int row = (kk & ~0x1c) | ((kk & 0x4) << 2) | ((kk & 0x18) >> 1);
+    if (p < PROJ_SLAB_K * 8) *reinterpret_cast<uint4*>(slab + tile_off(row, p & 7)) = w[j];
+  }
 }
 
 __device__ __forceinline__ float key_term(const uint8_t* km, int col, int Lk, int mask_mode) {
@@ -234,19 +275,36 @@ __global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // backward: grid = batch*heads, block = 64 * max(4, ceil(Lq/16), ceil(Lk/16)) threads
 struct BwdLds {                                  // byte offsets for BQ = 16*ceil(Lq/16) query rows and BKV key rows
-  int q, d, k, v, kadd, lse, D, red, strip, total;
-  __host__ __device__ BwdLds(int BQ, int BKV) {
-    q = 0; d = BQ * TQ; k = 2 * BQ * TQ; v = k + BKV * TQ; kadd = v + BKV * TQ;
+  int q, d, k, v, kadd, lse, D, red, strip, ring, total;
+  __host__ __device__ BwdLds(int BQ, int BKV, bool proj = false) {
+    d = 0; q = BQ * TQ; k = 2 * BQ * TQ; v = k + BKV * TQ; kadd = v + BKV * TQ;
     lse = kadd + BKV * 4; D = lse + 128 * 4; red = D + 128 * 4; strip = red + 16 * 4; total = strip + 8 * 16 * TP;
+    // the W slabs of the fused out-projection dgrad live where Q / K / V / the strips go AFTER the prologue (dO stays outside)
+    ring = BQ * TQ;
+    if (proj && total < ring + PROJ_RING * PROJ_SLAB_K * TQ) total = ring + PROJ_RING * PROJ_SLAB_K * TQ;
   }
 };
 
-template <int NKT, bool HAS_DIST>
+// PROJ = true (round 6): the out-projection's input gradient (BertSelfOutput.dense, vilmodel_cmt.py:150-154; BertOutAttention /
+// MHA out_proj alike) is no longer a GEMM launch of its own whose [B*Lq, H] result this kernel reads back as dO.  The workgroup of
+// (batch b, head h) computes its own 16*nqt x 64 tile  dO = dY[b rows, 0:Kp] . W[0:Kp, h*64 : h*64+64]  first:
+//   * dO^T = W_h^T dY^T with the k=32 MFMA: B operand = 8 consecutive k of the wavefront's OWN 16 rows of dY straight from global
+//     (one 16-byte load per lane and k-step, no sharing between wavefronts, nothing staged); A operand = W_h^T taken DOWN the rows
+//     of a [128 k][64] slab in LDS by two ds_read_b64_tr_b16 -- the slab's rows are stored permuted (k = 8g+e -> row 4g+e, 16+4g+e-4
+//     within each 32) so that the two transposed reads of lane group g return exactly the 8 consecutive k its B operand holds and
+//     both reads keep frag_t4's conflict-free row pattern;
+//   * slabs travel global -> registers -> LDS two slabs ahead of their use (ring of 3 x 16 KB that ALIASES the Q / K / V tiles
+//     and the output strips, which are only needed afterwards; their global loads are in flight in registers meanwhile): the
+//     kernel's LDS footprint, and with it two workgroups per CU, is unchanged;
+//   * the result lands in the dO tile as the same bf16 values the GEMM epilogue stored (round-to-nearest-even of the fp32 sum).
+// What it removes per attention block: one 128x64-class launch (9.9 us isolated for the text rows) + its boundary, 3.9 MB written
+// and read back.
+template <int NKT, bool HAS_DIST, bool PROJ>
 __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
   constexpr int BKV = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nqt = (a.Lq + 15) >> 4, BQ = nqt * 16;
-  const BwdLds L(BQ, BKV);
+  const BwdLds L(BQ, BKV, PROJ);
   char *qt = smem + L.q, *dt = smem + L.d, *kt = smem + L.k, *vt = smem + L.v;
   float* kadd = reinterpret_cast<float*>(smem + L.kadd);
   float* lse = reinterpret_cast<float*>(smem + L.lse);
@@ -260,15 +318,63 @@ __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
   {
     TileRegs<128> rq, rd;
     TileRegs<BKV> rk, rv;
-    tile_fetch<128>(rq, a.Q + (long)b * a.Lq * a.ldq + h * 64, a.ldq, a.Lq, BQ, tid, nthr);
-    tile_fetch<128>(rd, a.dO + (long)b * a.Lq * a.ldd + h * 64, a.ldd, a.Lq, BQ, tid, nthr);
-    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
-    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
+#define FETCH_QKV()                                                                                        \
+    tile_fetch<128>(rq, a.Q + (long)b * a.Lq * a.ldq + h * 64, a.ldq, a.Lq, BQ, tid, nthr);                 \
+    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);                \
+    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr)
+    if constexpr (!PROJ) {
+      FETCH_QKV();
+      tile_fetch<128>(rd, a.dO + (long)b * a.Lq * a.ldd + h * 64, a.ldd, a.Lq, BQ, tid, nthr);
+    } else {
+      constexpr int SLAB = PROJ_SLAB_K * TQ, WN = 4, NS = PROJ_K / PROJ_SLAB_K;     // WN * 256 threads >= 1024 16-byte pieces of a slab
+      char* ring = smem + L.ring;
+      const bf16_t* Wg = a.W + h * 64;
+      const int qrow = wave * 16 + i;
+      const bool computing = wave < nqt, qok = qrow < a.Lq;
+      const bf16_t* Yr = a.dO + ((long)b * a.Lq + min(qrow, a.Lq - 1)) * a.ldd + g * 8;
+      uint4 wr[2][WN], yb[3][4];
+      f32x4_t acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      proj_load_w<WN>(wr[0], Wg, a.ldw, 0, tid, nthr); proj_load_y(yb[0], Yr, 0, computing, qok);
+      proj_load_w<WN>(wr[1], Wg, a.ldw, 1, tid, nthr); proj_load_y(yb[1], Yr, 1, computing, qok);
+      proj_commit_w<WN>(ring, wr[0], tid, nthr);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        // slab s+2 -> registers (the set slab s was committed from); Q / K / V take the load slot once the last slab is on its way
+        if (s + 2 < NS) { proj_load_w<WN>(wr[s % 2], Wg, a.ldw, s + 2, tid, nthr); proj_load_y(yb[(s + 2) % 3], Yr, s + 2, computing, qok); }
+        if (s + ETP_PROJ_FETCH_AT == NS) { FETCH_QKV(); }
+        if (computing) {
+          const char* slab = ring + (s % 3) * SLAB;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const short4_t lo = frag_t4(slab, 32 * u, 16 * t, lane), hi = frag_t4(slab, 32 * u + 16, 16 * t, lane);
+              const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+              acc[t] = mma32(make_uint4(l2.x, l2.y, h2.x, h2.y), yb[s % 3][u], acc[t]);
+            }
+        }
+        if (s + 1 < NS) {
+          proj_commit_w<WN>(ring + ((s + 1) % 3) * SLAB, wr[(s + 1) % 2], tid, nthr);
+          __syncthreads();
+        }
+      }
+      if (computing) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          *reinterpret_cast<uint2*>(dt + tile_off(16 * wave + i, 2 * t + (g >> 1)) + (g & 1) * 8) =
+              make_uint2(pack_bf16(acc[t][0], acc[t][1]), pack_bf16(acc[t][2], acc[t][3]));
+      }
+      __syncthreads();                            // the ring is dead: Q / K / V and the row vectors may land on it
+    }
+#undef FETCH_QKV
     if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
     // padded query rows: lse = +inf makes their recomputed probabilities exactly 0
     if (tid < 128) lse[tid] = tid < a.Lq ? a.lse[(long)bh * a.Lq + tid] : INFINITY;
     tile_commit<128>(qt, rq, BQ, tid, nthr);
-    tile_commit<128>(dt, rd, BQ, tid, nthr);
+    if constexpr (!PROJ) tile_commit<128>(dt, rd, BQ, tid, nthr);
     tile_commit<BKV>(kt, rk, BKV, tid, nthr);
     tile_commit<BKV>(vt, rv, BKV, tid, nthr);
   }
@@ -403,13 +509,16 @@ template <int NKT, bool HAS_DIST> int launch_rows_fwd(const RowArgs& k, int bloc
   ETP_CHECK_LAUNCH("attn_rows_fwd");
   return ETP_OK;
 }
-template <int NKT, bool HAS_DIST> int launch_rows_bwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
-  const BwdLds L(((k.Lq + 15) >> 4) * 16, NKT * 16);
-  auto kern = rows_bwd_kernel<NKT, HAS_DIST>;
-  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BwdLds(128, NKT * 16).total));
+template <int NKT, bool HAS_DIST, bool PROJ> int launch_rows_bwd_p(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  const BwdLds L(((k.Lq + 15) >> 4) * 16, NKT * 16, PROJ);
+  auto kern = rows_bwd_kernel<NKT, HAS_DIST, PROJ>;
+  ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BwdLds(128, NKT * 16, PROJ).total));
   ETP_LAUNCH_ROW(ROWF_ATTN_BWD, kern, dim3(blocks), dim3(threads), L.total, st, k);
-  ETP_CHECK_LAUNCH("attn_rows_bwd");
+  ETP_CHECK_LAUNCH(PROJ ? "attn_rows_bwd_proj" : "attn_rows_bwd");
   return ETP_OK;
+}
+template <int NKT, bool HAS_DIST> int launch_rows_bwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  return k.W ? launch_rows_bwd_p<NKT, HAS_DIST, true>(k, blocks, threads, st) : launch_rows_bwd_p<NKT, HAS_DIST, false>(k, blocks, threads, st);
 }
 
 template <bool HAS_DIST> int dispatch_fwd(int nkt, const RowArgs& k, int blocks, int threads, hipStream_t st) {
@@ -481,14 +590,22 @@ int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float 
   return a.dist ? dispatch_fwd<true>(nkt, k, a.B * nh, threads, st) : dispatch_fwd<false>(nkt, k, a.B * nh, threads, st);
 }
 
+// the fused form is built for the reduction length 768 (BERT-base / XLM-R-base hidden size: the reference's only planners)
+bool attn_rows_proj_ok(int Kp, const void* W, long ldw) {
+  return opt_on(OPT_ATTN_PROJ, true) && Kp == PROJ_K && ldw % 8 == 0 && (uintptr_t)W % 16 == 0;
+}
+
 int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
-                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop) {
+                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop, const void* proj_w,
+                  long proj_ldw, int proj_k) {
   ETP_REQUIRE(ldd % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 &&
                   ((uintptr_t)dctx | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) % 16 == 0,
               "gradient operands of the register-resident attention must be 16-byte aligned");
+  ETP_REQUIRE(proj_w == nullptr || attn_rows_proj_ok(proj_k, proj_w, proj_ldw), "fused out-projection dgrad: unsupported reduction length / alignment");
   if (skip_attn("bwd")) return ETP_OK;
   RowArgs k = make_row_args(nh, a, const_cast<void*>(P), alpha, drop);
   k.dO = (const bf16_t*)dctx; k.ldd = ldd;
+  k.W = (const bf16_t*)proj_w; k.ldw = proj_ldw; k.Kp = proj_k;
   k.dQ = (bf16_t*)dQ; k.dK = (bf16_t*)dK; k.dV = (bf16_t*)dV; k.lddq = lddq; k.lddk = lddk; k.lddv = lddv;
   k.d_sp_w = d_sp_w; k.d_sp_b = d_sp_b;
   const int nqt = (a.Lq + 15) / 16, nkt = (a.Lk + 15) / 16;

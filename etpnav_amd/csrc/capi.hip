@@ -73,7 +73,7 @@ unsigned row_launch_lds(const void* kern, int family, unsigned smem) {
 static const char* const kOptNames[OPT_COUNT] = {
     "MM32", "MM32_GROUP", "MM32_K2", "GEMM_TILE", "GROUP_TILE", "GEMM_WIDE", "GEMM_SMALL", "GEMM_XCD", "ATTN_FUSED", "ATTN_FLASH", "ATTN_Q96",
     "ATTN_ROWS", "LNBWD_GRID", "LNBWD_TWO_STAGE", "LN_TICKET", "WGRAD_GROUP", "FLUSH_DELAY", "FLUSH_EVERY", "ROW_EXCLUSIVE",
-    "GROUP_ORDER", "GELU_TABLE",
+    "GROUP_ORDER", "GELU_TABLE", "ATTN_PROJ", "ATTN_QKV",
 #ifdef ETP_EXPERIMENTS
     "SKIP_LN", "SKIP_ATTN", "SKIP_WGRAD",
 #endif
@@ -276,6 +276,20 @@ int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t s) {
   ab.O = d->f.ctx; ab.ldo = d->f.ldc;          // the forward output (the streaming kernels need it)
   return attn_bwd_impl(d->f.dtype, d->f.heads, ab, d->f.P, d->dctx, d->ldd, d->dP, d->dQ, d->lddq, d->dK, d->lddk,
                        d->dV, d->lddv, d->f.alpha, d->d_sp_w, d->d_sp_b, (hipStream_t)s);
+}
+
+int etp_attn_bwd_proj(const etp_attn_bwd_desc* d, const void* w_out, int64_t ldw, etp_stream_t s) {
+  ETP_REQUIRE(d && d->f.Q && d->f.K && d->f.V && d->f.P && d->dctx && d->dQ && d->dK && d->dV && w_out, "null pointer");
+  ETP_REQUIRE(d->f.ldS >= d->f.Lk && d->f.ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");
+  AttnBuf ab = to_buf(d->f);
+  ab.O = d->f.ctx; ab.ldo = d->f.ldc;
+  const int H = d->f.heads * 64;
+  if (!(d->f.dtype == ETP_BF16 && attn_rows_ok(d->f.dtype, ab, d->f.ldc) && attn_rows_proj_ok(H, w_out, ldw))) {
+    set_error("etp_attn_bwd_proj: shape / dtype outside the fused kernel (bf16, Lq and Lk <= 128, heads*64 == 768)");
+    return ETP_ERR_INVALID;
+  }
+  return attn_rows_bwd(d->f.heads, ab, d->f.P, d->dctx, d->ldd, d->dQ, d->lddq, d->dK, d->lddk, d->dV, d->lddv, d->f.alpha, d->d_sp_w,
+                       d->d_sp_b, (hipStream_t)s, drop_none(), w_out, ldw, H);
 }
 
 int etp_text_embed_fwd(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,

@@ -98,8 +98,12 @@ int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, lo
 // kernels they keep lse (1 fp32 per query row) in the front of the P buffer and recompute the probabilities in backward.
 bool attn_rows_ok(int dt, const AttnBuf& a, long ldc);
 int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
+// proj_w != NULL (round 6): `dctx` is the gradient of the OUT-PROJECTION's output [B*Lq, proj_k] and the kernel computes
+// dctx_head = dctx . proj_w[0:proj_k, h*64 : h*64+64] itself (proj_w = the projection's weight [proj_k (out)][ldw]); see attn_rows.hip
+bool attn_rows_proj_ok(int Kp, const void* W, long ldw);
 int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,
-                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop);
+                  void* dV, long lddv, float alpha, float* d_sp_w, float* d_sp_b, hipStream_t st, Drop drop,
+                  const void* proj_w = nullptr, long proj_ldw = 0, int proj_k = 0);
 int drop_rows(int dtype, const void* src, void* dst, long rows, int Lk, int ldS, Drop drop, hipStream_t st);
 // fused single-kernel variants (attn.hip) for Lq, Lk <= 128
 bool attn_fused_ok(int dt, const AttnBuf& a, long ldc);

@@ -523,6 +523,21 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   return launch_gemm(dt, dt, 1, 1, k, a.B * nh, st);
 }
 
+// Input gradient of an attention block's out-projection + the attention backward.  Where the register-resident kernels run (bf16, both
+// axes <= 128: every R2R-CE shape) this is ONE launch -- the workgroup of a (batch, head) computes its own dctx tile from dY and the
+// projection's weight (attn_rows.hip, PROJ; switch ATTN_PROJ=0 restores the GEMM launch) -- otherwise the GEMM into `dctx` and the
+// attention backward reading it.
+static int attn_bwd_proj(const Ctx& c, const AttnBuf& a, const void* P, const void* dy, int wi, void* dctx, int M, void* dP, void* dQ,
+                         long lddq, void* dK, long lddk, void* dV, long lddv, float* d_sp_w, float* d_sp_b, Drop drop) {
+  const int H = c.H;
+  const void* W = c.pl->pw(wi);
+  const int epc = 8;
+  if (c.dt == ETP_BF16 && attn_rows_ok(c.dt, a, H) && attn_rows_proj_ok(H, W, H) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
+    return attn_rows_bwd(c.nh, a, P, dy, H, dQ, lddq, dK, lddk, dV, lddv, 0.125f, d_sp_w, d_sp_b, c.st, drop, W, H, H);
+  ETP_TRY(linear_dgrad(c, dy, H, wi, dctx, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
+  return attn_bwd_impl(c.dt, c.nh, a, P, dctx, H, dP, dQ, lddq, dK, lddk, dV, lddv, 0.125f, d_sp_w, d_sp_b, c.st, drop);
+}
+
 // ---- activations on the residual stream: fp32 tensor + (bf16 mode) a copy in the GEMM operand dtype -----------------
 struct Act { float* f; void* t; };
 static Act take_act(Bump& b, int dt, long n) {
@@ -624,13 +639,12 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
   ETP_TRY(ln_bwd_chain(c, g, s.s, s.st, p.ln_g, p.ln_b, nullptr, w.t1.f, lp2(c, w.t1, dh), M, dh, w.lnp));   // t1.f = ds, operand copy = ds * mask
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
-  ETP_TRY(linear_dgrad(c, ds, H, p.o_w, w.t2, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));            // t2 = dctx
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   a.Pd = s.Pd;
   a.O = s.ctx; a.ldo = H;
-  ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, s.P, w.t2, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
-                        offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, d_sp_w, d_sp_b, c.st, att(c, mode, layer, SITE_ATT_P)));
+  ETP_TRY(attn_bwd_proj(c, a, s.P, ds, p.o_w, w.t2, M, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,                    // t2 = dctx
+                        offs(w.dqkv, 2 * H, c.es), 3L * H, d_sp_w, d_sp_b, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
   return linear_dgrad_s(c, w.dqkv, 3 * H, p.qkv_w, g, M, 3 * H, H, w.t1.f);                                  // g = dx
 }
@@ -1095,13 +1109,12 @@ int etp_pano_bwd(etp_planner* p, const float* dout, const float* rgb, const floa
     // attention: x1 = x + dropout1(Wo attn(LN1(x)))
     const void* t2op = op2(c, w.t2, d1);
     ETP_TRY(linear_wgrad(c, t2op, H, t.ctx, H, q.out_w, q.out_b, M, H, H));
-    ETP_TRY(linear_dgrad(c, t2op, H, q.out_w, w.t1, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));           // t1 = dctx
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     a.Pd = t.Pd;
     a.O = t.ctx; a.ldo = H;
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, w.t1, H, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,
-                          offs(w.dqkv, 2 * H, c.es), 3L * H, 0.125f, nullptr, nullptr, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));
+    ETP_TRY(attn_bwd_proj(c, a, t.P, t2op, q.out_w, w.t1, M, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,               // t1 = dctx
+                          offs(w.dqkv, 2 * H, c.es), 3L * H, nullptr, nullptr, hid(c, MODE_PANO, l, SITE_ATT_P)));
     ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, t.a, H, q.in_w, q.in_b, M, 3 * H, H));
     ETP_TRY(linear_dgrad_s(c, w.dqkv, 3 * H, q.in_w, w.t1f, M, 3 * H, H, nullptr));                               // t1f = da
     gd = l > 0 ? hid(c, MODE_PANO, l - 1, SITE_FFN_O) : drop_none();
@@ -1438,7 +1451,6 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     ETP_TRY(ln_bwd_chain(c, g, t.cross.s, t.cross.st, q.xln_g, q.xln_b, nullptr, w.t1.f, lp2(c, w.t1, dx), Mg, dx, w.lnp));
     const void* dso = op2(c, w.t1, dx);
     ETP_TRY(linear_wgrad(c, dso, H, t.cross.ctx, H, q.xo_w, q.xo_b, Mg, H, H));
-    ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, w.t2, H, Mg, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     void* kv = cached ? kc.kv[l] : t.cross.kv;
     // with the cache, dK|dV of this step go straight to the caller's d_kv block of this layer (summed over the rollout's
     // steps by the caller, projected back to the text once by etp_nav_kv_bwd)
@@ -1446,8 +1458,8 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
     AttnBuf a{t.cross.q, (long)H, kv, 2L * H, offs(kv, H, c.es), 2L * H, B, G, L, ldL, txt_mask, 0, nullptr, nullptr, nullptr};
     a.Pd = t.cross.Pd;
     a.O = t.cross.ctx; a.ldo = H;
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.cross.P, w.t2, H, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
-                          0.125f, nullptr, nullptr, c.st, att(c, MODE_NAV, l, SITE_X_P)));
+    ETP_TRY(attn_bwd_proj(c, a, t.cross.P, dso, q.xo_w, w.t2, Mg, xc.dPx, xc.dq, H, dkv_out, 2L * H, offs(dkv_out, H, c.es), 2L * H,
+                          nullptr, nullptr, att(c, MODE_NAV, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, xc.dq, H, x.t, H, q.q_w, q.q_b, Mg, H, H));
     // layer 0 leaves dL/d(node embeddings) = dL/d(gmap_img_fts) in the caller's d_img directly
     ETP_TRY(linear_dgrad_s(c, xc.dq, H, q.q_w, l == 0 ? d_img : g, Mg, H, H, w.t1.f));
@@ -1685,13 +1697,12 @@ int etp_mlm_bwd(etp_planner* p, const float* txt, const uint8_t* txt_mask, const
     ETP_TRY(ln_bwd_chain(c, g, t.s, t.st, q.xln_g, q.xln_b, nullptr, wc.t1.f, lp2(c, wc.t1, dx), Mt, dx, wc.lnp));
     const void* dso = op2(c, wc.t1, dx);
     ETP_TRY(linear_wgrad(c, dso, H, t.ctx, H, q.xo_w, q.xo_b, Mt, H, H));
-    ETP_TRY(linear_dgrad(c, dso, H, q.xo_w, wc.t2, H, Mt, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
     AttnBuf a{t.q, (long)H, t.kv, 2L * H, offs(t.kv, H, c.es), 2L * H, B, L, G, ldG, gmask, 0, nullptr, nullptr, nullptr};
     a.Pd = t.Pd;
     a.O = t.ctx; a.ldo = H;
     void* dq = w.dq[l]; void* dkv = w.dkv[l];
-    ETP_TRY(attn_bwd_impl(c.dt, c.nh, a, t.P, wc.t2, H, w.dPx[l], dq, H, dkv, 2L * H, offs(dkv, H, c.es), 2L * H, 0.125f, nullptr,
-                          nullptr, c.st, att(c, MODE_MLM, l, SITE_X_P)));
+    ETP_TRY(attn_bwd_proj(c, a, t.P, dso, q.xo_w, wc.t2, Mt, w.dPx[l], dq, H, dkv, 2L * H, offs(dkv, H, c.es), 2L * H, nullptr,
+                          nullptr, att(c, MODE_MLM, l, SITE_X_P)));
     ETP_TRY(linear_wgrad(c, dq, H, x.t, H, q.q_w, q.q_b, Mt, H, H));
     ETP_TRY(linear_dgrad_s(c, dq, H, q.q_w, g, Mt, H, H, wc.t1.f));
     ETP_TRY(linear_wgrad(c, dkv, 2 * H, s.nodes.t, H, q.kv_w, q.kv_b, Mg, 2 * H, H));

@@ -132,6 +132,13 @@ typedef struct etp_attn_bwd_desc {
   float* d_sp_w; float* d_sp_b; /* accumulated, or NULL */
 } etp_attn_bwd_desc;
 int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t stream);
+/* The same backward with the OUT-PROJECTION's input gradient folded in (round 6): `d->dctx` is dL/d(dense output) [B*Lq, heads*64]
+ * (row stride ldd) of BertSelfOutput.dense / BertOutAttention's output dense / MHA out_proj (vilmodel_cmt.py:150-154, 325-352;
+ * common/transformer.py:138-142), `w_out` that projection's weight [heads*64 (out)][ldw] in the operand dtype; each (batch, head)
+ * workgroup forms dctx[:, h*64:h*64+64] = dctx_in . w_out[:, h*64:h*64+64] itself instead of reading the result of a GEMM launch.
+ * bf16 with both axes <= 128 and heads*64 == 768; anything else returns ETP_ERR_INVALID and the caller issues
+ * etp_gemm + etp_attn_bwd.  Results equal that pair's (the tile is rounded to bf16 exactly where the GEMM stored it). */
+int etp_attn_bwd_proj(const etp_attn_bwd_desc* d, const void* w_out, int64_t ldw, etp_stream_t stream);
 
 /* Residual-stream convention: tensors that flow from one LayerNorm / residual add to the next are ALWAYS fp32 (as under
  * the reference's autocast, where LayerNorm and residual adds stay fp32); `*_lp` arguments are optional copies in the GEMM

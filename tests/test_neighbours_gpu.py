@@ -279,7 +279,7 @@ def test_default_mask_matches_the_header():
     bits = {k: v for k, v in re.findall(r"ROWF_(\w+) = (\d+)", src) if k != "DEFAULT"}
     assert {k.lower(): int(v) for k, v in bits.items()} == {"pano_bwd": 1, "gmap_bwd": 2, "text_bwd": 4, "sap_bwd": 8, "ln_bwd": 16,
                                                             "ln_fwd": 32, "attn_bwd": 64, "attn_fwd": 128}
-    dflt = re.search(r"ROWF_DEFAULT = ([^\n}]+)", src).group(1).strip()
+    dflt = re.search(r"^\s*ROWF_DEFAULT = ([^\n}]+)", src, re.M).group(1).strip()       # the enum line, not the comment above it
     val = 0
     for term in dflt.split("|"):
         term = term.strip()

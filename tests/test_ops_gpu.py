@@ -583,3 +583,102 @@ def test_layer_norm_backward_two_stage(dtype, M):
     assert (dxt.float() - (xr.grad + add)).abs().max().item() <= tol(dtype, 4)
     assert (dg - dg0 - gr.grad).abs().max().item() < 2e-4 * math.sqrt(M)
     assert (db - db0 - br.grad).abs().max().item() < 2e-4 * math.sqrt(M)
+
+
+@pytest.mark.parametrize("with_dist", [False, True])
+@pytest.mark.parametrize("Lq,Lk", [(80, 80), (16, 80), (36, 36), (9, 20), (128, 128), (113, 16), (16, 16), (1, 1)])
+def test_attention_bwd_with_fused_out_projection(Lq, Lk, with_dist):
+    """etp_attn_bwd_proj (round 6; attn_rows.hip PROJ): the (batch, head) workgroup forms its dctx tile = dY . W_out[:, head] itself.
+    Checked against the pair it replaces -- etp_gemm (dgrad of BertSelfOutput.dense, vilmodel_cmt.py:150-154) + etp_attn_bwd -- on
+    the same operands: the tile is rounded to bf16 where the GEMM stored it, so the two differ only through the order of the fp32
+    sums (an occasional bf16 ulp of dctx), and against torch autograd in fp32."""
+    torch.manual_seed(11)
+    t = torch.bfloat16
+    B, nh, dh = 3, 12, 64
+    H = nh * dh
+    ldS = (Lk + 7) // 8 * 8
+    q = torch.randn(B * Lq, H, device=DEV).to(t)
+    kv = torch.randn(B * Lk, 2 * H, device=DEV).to(t)
+    km = torch.rand(B, Lk, device=DEV) > 0.2
+    km[:, 0] = True
+    dist = torch.rand(B, Lq, Lk, device=DEV)
+    w = torch.tensor([0.3], device=DEV); b0 = torch.tensor([0.1], device=DEV)
+    P = torch.empty(B, nh, Lq, ldS, device=DEV, dtype=t)
+    ctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
+    d = AttnDesc()
+    d.dtype, d.B, d.heads, d.Lq, d.Lk, d.ldS = _lib.ETP_BF16, B, nh, Lq, Lk, ldS
+    d.Q, d.ldq = q.data_ptr(), H
+    d.K, d.ldk = kv.data_ptr(), 2 * H
+    d.V, d.ldv = kv.data_ptr() + H * 2, 2 * H
+    d.P, d.ctx, d.ldc = P.data_ptr(), ctx.data_ptr(), H
+    d.keymask, d.mask_mode = km.data_ptr(), 0
+    if with_dist:
+        d.dist, d.sp_w, d.sp_b = dist.data_ptr(), w.data_ptr(), b0.data_ptr()
+    d.alpha = 0.125
+    check(L().etp_attn_fwd(ctypes.byref(d), stream()), "attn_fwd")
+    dy = (torch.randn(B * Lq, H, device=DEV) * 0.5).to(t)
+    Wo = (torch.randn(H, H, device=DEV) / math.sqrt(H)).to(t)           # [out][in], as nn.Linear stores it
+    dctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
+    run_gemm(dy, Wo, dctx, B * Lq, H, H, 0, 1, _lib.ETP_BF16)           # dctx = dy . Wo   (B operand [reduction][N])
+    ref_dctx = (dy.float() @ Wo.float())
+    assert (dctx.float() - ref_dctx).abs().max().item() <= 2e-2
+
+    def run(fused):
+        bd = AttnBwdDesc()
+        bd.f = d
+        dP = torch.empty_like(P); dq = torch.full_like(q, float("nan")); dkv = torch.full_like(kv, float("nan"))
+        dw = torch.zeros(1, device=DEV); db = torch.zeros(1, device=DEV)
+        bd.dctx, bd.ldd, bd.dP = (dy if fused else dctx).data_ptr(), H, dP.data_ptr()
+        bd.dQ, bd.lddq = dq.data_ptr(), H
+        bd.dK, bd.lddk = dkv.data_ptr(), 2 * H
+        bd.dV, bd.lddv = dkv.data_ptr() + H * 2, 2 * H
+        if with_dist:
+            bd.d_sp_w, bd.d_sp_b = dw.data_ptr(), db.data_ptr()
+        if fused:
+            check(L().etp_attn_bwd_proj(ctypes.byref(bd), Wo.data_ptr(), H, stream()), "attn_bwd_proj")
+        else:
+            check(L().etp_attn_bwd(ctypes.byref(bd), stream()), "attn_bwd")
+        torch.cuda.synchronize()
+        return dq.float(), dkv.float(), dw.item(), db.item()
+
+    dq_f, dkv_f, dw_f, db_f = run(True)
+    dq_u, dkv_u, dw_u, db_u = run(False)
+    assert torch.isfinite(dq_f).all() and torch.isfinite(dkv_f).all()
+    # against the unfused pair: a handful of dctx elements may sit one bf16 ulp apart
+    for a, b_ in ((dq_f, dq_u), (dkv_f, dkv_u)):
+        scale = b_.abs().max().item() + 1e-6
+        assert (a - b_).abs().max().item() <= 2e-2 * scale, ((a - b_).abs().max().item(), scale)
+        assert (a - b_).norm().item() <= 2e-3 * b_.norm().item() + 1e-6
+    if with_dist:
+        assert abs(dw_f - dw_u) <= 2e-2 * (abs(dw_u) + 1.0) and abs(db_f - db_u) <= 2e-2 * (abs(db_u) + 1.0)
+    # against torch autograd (fp32 math on the bf16 operands, dctx rounded to bf16 as both paths do)
+    qr = q.float().requires_grad_(True); kvr = kv.float().requires_grad_(True)
+    qh = qr.view(B, Lq, nh, dh).permute(0, 2, 1, 3)
+    kh = kvr[:, :H].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    vh = kvr[:, H:].reshape(B, Lk, nh, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / 8.0 + (1.0 - km.float())[:, None, None, :] * -10000.0
+    if with_dist:
+        s = s + (w * dist + b0)[:, None]
+    ctx_ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Lq, H)
+    ctx_ref.backward(ref_dctx.to(t).float())
+    assert (dq_f - qr.grad).abs().max().item() <= tol(_lib.ETP_BF16, 3) * max(1.0, qr.grad.abs().max().item())
+    assert (dkv_f - kvr.grad).abs().max().item() <= tol(_lib.ETP_BF16, 3) * max(1.0, kvr.grad.abs().max().item())
+
+
+def test_attention_bwd_proj_refuses_what_the_fused_kernel_does_not_take():
+    t = torch.bfloat16
+    B, nh, Lq, Lk = 1, 4, 16, 16                                          # heads * 64 = 256: not the fused reduction length
+    H = nh * 64
+    q = torch.randn(B * Lq, H, device=DEV).to(t); kv = torch.randn(B * Lk, 2 * H, device=DEV).to(t)
+    P = torch.empty(B, nh, Lq, 16, device=DEV, dtype=t); ctx = torch.empty(B * Lq, H, device=DEV, dtype=t)
+    d = AttnDesc()
+    d.dtype, d.B, d.heads, d.Lq, d.Lk, d.ldS = _lib.ETP_BF16, B, nh, Lq, Lk, 16
+    d.Q, d.ldq, d.K, d.ldk, d.V, d.ldv = q.data_ptr(), H, kv.data_ptr(), 2 * H, kv.data_ptr() + 2 * H, 2 * H
+    d.P, d.ctx, d.ldc, d.alpha = P.data_ptr(), ctx.data_ptr(), H, 0.125
+    bd = AttnBwdDesc()
+    bd.f = d
+    dq = torch.empty_like(q); dkv = torch.empty_like(kv); dP = torch.empty_like(P)
+    bd.dctx, bd.ldd, bd.dP = ctx.data_ptr(), H, dP.data_ptr()
+    bd.dQ, bd.lddq, bd.dK, bd.lddk, bd.dV, bd.lddv = dq.data_ptr(), H, dkv.data_ptr(), 2 * H, dkv.data_ptr() + 2 * H, 2 * H
+    Wo = torch.randn(H, H, device=DEV).to(t)
+    assert L().etp_attn_bwd_proj(ctypes.byref(bd), Wo.data_ptr(), H, stream()) != 0
