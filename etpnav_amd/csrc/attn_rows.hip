@@ -66,6 +66,10 @@ struct RowArgs {
   // PROJ backward (rows_bwd_kernel<.., true>): dO is not read from memory but computed in the kernel's prologue as
   // dO[b, q, h*64 : h*64+64] = dY[b*Lq + q, 0:Kp] . W[0:Kp, h*64 : h*64+64]   (dY = the `dO` pointer with row stride ldd)
   const bf16_t* W; long ldw; int Kp;
+  // QKV forward (rows_fwd_kernel<.., true>): Q / K / V are not read but computed in the kernel's prologue from the block's input rows
+  //   [Q | K | V][b, l, h*64 : h*64+64] = X[b*L + l, 0:Kp] . Wqkv[sec*H + h*64 + (0..63), 0:Kp]^T + bqkv   (sec = 0, 1, 2; H = nh*64)
+  // and WRITTEN to the Q / K / V pointers (the backward's stash).  X = the LayerNorm output in the operand dtype, W reuses `W` above.
+  const bf16_t* X; long ldx; const float* bqkv;
 };
 
 __device__ __forceinline__ f32x4_t mma32(const uint4& a, const uint4& b, f32x4_t c) {
@@ -173,6 +177,35 @@ __device__ __forceinline__ void proj_commit_w(char* slab, const uint4 (&w)[WN], 
   }
 }
 
+// ---- pieces of the fused QKV projection (rows_fwd_kernel<.., QKV = true>) ----
+// one [192 rows][64 k] slab of Wqkv (rows sec*H + h*64 + 0..63 for sec = 0, 1, 2) -> registers: 1536 16-byte pieces
+template <int WN>
+__device__ __forceinline__ void qkv_load_w(uint4 (&w)[WN], const bf16_t* __restrict__ W, long ldw, int Hh, int h, int s, int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int p = tid + j * nthr, row = p >> 3;
+    w[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (p < 192 * 8) w[j] = *reinterpret_cast<const uint4*>(W + (long)((row >> 6) * Hh + h * 64 + (row & 63)) * ldw + s * 64 + (p & 7) * 8);
+  }
+}
+__device__ __forceinline__ void qkv_load_x(uint4 (&y)[2], const bf16_t* __restrict__ Xr, int s, bool computing, bool ok) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (computing) v = *reinterpret_cast<const uint4*>(Xr + s * 64 + 32 * u);
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    y[u] = v;
+  }
+}
+template <int WN>
+__device__ __forceinline__ void qkv_commit_w(char* slab, const uint4 (&w)[WN], int tid, int nthr) {
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int p = tid + j * nthr;
+    if (p < 192 * 8) *reinterpret_cast<uint4*>(slab + tile_off(p >> 3, p & 7)) = w[j];
+  }
+}
+
 __device__ __forceinline__ float key_term(const uint8_t* km, int col, int Lk, int mask_mode) {
   if (col >= Lk) return -INFINITY;
   if (km && !km[col]) return mask_mode ? -INFINITY : -10000.0f;
@@ -181,7 +214,30 @@ __device__ __forceinline__ float key_term(const uint8_t* km, int col, int Lk, in
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: grid = batch*heads, block = 64 * max(4, ceil(Lq/16)) threads; NKT = ceil(Lk/16)
-template <int NKT, bool HAS_DIST>
+// QKV = true (round 6, self-attention only: Lq == Lk, Q / K / V rows of one token block): the QKV projection (BertSelfAttention.query /
+// key / value, vilmodel_cmt.py:108-110,115-117; MHA in_proj, common/transformer.py:138) is no longer a GEMM launch whose [B*L, 3H]
+// result this kernel reads back.  The workgroup of (batch b, head h) computes its own 16*NKT x 192 tile first:
+//   * C^T = W_h X^T with the k=32 MFMA: A operand = 8 consecutive k of a weight row from a [192 rows][64 k] slab in LDS (the three
+//     64-row blocks sec*H + h*64 of Wqkv; plain ds_read_b128 in the swizzled tile layout), B operand = 8 consecutive k of the
+//     wavefront's OWN 16 token rows straight from global; 12 accumulators (16 features x 16 tokens each) per wavefront;
+//   * slabs travel global -> registers -> LDS one slab ahead of their use, ring of 2 x 24 KB that ALIASES the K / V tiles and
+//     the output strips (only needed afterwards);
+//   * + bias, rounded to bf16 exactly where the GEMM epilogue stored it; Q / K / V rows go to the stash through the wave's strip as
+//     full 128-byte lines, K / V also into the LDS tiles, Q straight into the B-operand registers of S^T = K Q^T.
+constexpr int QKV_SLAB_K = 64;                   // k per slab: [192][64] bf16 = 24 KB
+constexpr int QKV_RING = 2;
+constexpr int QKV_SLAB_BYTES = 192 * TQ;
+// LDS of the forward kernel: K / V tiles, key terms, one output strip per wavefront; QKV: the ring aliases all of that and the head's
+// 192 bias values sit behind whichever is longer
+__host__ __device__ constexpr int rows_fwd_bias_off(int BKV, int nwaves) {
+  const int base = 2 * BKV * TQ + BKV * 4 + nwaves * 16 * TP, ring = QKV_RING * QKV_SLAB_BYTES;
+  return base < ring ? ring : base;
+}
+__host__ __device__ constexpr int rows_fwd_lds(int BKV, int nwaves, bool qkv) {
+  return qkv ? rows_fwd_bias_off(BKV, nwaves) + 192 * 4 : 2 * BKV * TQ + BKV * 4 + nwaves * 16 * TP;
+}
+
+template <int NKT, bool HAS_DIST, bool QKV>
 __global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
   constexpr int BKV = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,17 +246,78 @@ __global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
   char* strip = smem + 2 * BKV * TQ + BKV * 4 + wave * 16 * TP;
-
-  TileRegs<BKV> rk, rv;
-  tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
-  tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
-  // this wavefront's 16 queries go straight into the B-operand registers (rows past Lq repeat the last one; never stored)
   const int q = wave * 16 + i, qc = min(q, a.Lq - 1);
-  const bf16_t* Qr = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * 64 + g * 8;
-  const uint4 qf0 = *reinterpret_cast<const uint4*>(Qr), qf1 = *reinterpret_cast<const uint4*>(Qr + 32);
-  if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
-  tile_commit<BKV>(kt, rk, BKV, tid, nthr);
-  tile_commit<BKV>(vt, rv, BKV, tid, nthr);
+  uint4 qf0, qf1;
+
+  if constexpr (!QKV) {
+    TileRegs<BKV> rk, rv;
+    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
+    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
+    // this wavefront's 16 queries go straight into the B-operand registers (rows past Lq repeat the last one; never stored)
+    const bf16_t* Qr = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * 64 + g * 8;
+    qf0 = *reinterpret_cast<const uint4*>(Qr); qf1 = *reinterpret_cast<const uint4*>(Qr + 32);
+    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+    tile_commit<BKV>(kt, rk, BKV, tid, nthr);
+    tile_commit<BKV>(vt, rv, BKV, tid, nthr);
+  } else {
+    constexpr int NS = PROJ_K / QKV_SLAB_K, WN = 6;                 // WN * 256 threads >= 1536 16-byte pieces of a slab
+    const int Hh = a.nh * 64;
+    float* bias_l = reinterpret_cast<float*>(smem + rows_fwd_bias_off(BKV, nthr >> 6));
+    const bool computing = wave < NKT, tok_ok = q < a.Lq;
+    const bf16_t* Xr = a.X + ((long)b * a.Lq + qc) * a.ldx + g * 8;
+    uint4 wr[WN], yb[2][2];
+    f32x4_t acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (tid < 192) bias_l[tid] = a.bqkv ? a.bqkv[(tid >> 6) * Hh + h * 64 + (tid & 63)] : 0.f;
+    qkv_load_w<WN>(wr, a.W, a.ldw, Hh, h, 0, tid, nthr); qkv_load_x(yb[0], Xr, 0, computing, tok_ok);
+    qkv_commit_w<WN>(smem, wr, tid, nthr);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) { qkv_load_w<WN>(wr, a.W, a.ldw, Hh, h, s + 1, tid, nthr); qkv_load_x(yb[(s + 1) & 1], Xr, s + 1, computing, tok_ok); }
+      if (computing) {
+        const char* slab = smem + (s & 1) * QKV_SLAB_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int t = 0; t < 12; ++t) acc[t] = mma32(frag(slab, 16 * t, u, lane), yb[s & 1][u], acc[t]);
+      }
+      if (s + 1 < NS) qkv_commit_w<WN>(smem + ((s + 1) & 1) * QKV_SLAB_BYTES, wr, tid, nthr);
+      __syncthreads();                              // after the last slab: the ring is dead, K / V tiles and strips may land on it
+    }
+    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+    if (computing) {
+      const int rows_valid = a.Lq - wave * 16;
+#pragma unroll
+      for (int sec = 0; sec < 3; ++sec) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 bb = *reinterpret_cast<const float4*>(bias_l + sec * 64 + 16 * t + 4 * g);
+          const f32x4_t c = acc[sec * 4 + t];
+          *reinterpret_cast<uint2*>(strip + i * TP + (16 * t + 4 * g) * 2) =
+              make_uint2(pack_bf16(c[0] + bb.x, c[1] + bb.y), pack_bf16(c[2] + bb.z, c[3] + bb.w));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sec == 0) {
+          qf0 = *reinterpret_cast<const uint4*>(strip + i * TP + g * 16);
+          qf1 = *reinterpret_cast<const uint4*>(strip + i * TP + 64 + g * 16);
+        }
+        bf16_t* dst = const_cast<bf16_t*>(sec == 0 ? a.Q : sec == 1 ? a.K : a.V);
+        const long ld = sec == 0 ? a.ldq : sec == 1 ? a.ldk : a.ldv;
+        char* tile = sec == 1 ? kt : vt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = lane + 64 * j, row = c >> 3, part = c & 7;
+          uint4 v = *reinterpret_cast<const uint4*>(strip + row * TP + part * 16);
+          if (row < rows_valid) *reinterpret_cast<uint4*>(dst + ((long)b * a.Lq + wave * 16 + row) * ld + h * 64 + part * 8) = v;
+          else v = make_uint4(0u, 0u, 0u, 0u);
+          if (sec > 0) *reinterpret_cast<uint4*>(tile + tile_off(wave * 16 + row, part)) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
   __syncthreads();
   if (wave * 16 >= a.Lq) return;               // helper wavefronts of a short query axis only staged K / V
 
@@ -503,11 +620,16 @@ __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
   }
 }
 
-template <int NKT, bool HAS_DIST> int launch_rows_fwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
-  const int smem = 2 * NKT * 16 * TQ + NKT * 16 * 4 + (threads / 64) * 16 * TP;
-  ETP_LAUNCH_ROW(ROWF_ATTN_FWD, (rows_fwd_kernel<NKT, HAS_DIST>), dim3(blocks), dim3(threads), smem, st, k);
-  ETP_CHECK_LAUNCH("attn_rows_fwd");
+template <int NKT, bool HAS_DIST, bool QKV> int launch_rows_fwd_q(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  const int smem = rows_fwd_lds(NKT * 16, threads / 64, QKV);
+  auto kern = rows_fwd_kernel<NKT, HAS_DIST, QKV>;
+  if (smem > 64 * 1024) ETP_CHECK_HIP(ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem));
+  ETP_LAUNCH_ROW(ROWF_ATTN_FWD, kern, dim3(blocks), dim3(threads), smem, st, k);
+  ETP_CHECK_LAUNCH(QKV ? "attn_rows_fwd_qkv" : "attn_rows_fwd");
   return ETP_OK;
+}
+template <int NKT, bool HAS_DIST> int launch_rows_fwd(const RowArgs& k, int blocks, int threads, hipStream_t st) {
+  return k.X ? launch_rows_fwd_q<NKT, HAS_DIST, true>(k, blocks, threads, st) : launch_rows_fwd_q<NKT, HAS_DIST, false>(k, blocks, threads, st);
 }
 template <int NKT, bool HAS_DIST, bool PROJ> int launch_rows_bwd_p(const RowArgs& k, int blocks, int threads, hipStream_t st) {
   const BwdLds L(((k.Lq + 15) >> 4) * 16, NKT * 16, PROJ);
@@ -580,11 +702,21 @@ static bool skip_attn(const char* what) {
 #endif
 }
 
-int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop) {
+// fused QKV projection: self-attention blocks (one token axis) of a 768-wide model
+bool attn_rows_qkv_ok(int nh, const AttnBuf& a, const void* X, long ldx, const void* W, long ldw) {
+  return nh * 64 == PROJ_K && a.Lq == a.Lk && ldx % 8 == 0 && ldw % 8 == 0 &&
+         ((uintptr_t)X | (uintptr_t)W) % 16 == 0;
+}
+
+int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop, const void* qkv_x,
+                  long qkv_ldx, const void* qkv_w, long qkv_ldw, const float* qkv_b) {
   ETP_REQUIRE((uintptr_t)ctx % 16 == 0, "ctx must be 16-byte aligned");
+  ETP_REQUIRE(qkv_x == nullptr || attn_rows_qkv_ok(nh, a, qkv_x, qkv_ldx, qkv_w, qkv_ldw), "fused QKV projection: unsupported shape / alignment");
   if (skip_attn("fwd")) return ETP_OK;
   RowArgs k = make_row_args(nh, a, P, alpha, drop);
   k.ctx = (bf16_t*)ctx; k.ldc = ldc;
+  k.X = (const bf16_t*)qkv_x; k.ldx = qkv_ldx; k.bqkv = qkv_b;
+  if (qkv_x) { k.W = (const bf16_t*)qkv_w; k.ldw = qkv_ldw; k.Kp = nh * 64; }
   const int nqt = (a.Lq + 15) / 16, nkt = (a.Lk + 15) / 16;
   const int threads = 64 * (nqt > 4 ? nqt : 4);
   return a.dist ? dispatch_fwd<true>(nkt, k, a.B * nh, threads, st) : dispatch_fwd<false>(nkt, k, a.B * nh, threads, st);
@@ -592,7 +724,7 @@ int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float 
 
 // the fused form is built for the reduction length 768 (BERT-base / XLM-R-base hidden size: the reference's only planners)
 bool attn_rows_proj_ok(int Kp, const void* W, long ldw) {
-  return opt_on(OPT_ATTN_PROJ, true) && Kp == PROJ_K && ldw % 8 == 0 && (uintptr_t)W % 16 == 0;
+  return Kp == PROJ_K && ldw % 8 == 0 && (uintptr_t)W % 16 == 0;
 }
 
 int attn_rows_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, long ldd, void* dQ, long lddq, void* dK, long lddk,

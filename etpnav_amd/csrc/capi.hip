@@ -48,6 +48,19 @@ int cu_lds_bytes() {
   return v;
 }
 
+int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+  v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 unsigned row_launch_lds(const void* kern, int family, unsigned smem) {
   if (!(opt_int(OPT_ROW_EXCLUSIVE, ROWF_DEFAULT) & family)) return smem;
   static std::mutex mu;
@@ -278,6 +291,16 @@ int etp_attn_bwd(const etp_attn_bwd_desc* d, etp_stream_t s) {
                        d->dV, d->lddv, d->f.alpha, d->d_sp_w, d->d_sp_b, (hipStream_t)s);
 }
 
+int etp_attn_fwd_qkv(const etp_attn_desc* d, const void* x, int64_t ldx, const void* w_qkv, int64_t ldw, const float* b_qkv, etp_stream_t s) {
+  ETP_REQUIRE(d && d->Q && d->K && d->V && d->P && d->ctx && x && w_qkv, "null pointer");
+  ETP_REQUIRE(d->ldS >= d->Lk && d->ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");
+  const AttnBuf ab = to_buf(*d);
+  if (!(d->dtype == ETP_BF16 && attn_rows_ok(d->dtype, ab, d->ldc) && attn_rows_qkv_ok(d->heads, ab, x, ldx, w_qkv, ldw))) {
+    set_error("etp_attn_fwd_qkv: shape / dtype outside the fused kernel (bf16 self-attention, L <= 128, heads*64 == 768)");
+    return ETP_ERR_INVALID;
+  }
+  return attn_rows_fwd(d->heads, ab, d->P, d->ctx, d->ldc, d->alpha, (hipStream_t)s, drop_none(), x, ldx, w_qkv, ldw, b_qkv);
+}
 int etp_attn_bwd_proj(const etp_attn_bwd_desc* d, const void* w_out, int64_t ldw, etp_stream_t s) {
   ETP_REQUIRE(d && d->f.Q && d->f.K && d->f.V && d->f.P && d->dctx && d->dQ && d->dK && d->dV && w_out, "null pointer");
   ETP_REQUIRE(d->f.ldS >= d->f.Lk && d->f.ldS % 8 == 0, "ldS must be a multiple of 8 and >= Lk");

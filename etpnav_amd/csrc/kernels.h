@@ -97,7 +97,12 @@ int attn_flash_bwd(int nh, const AttnBuf& a, const void* P, const void* dctx, lo
 // register-resident kernels (attn_rows.hip): bf16, Lq and Lk <= 128 -- every R2R-CE shape of the planner.  Like the streaming
 // kernels they keep lse (1 fp32 per query row) in the front of the P buffer and recompute the probabilities in backward.
 bool attn_rows_ok(int dt, const AttnBuf& a, long ldc);
-int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop);
+// qkv_x != NULL (round 6, self-attention): Q / K / V (a.Q / a.K / a.V, written) = qkv_x[B*L, nh*64] . qkv_w[3*nh*64][ldw]^T + qkv_b are
+// computed in the kernel's prologue instead of read; see attn_rows.hip
+bool attn_rows_qkv_ok(int nh, const AttnBuf& a, const void* X, long ldx, const void* W, long ldw);
+int attn_rows_fwd(int nh, const AttnBuf& a, void* P, void* ctx, long ldc, float alpha, hipStream_t st, Drop drop,
+                  const void* qkv_x = nullptr, long qkv_ldx = 0, const void* qkv_w = nullptr, long qkv_ldw = 0,
+                  const float* qkv_b = nullptr);
 // proj_w != NULL (round 6): `dctx` is the gradient of the OUT-PROJECTION's output [B*Lq, proj_k] and the kernel computes
 // dctx_head = dctx . proj_w[0:proj_k, h*64 : h*64+64] itself (proj_w = the projection's weight [proj_k (out)][ldw]); see attn_rows.hip
 bool attn_rows_proj_ok(int Kp, const void* W, long ldw);

@@ -32,6 +32,7 @@ hipError_t ensure_dyn_lds(const void* kern, int bytes);
 // LDS bytes of one CU of the current device (hipDeviceProp.maxSharedMemoryPerMultiProcessor; 160 KB on gfx950): what a launch asks
 // for when it must have the CU to itself
 int cu_lds_bytes();
+int cu_count();                                              // compute units of the current device (256 on MI355X)
 // Row-kernel families that can be launched with the CU to themselves (a workgroup that asks for the CU's whole LDS
 // shares it with no other kernel's wavefronts).  The switch ROW_EXCLUSIVE is a bit mask over these families; default
 // ROWF_DEFAULT = none since round 6: the corruption the exclusivity of round 5 papered over was one packed-fp32 instruction form

@@ -22,8 +22,8 @@ enum Opt {
   OPT_ROW_EXCLUSIVE,    // 0: the row kernels of DESIGN.md §3.6 launch WITHOUT the CU-exclusive LDS request (neighbour-matrix test only)
   OPT_GROUP_ORDER,      // grouped weight gradients: 0 = contiguous XCD chunks (round 2-5), 1 = panel-major order inside an XCD
   OPT_GELU_TABLE,       // 0: bf16-mode GELU epilogues evaluate erf instead of the LDS table
-  OPT_ATTN_PROJ,        // 0: the out-projection dgrad stays a GEMM launch in front of the register-resident attention backward
-  OPT_ATTN_QKV,         // 0: the QKV projection stays a GEMM launch in front of the register-resident attention forward
+  OPT_ATTN_PROJ,        // out-projection dgrad folded into the register-resident attention backward: unset = when batch*heads <= CUs, 0 never, 1 always
+  OPT_ATTN_QKV,         // QKV projection folded into the register-resident self-attention forward: unset / 0 never (measured slower), 1 always
 #ifdef ETP_EXPERIMENTS
   OPT_SKIP_LN, OPT_SKIP_ATTN, OPT_SKIP_WGRAD,
 #endif

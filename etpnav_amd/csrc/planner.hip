@@ -523,19 +523,48 @@ int attn_bwd_impl(int dt, int nh, const AttnBuf& a, const void* P, const void* d
   return launch_gemm(dt, dt, 1, 1, k, a.B * nh, st);
 }
 
+// When to fold a projection into the register-resident attention kernels (switches ATTN_PROJ / ATTN_QKV: 0 = never, 1 = always, unset =
+// the rule below).  Measured (profiles/r06_attn_fusion.txt): a fused prologue works on a smaller tile than the GEMM it replaces
+// (16*n x 64 rows x columns per workgroup against 128 x 64 / 128 x 128), i.e. it pulls more operand bytes per CU through the ~35 B/clk
+// L2 -> CU feed.
+//   * out-projection dgrad in the backward (96 KB of weights + the block's dY rows per workgroup): with ONE workgroup per CU
+//     (batch * heads <= CUs: configs 4 and 5, the SAP unit, rollout steps of <= 21 episodes) it wins about the launch it removes
+//     (config 5: -1.0 ... -1.4 % of the step); with two per CU (config 2: 384 workgroups of five wavefronts at 158 registers) the
+//     doubled feed costs more than the launch saved (text 80 x 80: 32.8 us against 22.2 us for the pair; step +1.7 %).  Rule: by grid.
+//   * QKV projection in the forward (three times the weights: 288 KB + the block's rows per workgroup): slower than the launch pair at
+//     every grid size measured (B = 8: 17.4 against 14.2 us, B = 32: 33.6 against 24.0 us; config 5 step +1.4 %).  Rule: off.
+static bool fold_projection(Opt o, int workgroups, bool by_grid) {
+  const char* s = opt_str(o);
+  if (s) return s[0] != '0';
+  return by_grid && workgroups <= cu_count();
+}
+
 // Input gradient of an attention block's out-projection + the attention backward.  Where the register-resident kernels run (bf16, both
-// axes <= 128: every R2R-CE shape) this is ONE launch -- the workgroup of a (batch, head) computes its own dctx tile from dY and the
-// projection's weight (attn_rows.hip, PROJ; switch ATTN_PROJ=0 restores the GEMM launch) -- otherwise the GEMM into `dctx` and the
+// axes <= 128: every R2R-CE shape) AND the grid leaves every workgroup a CU of its own this is ONE launch -- the workgroup of a (batch,
+// head) computes its own dctx tile from dY and the projection's weight (attn_rows.hip, PROJ) -- otherwise the GEMM into `dctx` and the
 // attention backward reading it.
 static int attn_bwd_proj(const Ctx& c, const AttnBuf& a, const void* P, const void* dy, int wi, void* dctx, int M, void* dP, void* dQ,
                          long lddq, void* dK, long lddk, void* dV, long lddv, float* d_sp_w, float* d_sp_b, Drop drop) {
   const int H = c.H;
   const void* W = c.pl->pw(wi);
   const int epc = 8;
-  if (c.dt == ETP_BF16 && attn_rows_ok(c.dt, a, H) && attn_rows_proj_ok(H, W, H) && lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
+  if (c.dt == ETP_BF16 && fold_projection(OPT_ATTN_PROJ, a.B * c.nh, true) && attn_rows_ok(c.dt, a, H) && attn_rows_proj_ok(H, W, H) &&
+      lddq % epc == 0 && lddk % epc == 0 && lddv % epc == 0)
     return attn_rows_bwd(c.nh, a, P, dy, H, dQ, lddq, dK, lddk, dV, lddv, 0.125f, d_sp_w, d_sp_b, c.st, drop, W, H, H);
   ETP_TRY(linear_dgrad(c, dy, H, wi, dctx, H, M, H, H, ETP_ACT_NONE, nullptr, 0, nullptr, 0));
   return attn_bwd_impl(c.dt, c.nh, a, P, dctx, H, dP, dQ, lddq, dK, lddk, dV, lddv, 0.125f, d_sp_w, d_sp_b, c.st, drop);
+}
+
+// QKV projection + attention of a SELF-attention block: the GEMM into `qkv` and the attention reading it.  With ATTN_QKV=1 (bf16, axis
+// <= 128, hidden 768) ONE launch instead -- the workgroup of a (batch, head) projects its own Q / K / V rows from the block's input and
+// writes them to the stash (attn_rows.hip, QKV) -- built and parity-tested in round 6, measured slower than the pair, off by default.
+static int attn_fwd_qkv(const Ctx& c, const AttnBuf& a, void* P, void* ctx, const void* x, int wi, int bi, void* qkv, int M, Drop drop) {
+  const int H = c.H;
+  const void* W = c.pl->pw(wi);
+  if (c.dt == ETP_BF16 && fold_projection(OPT_ATTN_QKV, a.B * c.nh, false) && attn_rows_ok(c.dt, a, H) && attn_rows_qkv_ok(c.nh, a, x, H, W, H))
+    return attn_rows_fwd(c.nh, a, P, ctx, H, 0.125f, c.st, drop, x, H, W, H, bi >= 0 ? c.pl->pf(bi) : nullptr);
+  ETP_TRY(linear_fwd(c, x, H, wi, bi, qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
+  return attn_fwd_impl(c.dt, c.nh, a, P, ctx, H, 0.125f, c.st, drop);
 }
 
 // ---- activations on the residual stream: fp32 tensor + (bf16 mode) a copy in the GEMM operand dtype -----------------
@@ -621,11 +650,10 @@ static int ln_bwd_chain(const Ctx& c, const float* dy, const float* x, const flo
 static int self_att_fwd(const Ctx& c, const AttnP& p, const Act& x, SelfAttStash& s, int Bn, int L, const uint8_t* keymask,
                         const float* dist, const float* sp_w, const float* sp_b, float eps, int mode, int layer) {
   const int H = c.H, M = Bn * L;
-  ETP_TRY(linear_fwd(c, x.t, H, p.qkv_w, p.qkv_b, s.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   a.Pd = s.Pd;
-  ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, s.P, s.ctx, H, 0.125f, c.st, att(c, mode, layer, SITE_ATT_P)));
+  ETP_TRY(attn_fwd_qkv(c, a, s.P, s.ctx, x.t, p.qkv_w, p.qkv_b, s.qkv, M, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_fwd_s(c, s.ctx, H, p.o_w, p.o_b, s.s, M, H, H, x.f, hid(c, mode, layer, SITE_ATT_O)));
   return ln_fwd_s(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y.f, lp(s.y, c.dt), s.st, M, H, eps, c.st);
 }
@@ -1051,11 +1079,10 @@ int etp_pano_fwd(etp_planner* p, const float* rgb, const float* dep, const float
     PanoLayerStash& t = s.layers[l];
     ETP_TRY(ln_fwd_s(c.dt, x, p->pf(q.n1_g), p->pf(q.n1_b), c.dt == ETP_BF16 ? nullptr : (float*)t.a,
                      c.dt == ETP_BF16 ? t.a : nullptr, t.st1, M, H, 1e-5f, c.st));
-    ETP_TRY(linear_fwd(c, t.a, H, q.in_w, q.in_b, t.qkv, 3 * H, M, 3 * H, H, ETP_ACT_NONE, nullptr, nullptr, 0));
     AttnBuf a{t.qkv, 3L * H, offs(t.qkv, H, c.es), 3L * H, offs(t.qkv, 2 * H, c.es), 3L * H, B, V, V, ldS, s.mask, 1, nullptr,
               nullptr, nullptr};
     a.Pd = t.Pd;
-    ETP_TRY(attn_fwd_impl(c.dt, c.nh, a, t.P, t.ctx, H, 0.125f, c.st, hid(c, MODE_PANO, l, SITE_ATT_P)));   // MHA dropout = hidden rate
+    ETP_TRY(attn_fwd_qkv(c, a, t.P, t.ctx, t.a, q.in_w, q.in_b, t.qkv, M, hid(c, MODE_PANO, l, SITE_ATT_P)));   // MHA dropout = hidden rate
     ETP_TRY(linear_fwd_s(c, t.ctx, H, q.out_w, q.out_b, t.x1, M, H, H, x, hid(c, MODE_PANO, l, SITE_ATT_O)));
     ETP_TRY(ln_fwd_s(c.dt, t.x1, p->pf(q.n2_g), p->pf(q.n2_b), c.dt == ETP_BF16 ? nullptr : (float*)t.f,
                      c.dt == ETP_BF16 ? t.f : nullptr, t.st2, M, H, 1e-5f, c.st));

@@ -123,6 +123,16 @@ typedef struct etp_attn_desc {
   float alpha;
 } etp_attn_desc;
 int etp_attn_fwd(const etp_attn_desc* d, etp_stream_t stream);
+/* Self-attention forward with the QKV PROJECTION folded in (round 6): Q / K / V of `d` (Lq == Lk, rows of one token block, e.g. the
+ * three column blocks of a [B*L, 3*heads*64] stash) are OUTPUTS -- each (batch, head) workgroup computes
+ *   [Q | K | V][b, l, h*64 : h*64+64] = x[b*L + l, :] . w_qkv[sec*heads*64 + h*64 + (0..63), :]^T + b_qkv     (sec = 0, 1, 2)
+ * itself (BertSelfAttention.query / key / value, vilmodel_cmt.py:108-110; MHA in_proj_weight, common/transformer.py:138), stores them
+ * (the backward's stash) and goes on with the attention, instead of reading the result of a GEMM launch.  x [B*L, heads*64] (row
+ * stride ldx) and w_qkv [3*heads*64][ldw] in the operand dtype, b_qkv fp32 [3*heads*64] or NULL.  bf16, L <= 128, heads*64 == 768;
+ * anything else returns ETP_ERR_INVALID and the caller issues etp_gemm + etp_attn_fwd.  Results equal that pair's (the projections
+ * are rounded to bf16 exactly where the GEMM stored them). */
+int etp_attn_fwd_qkv(const etp_attn_desc* d, const void* x, int64_t ldx, const void* w_qkv, int64_t ldw, const float* b_qkv,
+                     etp_stream_t stream);
 typedef struct etp_attn_bwd_desc {
   etp_attn_desc f;              /* same as forward; ctx / ldc MUST be the forward's output: the bf16 kernels keep only lse in P and
                                  * recompute from it (Lq or Lk > 128 also read ctx for D = rowsum(dO * O)) */

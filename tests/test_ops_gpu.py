@@ -682,3 +682,66 @@ def test_attention_bwd_proj_refuses_what_the_fused_kernel_does_not_take():
     bd.dQ, bd.lddq, bd.dK, bd.lddk, bd.dV, bd.lddv = dq.data_ptr(), H, dkv.data_ptr(), 2 * H, dkv.data_ptr() + 2 * H, 2 * H
     Wo = torch.randn(H, H, device=DEV).to(t)
     assert L().etp_attn_bwd_proj(ctypes.byref(bd), Wo.data_ptr(), H, stream()) != 0
+
+
+@pytest.mark.parametrize("with_dist", [False, True])
+@pytest.mark.parametrize("Lx", [80, 36, 16, 9, 128, 113, 1])
+def test_self_attention_fwd_with_fused_qkv_projection(Lx, with_dist):
+    """etp_attn_fwd_qkv (round 6; attn_rows.hip QKV): the (batch, head) workgroup projects its own Q / K / V rows from the block's
+    input.  Checked against the pair it replaces -- etp_gemm (BertSelfAttention.query / key / value as one [3H, H] product,
+    vilmodel_cmt.py:108-110) + etp_attn_fwd -- on the same operands: the stash must hold the GEMM's bf16 values up to the order of
+    the fp32 sums, ctx / lse follow; and against torch in fp32."""
+    torch.manual_seed(13)
+    t = torch.bfloat16
+    B, nh, dh = 3, 12, 64
+    H = nh * dh
+    ldS = (Lx + 7) // 8 * 8
+    x = torch.randn(B * Lx, H, device=DEV).to(t)
+    W = (torch.randn(3 * H, H, device=DEV) / math.sqrt(H)).to(t)
+    bias = torch.randn(3 * H, device=DEV) * 0.1
+    km = torch.rand(B, Lx, device=DEV) > 0.2
+    km[:, 0] = True
+    dist = torch.rand(B, Lx, Lx, device=DEV)
+    w = torch.tensor([0.3], device=DEV); b0 = torch.tensor([0.1], device=DEV)
+
+    def run(fused):
+        qkv = torch.full((B * Lx, 3 * H), float("nan"), device=DEV, dtype=t)
+        if not fused:
+            run_gemm(x, W, qkv, B * Lx, 3 * H, H, 0, 0, _lib.ETP_BF16, bias=bias)
+        P = torch.zeros(B, nh, Lx, ldS, device=DEV, dtype=t)
+        ctx = torch.full((B * Lx, H), float("nan"), device=DEV, dtype=t)
+        d = AttnDesc()
+        d.dtype, d.B, d.heads, d.Lq, d.Lk, d.ldS = _lib.ETP_BF16, B, nh, Lx, Lx, ldS
+        d.Q, d.ldq = qkv.data_ptr(), 3 * H
+        d.K, d.ldk = qkv.data_ptr() + 2 * H, 3 * H
+        d.V, d.ldv = qkv.data_ptr() + 4 * H, 3 * H
+        d.P, d.ctx, d.ldc = P.data_ptr(), ctx.data_ptr(), H
+        d.keymask, d.mask_mode = km.data_ptr(), 0
+        if with_dist:
+            d.dist, d.sp_w, d.sp_b = dist.data_ptr(), w.data_ptr(), b0.data_ptr()
+        d.alpha = 0.125
+        if fused:
+            check(L().etp_attn_fwd_qkv(ctypes.byref(d), x.data_ptr(), H, W.data_ptr(), H, bias.data_ptr(), stream()), "attn_fwd_qkv")
+        else:
+            check(L().etp_attn_fwd(ctypes.byref(d), stream()), "attn_fwd")
+        torch.cuda.synchronize()
+        lse = P.view(torch.uint8).view(-1)[: B * nh * Lx * 4].view(torch.float32).clone()
+        return qkv.float(), ctx.float(), lse
+
+    qkv_f, ctx_f, lse_f = run(True)
+    qkv_u, ctx_u, lse_u = run(False)
+    assert torch.isfinite(qkv_f).all() and torch.isfinite(ctx_f).all()
+    ref = x.float() @ W.float().t() + bias
+    assert (qkv_f - ref).abs().max().item() <= 3e-2
+    assert (qkv_f - qkv_u).abs().max().item() <= 2e-2 * (qkv_u.abs().max().item())       # a bf16 ulp where the fp32 sums differ
+    assert (qkv_f != qkv_u).float().mean().item() <= 0.02
+    assert (ctx_f - ctx_u).abs().max().item() <= 3e-2
+    assert (lse_f - lse_u).abs().max().item() <= 3e-2
+    qh = ref[:, :H].to(t).float().view(B, Lx, nh, dh).permute(0, 2, 1, 3)
+    kh = ref[:, H:2 * H].to(t).float().view(B, Lx, nh, dh).permute(0, 2, 1, 3)
+    vh = ref[:, 2 * H:].to(t).float().view(B, Lx, nh, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / 8.0 + (1.0 - km.float())[:, None, None, :] * -10000.0
+    if with_dist:
+        s = s + (w * dist + b0)[:, None]
+    ctx_ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Lx, H)
+    assert (ctx_f - ctx_ref).abs().max().item() <= tol(_lib.ETP_BF16, 2)

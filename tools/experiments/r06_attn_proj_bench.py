@@ -54,7 +54,7 @@ def timeit(fn, n=60):
 
 out = {}
 for name, (B, nh, Lq, Lk, selfatt) in {"text 80x80": (32, 12, 80, 80, True), "pano 36x36": (32, 12, 36, 36, True),
-                                        "graph self 16x16": (32, 12, 16, 16, True), "graph->text 16x80": (32, 12, 16, 80, False),
+                                        "graph self 16x16": (32, 12, 16, 16, True), "graph->text 16x80": (32, 12, 16, 80, False), "text 80x80 B=8": (8, 12, 80, 80, True), "text 80x80 B=16": (16, 12, 80, 80, True), "pano 36x36 B=8": (8, 12, 36, 36, True),
                                         "c5 graph self 64x64": (8, 12, 64, 64, True), "c5 graph->text 64x80": (8, 12, 64, 80, False)}.items():
     sets = [make(B, nh, Lq, Lk, selfatt) for _ in range(NS)]
     def unf(i):
