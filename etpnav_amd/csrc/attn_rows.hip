@@ -70,6 +70,7 @@ struct RowArgs {
   //   [Q | K | V][b, l, h*64 : h*64+64] = X[b*L + l, 0:Kp] . Wqkv[sec*H + h*64 + (0..63), 0:Kp]^T + bqkv   (sec = 0, 1, 2; H = nh*64)
   // and WRITTEN to the Q / K / V pointers (the backward's stash).  X = the LayerNorm output in the operand dtype, W reuses `W` above.
   const bf16_t* X; long ldx; const float* bqkv;
+  int kv_mod;                                    // > 0: keys / values / key mask of episode b are those of instruction b % kv_mod
 };
 
 __device__ __forceinline__ f32x4_t mma32(const uint4& a, const uint4& b, f32x4_t c) {
@@ -249,14 +250,15 @@ __global__ __launch_bounds__(512) void rows_fwd_kernel(const RowArgs a) {
   const int q = wave * 16 + i, qc = min(q, a.Lq - 1);
   uint4 qf0, qf1;
 
+  const int bk = a.kv_mod > 0 ? b % a.kv_mod : b;
   if constexpr (!QKV) {
     TileRegs<BKV> rk, rv;
-    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
-    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
+    tile_fetch<BKV>(rk, a.K + (long)bk * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);
+    tile_fetch<BKV>(rv, a.V + (long)bk * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr);
     // this wavefront's 16 queries go straight into the B-operand registers (rows past Lq repeat the last one; never stored)
     const bf16_t* Qr = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * 64 + g * 8;
     qf0 = *reinterpret_cast<const uint4*>(Qr); qf1 = *reinterpret_cast<const uint4*>(Qr + 32);
-    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)bk * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
     tile_commit<BKV>(kt, rk, BKV, tid, nthr);
     tile_commit<BKV>(vt, rv, BKV, tid, nthr);
   } else {
@@ -435,10 +437,11 @@ __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
   {
     TileRegs<128> rq, rd;
     TileRegs<BKV> rk, rv;
+    const int bk = a.kv_mod > 0 ? b % a.kv_mod : b;
 #define FETCH_QKV()                                                                                        \
     tile_fetch<128>(rq, a.Q + (long)b * a.Lq * a.ldq + h * 64, a.ldq, a.Lq, BQ, tid, nthr);                 \
-    tile_fetch<BKV>(rk, a.K + (long)b * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);                \
-    tile_fetch<BKV>(rv, a.V + (long)b * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr)
+    tile_fetch<BKV>(rk, a.K + (long)bk * a.Lk * a.ldk + h * 64, a.ldk, a.Lk, BKV, tid, nthr);               \
+    tile_fetch<BKV>(rv, a.V + (long)bk * a.Lk * a.ldv + h * 64, a.ldv, a.Lk, BKV, tid, nthr)
     if constexpr (!PROJ) {
       FETCH_QKV();
       tile_fetch<128>(rd, a.dO + (long)b * a.Lq * a.ldd + h * 64, a.ldd, a.Lq, BQ, tid, nthr);
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512) void rows_bwd_kernel(const RowArgs a) {
       __syncthreads();                            // the ring is dead: Q / K / V and the row vectors may land on it
     }
 #undef FETCH_QKV
-    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)b * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
+    if (tid < BKV) kadd[tid] = key_term(a.keymask ? a.keymask + (long)bk * a.Lk : nullptr, tid, a.Lk, a.mask_mode);
     // padded query rows: lse = +inf makes their recomputed probabilities exactly 0
     if (tid < 128) lse[tid] = tid < a.Lq ? a.lse[(long)bh * a.Lq + tid] : INFINITY;
     tile_commit<128>(qt, rq, BQ, tid, nthr);
@@ -674,6 +677,7 @@ RowArgs make_row_args(int nh, const AttnBuf& a, void* P, float alpha, Drop drop)
   k.Q = (const bf16_t*)a.Q; k.K = (const bf16_t*)a.K; k.V = (const bf16_t*)a.V; k.ldq = a.ldq; k.ldk = a.ldk; k.ldv = a.ldv;
   k.lse = (float*)P; k.nh = nh; k.Lq = a.Lq; k.Lk = a.Lk; k.drop = drop;
   k.keymask = a.keymask; k.mask_mode = a.mask_mode; k.dist = a.dist; k.sp_w = a.sp_w; k.sp_b = a.sp_b; k.alpha = alpha;
+  k.kv_mod = a.kv_mod;
   return k;
 }
 
@@ -704,7 +708,7 @@ static bool skip_attn(const char* what) {
 
 // fused QKV projection: self-attention blocks (one token axis) of a 768-wide model
 bool attn_rows_qkv_ok(int nh, const AttnBuf& a, const void* X, long ldx, const void* W, long ldw) {
-  return nh * 64 == PROJ_K && a.Lq == a.Lk && ldx % 8 == 0 && ldw % 8 == 0 &&
+  return nh * 64 == PROJ_K && a.Lq == a.Lk && a.kv_mod == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
          ((uintptr_t)X | (uintptr_t)W) % 16 == 0;
 }
 

@@ -83,6 +83,9 @@ struct AttnBuf {
   const uint8_t* keymask; int mask_mode; const float* dist; const float* sp_w; const float* sp_b;
   void* Pd = nullptr;      // unfused path only: second [B,heads,Lq,ldS] buffer for the DROPPED probabilities (training mode)
   const void* O = nullptr; long ldo = 0;   // backward only: the forward output (streaming kernels: D = rowsum(dO * O))
+  // > 0 (round 6, batched rollout on the text K/V cache): episode b reads the keys / values / key mask of instruction b % kv_mod
+  // (Q, ctx and every gradient stay per episode).  Register-resident kernels only (attn_rows.hip); the other families refuse it.
+  int kv_mod = 0;
 };
 // shapes the fused kernels do not take (the batched-GEMM path runs them and needs AttnBuf::Pd for dropout)
 // (bf16 with Lq or Lk > 128 normally runs the streaming kernels instead; the second buffer is still planned so that

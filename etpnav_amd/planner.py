@@ -324,26 +324,37 @@ class _NavKVStepsFn(torch.autograd.Function):
 
 
 class _NavCachedFn(torch.autograd.Function):
+    """forward_navigation on the text K/V cache.  steps_T > 1 (batched rollout, round 6): `kv` / `txt_masks` hold the Bt = B / steps_T
+    instructions ONCE and stacked episode e reads instruction e % Bt inside the cross-attention kernels (etp_nav_fwd_kv_steps /
+    etp_nav_bwd_kv_steps) -- no replicated cache; the backward sums d_kv over the steps (etp_nav_kv_sum_steps), the sum the reference's
+    shared txt_embeds tensor accumulates through autograd (ss_trainer_ETP.py:819-822,1055)."""
+
     @staticmethod
-    def forward(ctx, anchor, eng: Engine, drop, kv, L, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists):
+    def forward(ctx, anchor, eng: Engine, drop, kv, L, txt_masks, step_ids, img_fts, pos_fts, gmasks, visited, dists, steps_T=1):
         B, G = step_ids.shape
         H = eng.cconf.hidden
-        cache = ctypes.c_void_p(kv.data_ptr() - int(eng.L.etp_nav_kv_offset(eng.handle, B, L)))   # base of the cache buffer
+        Bt = B // steps_T
+        cache = ctypes.c_void_p(kv.data_ptr() - int(eng.L.etp_nav_kv_offset(eng.handle, Bt, L)))   # base of the cache buffer
         eng.set_dropout(drop)
         ctx.drop = drop
         out = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         logits = torch.empty(B, G, dtype=torch.float32, device=eng.device)
         stash = eng.buf(eng.L.etp_nav_stash_bytes(eng.handle, B, L, G))
-        check(eng.L.etp_nav_fwd_kv(eng.handle, cache, ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts), ptr(gmasks),
-                                   ptr(visited), ptr(dists), B, L, G, ptr(out), ptr(logits), ptr(stash), eng.stream()),
-              "etp_nav_fwd_kv")
-        ctx.eng, ctx.stash, ctx.dims, ctx.cache, ctx.kv_shape = eng, stash, (B, L, G), cache, kv.shape
+        if steps_T > 1:
+            check(eng.L.etp_nav_fwd_kv_steps(eng.handle, cache, ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts), ptr(gmasks),
+                                             ptr(visited), ptr(dists), B, L, G, Bt, ptr(out), ptr(logits), ptr(stash), eng.stream()),
+                  "etp_nav_fwd_kv_steps")
+        else:
+            check(eng.L.etp_nav_fwd_kv(eng.handle, cache, ptr(txt_masks), ptr(step_ids), ptr(img_fts), ptr(pos_fts), ptr(gmasks),
+                                       ptr(visited), ptr(dists), B, L, G, ptr(out), ptr(logits), ptr(stash), eng.stream()),
+                  "etp_nav_fwd_kv")
+        ctx.eng, ctx.stash, ctx.dims, ctx.cache, ctx.kv_shape, ctx.steps_T = eng, stash, (B, L, G), cache, kv.shape, steps_T
         ctx.save_for_backward(txt_masks, step_ids, pos_fts, gmasks, visited, dists, kv)
         return out, logits
 
     @staticmethod
     def backward(ctx, d_out, d_logits):
-        eng, (B, L, G) = ctx.eng, ctx.dims
+        eng, (B, L, G), T = ctx.eng, ctx.dims, ctx.steps_T
         txt_masks, step_ids, pos_fts, gmasks, visited, dists, _kv = ctx.saved_tensors
         H = eng.cconf.hidden
         d_out = d_out.float().contiguous() if d_out is not None else None
@@ -352,13 +363,21 @@ class _NavCachedFn(torch.autograd.Function):
         d_img = torch.empty(B, G, H, dtype=torch.float32, device=eng.device)
         ws = eng.ws(("nav", B, L, G), eng.L.etp_nav_ws_bytes(eng.handle, B, L, G))
         eng.set_dropout(ctx.drop)
-        check(eng.L.etp_nav_bwd_kv(eng.handle, ptr(d_out), ptr(d_logits), ctx.cache, ptr(txt_masks), ptr(step_ids),
-                                   ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_kv), ptr(d_img),
-                                   ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd_kv")
+        if T > 1:
+            n_x, _, H2 = ctx.kv_shape
+            d_kv_steps = torch.empty(n_x, B * L, H2, dtype=eng.tdtype, device=eng.device)
+            check(eng.L.etp_nav_bwd_kv_steps(eng.handle, ptr(d_out), ptr(d_logits), ctx.cache, ptr(txt_masks), ptr(step_ids),
+                                             ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, B // T, ptr(d_kv_steps),
+                                             ptr(d_img), ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd_kv_steps")
+            check(eng.L.etp_nav_kv_sum_steps(eng.handle, ptr(d_kv_steps), B // T, L, T, ptr(d_kv), eng.stream()), "etp_nav_kv_sum_steps")
+        else:
+            check(eng.L.etp_nav_bwd_kv(eng.handle, ptr(d_out), ptr(d_logits), ctx.cache, ptr(txt_masks), ptr(step_ids),
+                                       ptr(pos_fts), ptr(gmasks), ptr(visited), ptr(dists), B, L, G, ptr(d_kv), ptr(d_img),
+                                       ptr(ctx.stash), ptr(ws), eng.stream()), "etp_nav_bwd_kv")
         # a PlannerStep sharing this planner may have switched on lazy joins of the weight-gradient stream: autograd
         # consumers read .grad right after backward, so join here (no-op without an aux stream)
         check(eng.L.etp_planner_join_aux(eng.handle, eng.stream()), "join_aux")
-        return None, None, None, d_kv, None, None, None, d_img, None, None, None, None
+        return None, None, None, d_kv, None, None, None, d_img, None, None, None, None, None
 
 
 class GlocalTextPathNavCMT(nn.Module):
@@ -390,6 +409,7 @@ class GlocalTextPathNavCMT(nn.Module):
         # text K/V cache across rollout steps; off = the reference's per-step re-projection
         self.cache_text_kv = False
         self.batch_steps_kv = True        # forward_navigation_steps: project the text keys/values once, not T times
+        self.kv_indirection = True        # ... and let the cross-attention kernels read instruction e % B (no replicated cache; bf16, axes <= 128)
         self._kv_cache = None
         self.drop_env_prob = 0.0          # >0 fuses the policy's drop_env (Policy_ViewSelection_ETP.py:102,345) into forward_panorama
         self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -595,7 +615,9 @@ class GlocalTextPathNavCMT(nn.Module):
 
         Text keys/values (self.batch_steps_kv, default on): the K|V projections of the B instructions are computed ONCE
         (etp_nav_kv_fwd, shared with cache_text_kv's per-step calls), replicated for the T stacked steps by a copy
-        (etp_nav_kv_repeat) and their gradient is summed over the steps (etp_nav_kv_sum_steps) before ONE projection back to
+        (etp_nav_kv_repeat; round 6: not even that where the register-resident attention kernels run -- bf16, both axes <= 128 --
+        the stacked episode e reads instruction e % B inside the kernels, etp_nav_fwd_kv_steps) and their gradient is summed over
+        the steps (etp_nav_kv_sum_steps) before ONE projection back to
         the text (etp_nav_kv_bwd) -- instead of projecting T * B * L stacked text rows forward and backward in every x-layer,
         which is the re-projection of vilmodel_cmt.py:326-328 the reference repeats per step.  batch_steps_kv = False keeps
         the stacked re-projection (same results up to the rounding of the summed bf16 key/value gradients)."""
@@ -621,15 +643,20 @@ class GlocalTextPathNavCMT(nn.Module):
             t = torch.float32
             L = txt_embeds.shape[1]
             kv = self._text_kv(eng, txt_embeds)
-            kv_steps = _NavKVStepsFn.apply(eng, kv, B, L, T)
-            embeds, logits = _NavCachedFn.apply(self._anchor, eng, self._dropout(), kv_steps, L,
-                                                txt_masks.to(torch.bool).repeat(T, 1).contiguous(),
+            # bf16 with both axes <= 128 (every R2R-CE shape): the cross-attention kernels read instruction e % B themselves; otherwise
+            # (fp32 parity mode, RxR's 512-token instructions) the cache is replicated for the stacked steps (etp_nav_kv_repeat)
+            indirect = T > 1 and eng.tdtype == torch.bfloat16 and L <= 128 and Gm <= 128 and self.kv_indirection
+            if indirect:
+                kv_in, masks_in, steps_T = kv, txt_masks.to(torch.bool).contiguous(), T
+            else:
+                kv_in, masks_in, steps_T = _NavKVStepsFn.apply(eng, kv, B, L, T), txt_masks.to(torch.bool).repeat(T, 1).contiguous(), 1
+            embeds, logits = _NavCachedFn.apply(self._anchor, eng, self._dropout(), kv_in, L, masks_in,
                                                 cat("gmap_step_ids", (1,)).long().contiguous(),
                                                 cat("gmap_img_fts", (1,)).to(t).contiguous(),
                                                 cat("gmap_pos_fts", (1,)).float().contiguous(),
                                                 cat("gmap_masks", (1,), False).to(torch.bool).contiguous(),
                                                 cat("gmap_visited_masks", (1,), False).to(torch.bool).contiguous(),
-                                                cat("gmap_pair_dists", (1, 2)).float().contiguous())
+                                                cat("gmap_pair_dists", (1, 2)).float().contiguous(), steps_T)
             out = {"gmap_embeds": embeds, "global_logits": logits}
         else:
             out = self.forward_navigation(txt_embeds.repeat(T, 1, 1), txt_masks.repeat(T, 1), None,

@@ -408,6 +408,21 @@ int etp_nav_bwd_kv(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const
                    const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
                    const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L,
                    int G, void* d_kv /*overwritten*/, float* d_gmap_img_fts, void* stash, void* ws, etp_stream_t stream);
+/* The same two calls with PER-EPISODE INDIRECTION instead of the replicated copy (round 6; N1): B = T * Bt stacked episodes, `kv_cache`
+ * (etp_nav_kv_bytes(p, Bt, L)) and `txt_masks` [Bt, L] hold the Bt instructions once, and episode e reads the keys / values / key mask
+ * of instruction e % Bt inside the cross-attention kernels (vilmodel_cmt.py:326-328 with the same txt_embeds at every step,
+ * ss_trainer_ETP.py:819-822).  d_kv is still per stacked episode [n_x][B*L][2H] (the caller sums it over the steps with
+ * etp_nav_kv_sum_steps).  bf16 with L and G <= 128 (the register-resident attention kernels); otherwise ETP_ERR_INVALID: use
+ * etp_nav_kv_repeat + the calls above. */
+int etp_nav_fwd_kv_steps(etp_planner* p, const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids,
+                         const float* gmap_img_fts, const float* gmap_pos_fts, const uint8_t* gmap_masks,
+                         const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L, int G, int Bt,
+                         float* gmap_embeds, float* global_logits, void* stash, etp_stream_t stream);
+int etp_nav_bwd_kv_steps(etp_planner* p, const float* d_gmap_embeds /*or NULL*/, const float* d_logits /*or NULL*/,
+                         const void* kv_cache, const uint8_t* txt_masks, const int64_t* gmap_step_ids, const float* gmap_pos_fts,
+                         const uint8_t* gmap_masks, const uint8_t* gmap_visited_masks, const float* gmap_pair_dists, int B, int L,
+                         int G, int Bt, void* d_kv /*[n_x][B*L][2H], overwritten*/, float* d_gmap_img_fts, void* stash, void* ws,
+                         etp_stream_t stream);
 
 /* Device-side graph-input assembly: everything RLTrainer._nav_gmap_variable computes on the host
  * besides the node embeddings (ss_trainer_ETP.py:344-417) -- all-pairs shortest paths over the visited-node graph

@@ -6,7 +6,9 @@ Three ways of issuing the same work (identical outputs and gradients: tests/test
     per_step_kv     the same with cache_text_kv (one projection of the text K/V serves all T steps)
     batched_reproject  forward_navigation_steps with batch_steps_kv = False: the T steps as one (T * B)-episode call that
                     projects the T-fold stacked text rows to keys/values in every x-layer (round 3's form)
-    batched         forward_navigation_steps: the same call on the K/V cache (one projection, replicated by a copy)
+    batched_copy    forward_navigation_steps on the K/V cache: one projection, replicated for the stacked steps by a copy (round 4's form)
+    batched         the same with per-episode indirection (round 6): stacked episode e reads instruction e % B inside the
+                    cross-attention kernels, no replicated cache (bf16, axes <= 128)
 
     python tools/rollout_bench.py [--B 8] [--L 80] [--T 5,10,15] [--G 16] [--dtype bf16] [--iters 20]
 Prints one JSON object (ms per episode fwd+bwd, episodes/s) -> profiles/r03_rollout_bench.json.
@@ -29,7 +31,8 @@ def episode(model, ids, masks, steps, how):
     model.zero_grad()
     txt = model.forward_txt(ids, masks)
     if how.startswith("batched"):
-        model.batch_steps_kv = how == "batched"          # "batched_reproject": the T-fold stacked K/V projection (round 3)
+        model.batch_steps_kv = how != "batched_reproject"    # "batched_reproject": the T-fold stacked K/V projection (round 3)
+        model.kv_indirection = how == "batched"
         outs = model.forward_navigation_steps(txt, masks, steps)
     else:
         outs = [model.forward_navigation(txt, masks, None, st["gmap_step_ids"], st["gmap_img_fts"], st["gmap_pos_fts"],
@@ -67,7 +70,7 @@ def main():
             b["gmap_img_fts"] = torch.randn(a.B, G, cfg.hidden_size, generator=gen) * 0.5
             steps.append({k: v.cuda() for k, v in b.items() if k.startswith("gmap_") or k == "labels"})
         row = {"T": T, "B": a.B, "L": a.L, "G_last": a.G}
-        for how in ("per_step", "per_step_kv", "batched_reproject", "batched"):
+        for how in ("per_step", "per_step_kv", "batched_reproject", "batched_copy", "batched"):
             model.cache_text_kv = how == "per_step_kv"
             for _ in range(3):
                 episode(model, ids, masks, steps, how)
