@@ -138,7 +138,9 @@ def newest_profile(suffix, round_no=None):
 
 def env_overrides():
     """every ETP_* / HIP / ROCm tuning variable set in this process: they select kernels inside the timed region (VERDICT r4 weak #9)"""
-    keys = sorted(k for k in os.environ if k.startswith("ETP_") or k in ("AMD_SERIALIZE_KERNEL", "GPU_MAX_HW_QUEUES", "HIP_LAUNCH_BLOCKING"))
+    runtime = ("AMD_SERIALIZE_KERNEL", "GPU_MAX_HW_QUEUES", "HIP_LAUNCH_BLOCKING", "AMD_OPT_FLUSH", "HIP_FORCE_DEV_KERNARG", "AMD_DIRECT_DISPATCH",
+               "ROC_SYSTEM_SCOPE_SIGNAL", "DEBUG_CLR_KERNARG_HDP_FLUSH_WA", "GPU_FLUSH_ON_EXECUTION", "ROC_AQL_QUEUE_SIZE", "ROC_SIGNAL_POOL_SIZE")
+    keys = sorted(k for k in os.environ if k.startswith("ETP_") or k in runtime)
     out = {k: os.environ[k] for k in keys}
     try:                       # the library's own table (csrc/options.h): what its launch paths really consult, set by env or by the C ABI
         from etpnav_amd import _lib

@@ -162,6 +162,9 @@ class PlannerStep:
             check(self.L.etp_stream_create(ctypes.byref(a2)), "stream_create")
             self.aux2 = a2.value
         self._lazy = 1 if self.aux is not None else 0
+        # schedule switches are read ONCE, here (no environment lookups on the per-step path)
+        self._txt_cast_split = os.environ.get("ETP_TXT_CAST_SPLIT", "1") != "0"
+        self._chain_first = os.environ.get("ETP_CHAIN_FIRST", "0") == "1"
         self._install_streams()
         self._pano_pending = False
         self.graph = None
@@ -251,7 +254,7 @@ class PlannerStep:
         if self.refresh_weights:
             # only layer 0's cast stays in front of the first text GEMM; layers 1.. are cast on the panorama stream and
             # etp_txt_fwd waits for them after its layer 0 (ETP_TXT_CAST_SPLIT=0: the whole text cast on the main stream)
-            if self.s2 is not None and os.environ.get("ETP_TXT_CAST_SPLIT", "1") != "0":
+            if self.s2 is not None and self._txt_cast_split:
                 check(L.etp_planner_refresh_text_split(h, s, s2), "refresh text weights")
             else:
                 check(L.etp_planner_refresh_part(h, 0, s), "refresh text weights")
@@ -365,7 +368,7 @@ class PlannerStep:
             self.enqueue_main(s, False, join_pano=True)
             return
         n_l = self.eng.cconf.n_l
-        head = max(0, min(3, n_l - 1)) if os.environ.get("ETP_CHAIN_FIRST", "0") == "1" else 0
+        head = max(0, min(3, n_l - 1)) if self._chain_first else 0
         self.enqueue_main(s, True, join_pano=False, defer_pano=head > 0)   # panorama backward overlaps the text backward
         if head > 0:
             lazy = self.aux is not None
