@@ -68,6 +68,10 @@ struct etp_planner {
   // etp_txt_fwd, after it has enqueued layer 0)
   hipEvent_t txt_w_ready = nullptr;
   bool txt_w_pending = false;
+  // etp_nav_bwd under lazy joins (round 6): d txt_embeds is complete on the aux2 stream at this event; the consumers -- the text backward,
+  // etp_planner_join_aux -- wait for it, the navigation backward itself no longer does (its tail and the node-assembly backward overlap it)
+  hipEvent_t dtxt_ready = nullptr;
+  bool dtxt_pending = false;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   hipEvent_t next_event() {
@@ -793,6 +797,7 @@ int etp_planner_set_grad_overwrite(etp_planner* p, int on) {
 int etp_planner_join_aux(etp_planner* p, etp_stream_t stream) {
   ETP_REQUIRE(p, "null planner");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->dtxt_pending) ETP_CHECK_HIP(stream_wait_event(st, p->dtxt_ready));     // (not cleared: see etp_txt_bwd_range)
   if (p->aux == nullptr || p->aux == st) return ETP_OK;
   return stream_after(p, p->aux, st);
 }
@@ -896,6 +901,11 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
   ETP_REQUIRE(p && p->P && p->G && dout && ids && mask && stash && ws && B > 0 && L > 0, "bad arguments");
   ETP_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= p->cfg.n_l, "bad layer range");
   Ctx c = make_ctx(p, stream);
+  // `dout` may be the d txt_embeds a lazily joined etp_nav_bwd left running on the aux2 stream.  The flag is NOT cleared here: several
+  // callers on different streams may consume deferred results of the one aux2 stream (MicroBatchedStep: the navigation backward of every
+  // micro-batch, then their text backwards); the event is re-recorded by every deferring etp_nav_bwd, the stream is in-order, so waiting
+  // for the latest record covers all earlier ones, and a wait on a completed event costs nothing on the device
+  if (p->dtxt_pending) ETP_CHECK_HIP(stream_wait_event(c.st, p->dtxt_ready));
   std::vector<std::function<int()>> pend;
   std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
@@ -938,10 +948,21 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     if (delay && l != layer_lo) continue;             // held back: goes out behind the next layer's FFN dgrad
     if (every == 1 || (layer_hi - 1 - l) % every == every - 1 || l == layer_lo) ETP_TRY(flush_side(c));
   }
-  if (layer_lo == 0)
+  if (layer_lo == 0) {
+    // TXT_TAIL (round 6, default on): the embedding backward produces parameter gradients only -- a LEAF, and the last kernel of the step's
+    // chain, which then still waits ~66 us for the weight-gradient backlog (profiles/r06_chain_waits.txt).  With a third stream (aux2: idle
+    // by now) it runs BESIDE that backlog instead of in front of the wait; the stream is joined below with the weight-gradient stream.
+    hipStream_t se = (opt_on(OPT_TXT_TAIL, true) && c.s3 != c.st && c.s3 != c.sw) ? c.s3 : c.st;
+    if (se != c.st) ETP_TRY(stream_after(p, c.st, se));
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
-                           p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, c.st,
+                           p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, se,
                            hid(c, MODE_TXT, 0, SITE_EMBED)));
+    if (se != c.st) {
+      stamp_mark(c.st, 2299);
+      ETP_TRY(join_wgrads(c));
+      return stream_after(p, se, c.st);
+    }
+  }
   stamp_mark(c.st, 2299);
   // a range that stops above layer 0 is followed by another one: with lazy level 2 its weight gradients keep running on the
   // side stream (the final range, or etp_planner_join_aux, joins them)
@@ -1371,6 +1392,8 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
     ETP_TRY(stream_after(p, c.st, c.sw));
     Ctx cs = c;
     cs.st = c.sw;
+    // (round 6: the n_x projections as ONE grouped launch -- on this stream or on the chain itself -- measured +0.9 % on config 2 and +0.8 %
+    // on config 5, profiles/r06_ab_runs.json r6c9: the grouped class is the older 16x16x32 family, and x-layer 0 then waits for all four)
     for (int l = 0; l < cf.n_x; ++l) {
       ETP_TRY(linear_fwd(cs, txtT, H, p->xl[l].kv_w, p->xl[l].kv_b, s.layers[l].cross.kv, 2 * H, Mt, 2 * H, H, ETP_ACT_NONE,
                          nullptr, nullptr, 0));
@@ -1512,11 +1535,36 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
   }
   if (cf.n_x == 0) ETP_TRY(copy_f32(g, d_img, (long)Mg * H, c.st));
   stamp_mark(c.st, 2090);
-  if (!cached && c.s3 != c.st) ETP_TRY(stream_after(p, c.s3, c.st));      // d_txt complete in `stream` order
+  // NAV_TAIL (round 6; bit 0, default on): the node-embedding backward produces parameter gradients only -- a LEAF like the weight gradients:
+  // it rides on their stream instead of holding the chain for ~38 us.  Bit 1 (default on, lazy joins only = PlannerStep): the chain does
+  // not wait for the d txt_embeds accumulate chain on the aux2 stream here; its consumers do (etp_txt_bwd_range, etp_planner_join_aux), so
+  // the node-assembly backward and the panorama fork overlap it.
+  const int tail = opt_int(OPT_NAV_TAIL, 3);
+  if (!cached && c.s3 != c.st) {
+    if ((tail & 2) && p->lazy_join >= 1) {
+      if (!p->dtxt_ready) ETP_CHECK_HIP(hipEventCreateWithFlags(&p->dtxt_ready, hipEventDisableTiming));
+      ETP_CHECK_HIP(event_record(p->dtxt_ready, c.s3));
+      p->dtxt_pending = true;
+    } else {
+      ETP_TRY(stream_after(p, c.s3, c.st));                                // d_txt complete in `stream` order
+      p->dtxt_pending = false;
+    }
+  }
   stamp_mark(c.st, 2091);
-  ETP_TRY(gmap_embed_bwd(c.dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), s.st0,
-                         p->gf(p->step_emb), p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H,
-                         cf.ang_feat + 3, c.st));
+  {
+    const int dt = c.dt, PK = cf.ang_feat + 3;
+    const float* st0 = s.st0;
+    auto embed_bwd = [=](hipStream_t st) -> int {
+      return gmap_embed_bwd(dt, d_img, step_ids, pos, p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g), st0, p->gf(p->step_emb),
+                            p->gf(p->gpos_w), p->gf(p->gpos_b), p->gf(p->gpos_g), p->gf(p->gpos_bb), Mg, H, PK, st);
+    };
+    if ((tail & 1) && c.sw != c.st) {
+      hipStream_t sw = c.sw;
+      ETP_TRY(on_side(c, [=]() -> int { return embed_bwd(sw); }));
+    } else {
+      ETP_TRY(embed_bwd(c.st));
+    }
+  }
   return finish_wgrads(c);
 }
 }  // namespace

@@ -165,6 +165,9 @@ class PlannerStep:
         # schedule switches are read ONCE, here (no environment lookups on the per-step path)
         self._txt_cast_split = os.environ.get("ETP_TXT_CAST_SPLIT", "1") != "0"
         self._chain_first = os.environ.get("ETP_CHAIN_FIRST", "0") == "1"
+        # node assembly (gather-mean of the view embeddings) rides behind pano_fwd on the panorama stream, off the chain (round 6: -0.35 %,
+        # 4.045 against 4.059 ms, three pairs, profiles/r06_ab_runs.json r6c9); ETP_ASSEMBLE_ON_S2=0 puts it back behind the join
+        self._assemble_on_s2 = os.environ.get("ETP_ASSEMBLE_ON_S2", "1") != "0"
         self._install_streams()
         self._pano_pending = False
         self.graph = None
@@ -271,10 +274,13 @@ class PlannerStep:
         check(L.etp_txt_fwd(h, ptr(i["txt_ids"]), ptr(i["txt_masks"]), B, Lt, ptr(self.txt), ptr(self.st_txt), s), "txt_fwd")
         check(L.etp_pano_fwd(h, ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), ptr(i["view_lens"]), self.Bp, V,
                              ptr(self.pano), ptr(self.pmask), ptr(self.st_pano), s2), "pano_fwd")
-        check(L.etp_stream_after(s2, s), "join")
         pf, xf, wf = self.csr_f
+        if self._assemble_on_s2 and s2 != s:   # the gather-mean of the view embeddings depends on the panorama branch only: behind it, off the chain
+            check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s2), "node assembly")
+        check(L.etp_stream_after(s2, s), "join")
         L.etp_stamp_mark(s, 2)
-        check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
+        if not (self._assemble_on_s2 and s2 != s):
+            check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
         check(L.etp_nav_fwd(h, ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]), ptr(self.gimg), ptr(i["pos"]),
                             ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.gemb), ptr(self.logits),
                             ptr(self.st_nav), s), "nav_fwd")
