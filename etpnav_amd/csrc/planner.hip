@@ -71,7 +71,12 @@ struct etp_planner {
   // etp_nav_bwd under lazy joins (round 6): d txt_embeds is complete on the aux2 stream at this event; the consumers -- the text backward,
   // etp_planner_join_aux -- wait for it, the navigation backward itself no longer does (its tail and the node-assembly backward overlap it)
   hipEvent_t dtxt_ready = nullptr;
-  bool dtxt_pending = false;
+  std::vector<hipStream_t> dtxt_waiters;   // main streams whose etp_nav_bwd deferred the join and that have not consumed it yet
+  bool dtxt_owed(hipStream_t st) {         // true once per deferral of `st`
+    for (size_t i = 0; i < dtxt_waiters.size(); ++i)
+      if (dtxt_waiters[i] == st) { dtxt_waiters.erase(dtxt_waiters.begin() + i); return true; }
+    return false;
+  }
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   hipEvent_t next_event() {
@@ -797,7 +802,7 @@ int etp_planner_set_grad_overwrite(etp_planner* p, int on) {
 int etp_planner_join_aux(etp_planner* p, etp_stream_t stream) {
   ETP_REQUIRE(p, "null planner");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (p->dtxt_pending) ETP_CHECK_HIP(stream_wait_event(st, p->dtxt_ready));     // (not cleared: see etp_txt_bwd_range)
+  if (p->dtxt_owed(st)) ETP_CHECK_HIP(stream_wait_event(st, p->dtxt_ready));
   if (p->aux == nullptr || p->aux == st) return ETP_OK;
   return stream_after(p, p->aux, st);
 }
@@ -843,6 +848,7 @@ int etp_planner_refresh_text_split(etp_planner* p, etp_stream_t main, etp_stream
   const long l1 = p->off(p->txt[1].att.qkv_w);
   ETP_TRY(cast_f32_to_bf16(p->P, p->S, l1, sm));
   ETP_TRY(stream_after(p, sm, ss));                     // the side stream starts no earlier than this step (ordering with the optimizer)
+  // (round 6: layer 0's cast on the side stream too, beside the embedding kernel: 3.949 against 3.931 ms, no gain -- r06_ab_runs.json r6c11)
   ETP_TRY(cast_f32_to_bf16(p->P + l1, reinterpret_cast<uint16_t*>(p->S) + l1, txt_end - l1, ss));
   if (!p->txt_w_ready) ETP_CHECK_HIP(hipEventCreateWithFlags(&p->txt_w_ready, hipEventDisableTiming));
   ETP_CHECK_HIP(event_record(p->txt_w_ready, ss));
@@ -901,11 +907,11 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
   ETP_REQUIRE(p && p->P && p->G && dout && ids && mask && stash && ws && B > 0 && L > 0, "bad arguments");
   ETP_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= p->cfg.n_l, "bad layer range");
   Ctx c = make_ctx(p, stream);
-  // `dout` may be the d txt_embeds a lazily joined etp_nav_bwd left running on the aux2 stream.  The flag is NOT cleared here: several
-  // callers on different streams may consume deferred results of the one aux2 stream (MicroBatchedStep: the navigation backward of every
-  // micro-batch, then their text backwards); the event is re-recorded by every deferring etp_nav_bwd, the stream is in-order, so waiting
-  // for the latest record covers all earlier ones, and a wait on a completed event costs nothing on the device
-  if (p->dtxt_pending) ETP_CHECK_HIP(stream_wait_event(c.st, p->dtxt_ready));
+  // `dout` may be the d txt_embeds a lazily joined etp_nav_bwd ON THIS STREAM left running on the aux2 stream: wait for it once.  The debt
+  // is kept per main stream (MicroBatchedStep: the navigation backward of every micro-batch on its own stream, then their text backwards;
+  // the one event is re-recorded by every deferral and aux2 is in-order, so the latest record covers the earlier ones), and a stream that
+  // never deferred never waits -- a stale event must not be waited for inside a stream capture
+  if (p->dtxt_owed(c.st)) ETP_CHECK_HIP(stream_wait_event(c.st, p->dtxt_ready));
   std::vector<std::function<int()>> pend;
   std::vector<GemmArgs> wq;
   if (c.sw != c.st) c.pend = &pend;
@@ -949,10 +955,12 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     if (every == 1 || (layer_hi - 1 - l) % every == every - 1 || l == layer_lo) ETP_TRY(flush_side(c));
   }
   if (layer_lo == 0) {
-    // TXT_TAIL (round 6, default on): the embedding backward produces parameter gradients only -- a LEAF, and the last kernel of the step's
-    // chain, which then still waits ~66 us for the weight-gradient backlog (profiles/r06_chain_waits.txt).  With a third stream (aux2: idle
-    // by now) it runs BESIDE that backlog instead of in front of the wait; the stream is joined below with the weight-gradient stream.
-    hipStream_t se = (opt_on(OPT_TXT_TAIL, true) && c.s3 != c.st && c.s3 != c.sw) ? c.s3 : c.st;
+    // TXT_TAIL=1 (round 6 experiment, default OFF): the embedding backward produces parameter gradients only -- a LEAF, and the last kernel
+    // of the step's chain, which then still waits ~66 us for the weight-gradient backlog (profiles/r06_chain_waits.txt).  On a third stream
+    // (aux2: idle by now) it runs BESIDE that backlog instead of in front of the wait.  Measured (r06_ab_runs.json r6c10): the chain ends
+    // 35 us earlier and the backlog it now shares the chip with takes 28 us longer: -0.26 % alone, and WORSE than without it once the
+    // navigation tail (NAV_TAIL) is off the chain (3.991 against 3.977 ms).  Kept as a switch.
+    hipStream_t se = (opt_on(OPT_TXT_TAIL, false) && c.s3 != c.st && c.s3 != c.sw) ? c.s3 : c.st;
     if (se != c.st) ETP_TRY(stream_after(p, c.st, se));
     ETP_TRY(text_embed_bwd(c.dt, g, ids, p->pf(p->word), p->pf(p->pos), p->pf(p->type), p->pf(p->emb_g), t.st0, p->gf(p->word),
                            p->gf(p->pos), p->gf(p->type), p->gf(p->emb_g), p->gf(p->emb_b), B, L, H, se,
@@ -1538,16 +1546,18 @@ int nav_bwd_impl(etp_planner* p, const float* d_embeds, const float* d_logits, c
   // NAV_TAIL (round 6; bit 0, default on): the node-embedding backward produces parameter gradients only -- a LEAF like the weight gradients:
   // it rides on their stream instead of holding the chain for ~38 us.  Bit 1 (default on, lazy joins only = PlannerStep): the chain does
   // not wait for the d txt_embeds accumulate chain on the aux2 stream here; its consumers do (etp_txt_bwd_range, etp_planner_join_aux), so
-  // the node-assembly backward and the panorama fork overlap it.
+  // the node-assembly backward and the panorama fork overlap it.  Same-box A/B (r06_ab_runs.json r6c10, three rounds): 3.977 against
+  // 4.010 ms (-0.8 %); bit 0 alone 3.992; device-side stamps: `nav_bwd x-layer 0 done -> text backward begins` 99 -> 50 us.
   const int tail = opt_int(OPT_NAV_TAIL, 3);
   if (!cached && c.s3 != c.st) {
     if ((tail & 2) && p->lazy_join >= 1) {
       if (!p->dtxt_ready) ETP_CHECK_HIP(hipEventCreateWithFlags(&p->dtxt_ready, hipEventDisableTiming));
       ETP_CHECK_HIP(event_record(p->dtxt_ready, c.s3));
-      p->dtxt_pending = true;
+      (void)p->dtxt_owed(c.st);
+      p->dtxt_waiters.push_back(c.st);
     } else {
       ETP_TRY(stream_after(p, c.s3, c.st));                                // d_txt complete in `stream` order
-      p->dtxt_pending = false;
+      (void)p->dtxt_owed(c.st);
     }
   }
   stamp_mark(c.st, 2091);

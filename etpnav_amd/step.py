@@ -267,6 +267,7 @@ class PlannerStep:
             check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
         if backward and self.zero_grads:
             # overwrite mode: the matrix region [0, n_matrix) is fully rewritten by this step's weight-gradient stores
+            # (round 6: navigation cast + this memset BEHIND the panorama branch instead of in front of it: no gain, r06_ab_runs.json r6c11)
             lo = eng.n_matrix if self.grad_overwrite else 0
             check(L.etp_memset_async(eng.grads.data_ptr() + lo * 4, 0, (eng.grads.numel() - lo) * 4, s2), "memset grads")
         if after_prologue is not None:         # MicroBatchedStep: the other micro-batches' streams are ordered after the casts / memset
