@@ -673,15 +673,19 @@ static int self_att_fwd(const Ctx& c, const AttnP& p, const Act& x, SelfAttStash
   return ln_fwd_s(c.dt, s.s, c.pl->pf(p.ln_g), c.pl->pf(p.ln_b), s.y.f, lp(s.y, c.dt), s.st, M, H, eps, c.st);
 }
 // g (fp32): in = dL/dy, out = dL/dx (same buffer)
+// tail_flush (round 6): the caller's LAST sub-block of the step -- nothing runs behind it that could hide its weight gradients, so each of
+// the two goes out the moment its operands exist (out-projection: behind the LayerNorm backward; QKV: behind the attention backward)
+// instead of together at the end of the block
 static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAttStash& s, int Bn, int L,
                         const uint8_t* keymask, const float* dist, const float* sp_w, const float* sp_b, float* d_sp_w,
-                        float* d_sp_b, float* g, const BwdWs& w, int mode, int layer) {
+                        float* d_sp_b, float* g, const BwdWs& w, int mode, int layer, bool tail_flush = false) {
   const int H = c.H, M = Bn * L;
   etp_planner* pl = c.pl;
   const Drop dh = hid(c, mode, layer, SITE_ATT_O);
   ETP_TRY(ln_bwd_chain(c, g, s.s, s.st, p.ln_g, p.ln_b, nullptr, w.t1.f, lp2(c, w.t1, dh), M, dh, w.lnp));   // t1.f = ds, operand copy = ds * mask
   const void* ds = op2(c, w.t1, dh);
   ETP_TRY(linear_wgrad(c, ds, H, s.ctx, H, p.o_w, p.o_b, M, H, H));
+  if (tail_flush) ETP_TRY(flush_side(c));
   AttnBuf a{s.qkv, 3L * H, offs(s.qkv, H, c.es), 3L * H, offs(s.qkv, 2 * H, c.es), 3L * H, Bn, L, L, (int)round_up(L, 8),
             keymask, 0, dist, sp_w, sp_b};
   a.Pd = s.Pd;
@@ -689,6 +693,7 @@ static int self_att_bwd(const Ctx& c, const AttnP& p, const Act& x, const SelfAt
   ETP_TRY(attn_bwd_proj(c, a, s.P, ds, p.o_w, w.t2, M, w.dP, w.dqkv, 3L * H, offs(w.dqkv, H, c.es), 3L * H,                    // t2 = dctx
                         offs(w.dqkv, 2 * H, c.es), 3L * H, d_sp_w, d_sp_b, att(c, mode, layer, SITE_ATT_P)));
   ETP_TRY(linear_wgrad(c, w.dqkv, 3 * H, x.t, H, p.qkv_w, p.qkv_b, M, 3 * H, H));
+  if (tail_flush) ETP_TRY(flush_side(c));
   return linear_dgrad_s(c, w.dqkv, 3 * H, p.qkv_w, g, M, 3 * H, H, w.t1.f);                                  // g = dx
 }
 
@@ -947,7 +952,11 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // 256-tile budget that leaves every CU room for a chain workgroup both cost +1..2 %: profiles/r05_ab_runs.json; the patch is
     // tools/experiments/r05_ln_fold_and_flush_split.patch)
     if (l == 0 && layer_lo == 0) ETP_TRY(flush_side(c));
-    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l));
+    // TXT_LAST_SPLIT (round 6, default on): layer 0's two attention weight gradients each start as soon as their operands exist; held back
+    // to the end of the layer (as every other layer's are) they began when the chain had 40 us left and set a ~66-us tail behind it
+    const bool last_split = l == 0 && layer_lo == 0 && opt_on(OPT_TXT_LAST_SPLIT, true);
+    ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l,
+                         last_split));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
     // tools/r03_call15.sh) forks every n layers instead: 4n products per launch, fewer launch tails, later start of the leaf work
     const int every = std::max(1, opt_int(OPT_FLUSH_EVERY, 1));
