@@ -24,7 +24,7 @@ enum Opt {
   OPT_GELU_TABLE,       // 0: bf16-mode GELU epilogues evaluate erf instead of the LDS table
   OPT_ATTN_PROJ,        // out-projection dgrad folded into the register-resident attention backward: unset = when batch*heads <= CUs, 0 never, 1 always
   OPT_NAV_TAIL,         // bit 0: the node-embedding backward as a leaf on the weight-gradient stream; bit 1: d txt_embeds joined by its consumers (default 3)
-  OPT_TXT_LAST_SPLIT,   // 0: text layer 0's attention weight gradients go out together at the end of the layer (default: each as soon as it can)
+  OPT_TXT_LAST_SPLIT,   // text layer 0's attention weight gradients forked each as soon as it can: unset = for multi-round grids (config 4), 0 never, 1 always
   OPT_TXT_TAIL,         // 1: the text-embedding backward on the aux2 stream beside the weight-gradient backlog (measured neutral: default off)
   OPT_ATTN_QKV,         // QKV projection folded into the register-resident self-attention forward: unset / 0 never (measured slower), 1 always
 #ifdef ETP_EXPERIMENTS

@@ -952,9 +952,13 @@ int etp_txt_bwd_range(etp_planner* p, const float* dout, const int64_t* ids, con
     // 256-tile budget that leaves every CU room for a chain workgroup both cost +1..2 %: profiles/r05_ab_runs.json; the patch is
     // tools/experiments/r05_ln_fold_and_flush_split.patch)
     if (l == 0 && layer_lo == 0) ETP_TRY(flush_side(c));
-    // TXT_LAST_SPLIT (round 6, default on): layer 0's two attention weight gradients each start as soon as their operands exist; held back
-    // to the end of the layer (as every other layer's are) they began when the chain had 40 us left and set a ~66-us tail behind it
-    const bool last_split = l == 0 && layer_lo == 0 && opt_on(OPT_TXT_LAST_SPLIT, true);
+    // TXT_LAST_SPLIT (round 6): layer 0's two attention weight gradients each start as soon as their operands exist; held back to the end
+    // of the layer (as every other layer's are) they begin when the chain has 40 us left and set a ~66-us tail behind it.  Measured
+    // (r06_ab_runs.json r6c13): config 2 -- tail 66 -> 44 us, but the attention half they now share the chip with 142 -> 154 us: +0.3 %;
+    // config 5 +0.5 %; config 4 (8192 rows: long products, the tail is theirs) 10.516 against 10.574 ms, -0.55 %.  Rule: where the
+    // weight gradients are NOT held back behind the next layer's dgrad either (delay == 0: multi-round grids); 0 / 1 force it.
+    const int split_env = opt_int(OPT_TXT_LAST_SPLIT, -1);
+    const bool last_split = l == 0 && layer_lo == 0 && (split_env >= 0 ? split_env != 0 : delay == 0);
     ETP_TRY(self_att_bwd(c, p->txt[l].att, x, t.att[l], B, L, mask, nullptr, nullptr, nullptr, nullptr, nullptr, g, wa, MODE_TXT, l,
                          last_split));
     // one fork per layer: this layer's four weight gradients as one grouped launch.  ETP_FLUSH_EVERY=n (measurement knob,
@@ -1395,18 +1399,24 @@ int nav_fwd_impl(etp_planner* p, const float* txt, void* kvbuf, const uint8_t* t
   KvCache kc;
   if (cached) kc = plan_kv(p, kvbuf, kv_mod > 0 ? kv_mod : B, L);     // kv_mod: the cache holds kv_mod instructions, episode b reads b % kv_mod
   const void* txtT = txt;
-  if (!cached && c.dt == ETP_BF16) { ETP_TRY(cast_f32_to_bf16(txt, s.txtT, (long)Mt * H, c.st)); txtT = s.txtT; }
+  // The text K/V projections of ALL x-layers depend only on the text (M = B*L rows, the largest GEMMs of this entry
+  // point), not on the node chain: with a side stream they are issued up front and each layer waits for its own.
+  const bool kv_side = !cached && c.sw != c.st;
+  // their bf16 operand copy of the text is read by nothing else in this entry point (the backward's K/V weight gradients read it on
+  // the same side stream): with a side stream the cast goes there too (round 6), off the chain
+  if (!cached && c.dt == ETP_BF16) {
+    if (kv_side) ETP_TRY(stream_after(p, c.st, c.sw));
+    ETP_TRY(cast_f32_to_bf16(txt, s.txtT, (long)Mt * H, kv_side ? c.sw : c.st));
+    txtT = s.txtT;
+  }
   ETP_TRY(gmap_embed_fwd(c.dt, img, step_ids, pos, p->pf(p->step_emb), p->pf(p->gpos_w), p->pf(p->gpos_b), p->pf(p->gpos_g),
                          p->pf(p->gpos_bb), s.x0.f, lp(s.x0, c.dt), s.st0, Mg, H, cf.ang_feat + 3, c.st));
   const float* spw = cf.use_sprels ? p->pf(p->sp_w) : nullptr;
   const float* spb = cf.use_sprels ? p->pf(p->sp_b) : nullptr;
   Act x = s.x0;
-  // The text K/V projections of ALL x-layers depend only on the text (M = B*L rows, the largest GEMMs of this entry
-  // point), not on the node chain: with a side stream they are issued up front and each layer waits for its own.
-  const bool kv_side = !cached && c.sw != c.st;
   std::vector<hipEvent_t> kv_ready(cf.n_x);
   if (kv_side) {
-    ETP_TRY(stream_after(p, c.st, c.sw));
+    if (c.dt != ETP_BF16) ETP_TRY(stream_after(p, c.st, c.sw));       // (bf16: forked above, in front of the operand cast)
     Ctx cs = c;
     cs.st = c.sw;
     // (round 6: the n_x projections as ONE grouped launch -- on this stream or on the chain itself -- measured +0.9 % on config 2 and +0.8 %
