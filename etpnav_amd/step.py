@@ -168,7 +168,6 @@ class PlannerStep:
         # node assembly (gather-mean of the view embeddings) rides behind pano_fwd on the panorama stream, off the chain (round 6: -0.35 %,
         # 4.045 against 4.059 ms, three pairs, profiles/r06_ab_runs.json r6c9); ETP_ASSEMBLE_ON_S2=0 puts it back behind the join
         self._assemble_on_s2 = os.environ.get("ETP_ASSEMBLE_ON_S2", "1") != "0"
-        self._assemble_bwd_on_s2 = self._assemble_on_s2 and os.environ.get("ETP_ASSEMBLE_BWD_ON_S2", "1") != "0"
         self._install_streams()
         self._pano_pending = False
         self.graph = None
@@ -310,20 +309,16 @@ class PlannerStep:
                 check(L.etp_planner_join_aux(h, s), "join aux")
             check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
             return
-        # the node-assembly backward feeds the panorama backward only: with the panorama stream it goes THERE, behind the fork, and the chain
-        # continues with the text backward at once (round 6; ETP_ASSEMBLE_ON_S2=0: on the chain, in front of the fork)
-        on_s2 = self._assemble_bwd_on_s2 and s2 != s
-        if not on_s2:
-            check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s),
-                  "node assembly bwd")
+        # (round 6: this gather on the panorama stream behind the fork instead -- it feeds the panorama backward only -- measured neutral,
+        # 3.971 against 3.969 ms over four pairs, r06_ab_runs.json r6c14: the text backward waits for d txt_embeds meanwhile anyway)
+        check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s),
+              "node assembly bwd")
         L.etp_stamp_mark(s, 5)
-        check(L.etp_stream_after(s, s2), "fork")                 # (defer_pano: the panorama stream is ordered after d_gimg's producer already now)
-        if on_s2:
-            check(L.etp_gather_sum(dt, ptr(self.d_gimg), ptr(pb), ptr(xb), ptr(wb), ptr(self.d_pano), self.Bp * V, H, 0, s2),
-                  "node assembly bwd")
-        if defer_pano:             # the caller enqueues the panorama backward later (run_eager: after the first text layers)
+        if defer_pano:             # the caller enqueues the panorama backward later (run_eager: after the first text layers);
+            check(L.etp_stream_after(s, s2), "fork")             # its stream is ordered after d_pano's producer already now
             check(L.etp_planner_set_grad_overwrite(h, 0), "set_grad_overwrite")
             return
+        check(L.etp_stream_after(s, s2), "fork")
         check(L.etp_pano_bwd(h, ptr(self.d_pano), ptr(i["rgb"]), ptr(i["dep"]), ptr(i["loc"]), ptr(i["nav"]), self.Bp, V, None,
                              ptr(self.st_pano), ptr(self.ws_pano), s2), "pano_bwd")
         if join_pano:
