@@ -168,7 +168,6 @@ class PlannerStep:
         # node assembly (gather-mean of the view embeddings) rides behind pano_fwd on the panorama stream, off the chain (round 6: -0.35 %,
         # 4.045 against 4.059 ms, three pairs, profiles/r06_ab_runs.json r6c9); ETP_ASSEMBLE_ON_S2=0 puts it back behind the join
         self._assemble_on_s2 = os.environ.get("ETP_ASSEMBLE_ON_S2", "1") != "0"
-        self._late_zero = os.environ.get("ETP_LATE_ZERO", "0") == "1"
         self._install_streams()
         self._pano_pending = False
         self.graph = None
@@ -266,12 +265,10 @@ class PlannerStep:
         if self.refresh_weights:
             check(L.etp_planner_refresh_part(h, 1, s2), "refresh panorama weights")
             check(L.etp_planner_refresh_part(h, 2, s2), "refresh navigation weights")
-        # ETP_LATE_ZERO=1 (round-6 experiment): the 96-MB gradient memset runs on the panorama stream BESIDE forward_navigation (small,
-        # latency-bound kernels) instead of beside text layer 0; the backward waits for it
-        late_zero = self._late_zero and s2 != s and after_prologue is None
-        if backward and self.zero_grads and not late_zero:
+        if backward and self.zero_grads:
             # overwrite mode: the matrix region [0, n_matrix) is fully rewritten by this step's weight-gradient stores
-            # (round 6: navigation cast + this memset BEHIND the panorama branch instead of in front of it: no gain, r06_ab_runs.json r6c11)
+            # (round 6: navigation cast + this memset BEHIND the panorama branch instead of in front of it: no gain, r06_ab_runs.json r6c11;
+            # the memset beside forward_navigation, the backward waiting for it: +0.7 %, 3.952 against 3.924 ms, four pairs, r6c16)
             lo = eng.n_matrix if self.grad_overwrite else 0
             check(L.etp_memset_async(eng.grads.data_ptr() + lo * 4, 0, (eng.grads.numel() - lo) * 4, s2), "memset grads")
         if after_prologue is not None:         # MicroBatchedStep: the other micro-batches' streams are ordered after the casts / memset
@@ -283,10 +280,6 @@ class PlannerStep:
         if self._assemble_on_s2 and s2 != s:   # the gather-mean of the view embeddings depends on the panorama branch only: behind it, off the chain
             check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s2), "node assembly")
         check(L.etp_stream_after(s2, s), "join")
-        if backward and self.zero_grads and late_zero:
-            lo = eng.n_matrix if self.grad_overwrite else 0
-            check(L.etp_memset_async(eng.grads.data_ptr() + lo * 4, 0, (eng.grads.numel() - lo) * 4, s2), "memset grads")
-            self._zero_pending = True
         L.etp_stamp_mark(s, 2)
         if not (self._assemble_on_s2 and s2 != s):
             check(L.etp_gather_sum(dt, ptr(self.pano), ptr(pf), ptr(xf), ptr(wf), ptr(self.gimg), B * G, H, 0, s), "node assembly")
@@ -307,9 +300,6 @@ class PlannerStep:
         self._install_streams()
         eng.set_dropout(self._drop_state())
         check(L.etp_planner_set_grad_overwrite(h, int(self.grad_overwrite)), "set_grad_overwrite")
-        if getattr(self, "_zero_pending", False):               # ETP_LATE_ZERO: the gradient memset rode beside forward_navigation
-            check(L.etp_stream_after(s2, s), "join memset")
-            self._zero_pending = False
         check(L.etp_nav_bwd(h, None, ptr(self.dlogits), ptr(self.txt), ptr(i["txt_masks"]), ptr(i["step_ids"]),
                             ptr(i["pos"]), ptr(i["gmask"]), ptr(i["visited"]), ptr(i["dists"]), B, Lt, G, ptr(self.d_txt),
                             ptr(self.d_gimg), ptr(self.st_nav), ptr(self.ws_nav), s), "nav_bwd")
