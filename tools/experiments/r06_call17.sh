@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, GPU call 17: upper bound of hiding the residual read of the N = 768 products behind their reduction -- a timing-only build of
+# (the -DETP_EXPT_SKIP_R hook in gemm_shared.h was removed together with the experiment: profiles/r06_ab_runs.json r6c17)
 # gemm_mm32.hip that does not read the residual at all (results wrong), same-box A/B on config 2.
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r06c17; mkdir -p $O

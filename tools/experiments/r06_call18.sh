@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, GPU call 18: the fp32 residual of the 128x64 stream tiles fetched before the reduction (gemm_mm32.hip RPre): parity, phase probe,
 # same-box A/B against the same library built with -DETP_MM32_NO_RPRE.
+# (RPre / -DETP_MM32_NO_RPRE were reverted after this call: profiles/r06_ab_runs.json r6c18)
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r06c18; mkdir -p $O
 export TMPDIR=/tmp
