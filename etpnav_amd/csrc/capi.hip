@@ -85,8 +85,8 @@ unsigned row_launch_lds(const void* kern, int family, unsigned smem) {
 // ---- run-time switches (options.h) -------------------------------------------------------------------------------------------
 static const char* const kOptNames[OPT_COUNT] = {
     "MM32", "MM32_GROUP", "MM32_K2", "GEMM_TILE", "GROUP_TILE", "GEMM_WIDE", "GEMM_SMALL", "GEMM_XCD", "ATTN_FUSED", "ATTN_FLASH", "ATTN_Q96",
-    "ATTN_ROWS", "LNBWD_GRID", "LNBWD_TWO_STAGE", "LN_TICKET", "WGRAD_GROUP", "FLUSH_DELAY", "FLUSH_EVERY", "ROW_EXCLUSIVE",
-    "GROUP_ORDER", "GELU_TABLE", "ATTN_PROJ", "NAV_TAIL", "TXT_LAST_SPLIT", "TXT_TAIL", "ATTN_QKV",
+    "ATTN_ROWS", "LNBWD_GRID", "LNBWD_TWO_STAGE", "WGRAD_GROUP", "FLUSH_DELAY", "FLUSH_EVERY", "ROW_EXCLUSIVE",
+    "ATTN_PROJ", "NAV_TAIL", "TXT_LAST_SPLIT", "TXT_TAIL", "ATTN_QKV",
 #ifdef ETP_EXPERIMENTS
     "SKIP_LN", "SKIP_ATTN", "SKIP_WGRAD",
 #endif

@@ -17,11 +17,9 @@ enum Opt {
   OPT_GEMM_SMALL,       // 0: gemm.hip's 32x64 class off
   OPT_GEMM_XCD,         // 0: XCD-chunked tile order off
   OPT_ATTN_FUSED, OPT_ATTN_FLASH, OPT_ATTN_Q96, OPT_ATTN_ROWS,
-  OPT_LNBWD_GRID, OPT_LNBWD_TWO_STAGE, OPT_LN_TICKET,
+  OPT_LNBWD_GRID, OPT_LNBWD_TWO_STAGE,
   OPT_WGRAD_GROUP, OPT_FLUSH_DELAY, OPT_FLUSH_EVERY,
   OPT_ROW_EXCLUSIVE,    // 0: the row kernels of DESIGN.md §3.6 launch WITHOUT the CU-exclusive LDS request (neighbour-matrix test only)
-  OPT_GROUP_ORDER,      // grouped weight gradients: 0 = contiguous XCD chunks (round 2-5), 1 = panel-major order inside an XCD
-  OPT_GELU_TABLE,       // 0: bf16-mode GELU epilogues evaluate erf instead of the LDS table
   OPT_ATTN_PROJ,        // out-projection dgrad folded into the register-resident attention backward: unset = when batch*heads <= CUs, 0 never, 1 always
   OPT_NAV_TAIL,         // bit 0: the node-embedding backward as a leaf on the weight-gradient stream; bit 1: d txt_embeds joined by its consumers (default 3)
   OPT_TXT_LAST_SPLIT,   // text layer 0's attention weight gradients forked each as soon as it can: unset = for multi-round grids (config 4), 0 never, 1 always
