@@ -35,6 +35,11 @@ template <int V> __device__ __forceinline__ f2 pk(f2 a, f2 b) {
   if constexpr (V == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0]" : "=v"(r) : "v"(a), "v"(b));      // a.lo * b.hi + a.lo | a.hi * b.hi + a.hi
   if constexpr (V == 8) asm volatile("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1]" : "=v"(r) : "v"(a), "v"(b));      // a.lo * a.lo + b.hi | a.hi * a.hi + b.hi
   if constexpr (V == 9) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+  // v_pk_mov_b32: D.lo = src0[op_sel[0]], D.hi = src1[op_sel[1]].  op_sel:[1,0] is the form the compiler emits in the mm32 GEMM epilogues
+  // (132 of them in gemm_mm32.o); [0,1], [1,1] for completeness
+  if constexpr (V == 10) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  if constexpr (V == 11) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  if constexpr (V == 12) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 // expected (lo, hi) of variant V: op_sel picks the source register of the LOW product, op_sel_hi of the HIGH product (default 1)
@@ -53,6 +58,9 @@ template <int V> __device__ __forceinline__ f2 expect(f2 a, f2 b) {
   if constexpr (V == 6) { r.x = sadd(a.x, b.y); r.y = sadd(a.y, b.y); return r; }
   if constexpr (V == 7) { r.x = sfma(a.x, b.y, a.x); r.y = sfma(a.y, b.y, a.y); return r; }
   if constexpr (V == 8) { r.x = sfma(a.x, a.x, b.y); r.y = sfma(a.y, a.y, b.y); return r; }
+  if constexpr (V == 10) { r.x = a.y; r.y = b.x; return r; }
+  if constexpr (V == 11) { r.x = a.x; r.y = b.y; return r; }
+  if constexpr (V == 12) { r.x = a.y; r.y = b.y; return r; }
   constexpr int sl0 = (V == 2 || V == 9) ? 1 : 0, sl1 = (V == 1 || V == 5 || V == 9) ? 1 : 0;
   constexpr int sh0 = (V == 4 || V == 5) ? 0 : 1, sh1 = (V == 3) ? 0 : 1;
   r.x = smul(sl0 ? a.y : a.x, sl1 ? b.y : b.x);
@@ -123,6 +131,9 @@ int pk_run(int variant, unsigned* out, int iters, int blocks, unsigned seed, voi
     case 7: hipLaunchKernelGGL(pk_victim<7>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
     case 8: hipLaunchKernelGGL(pk_victim<8>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
     case 9: hipLaunchKernelGGL(pk_victim<9>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
+    case 10: hipLaunchKernelGGL(pk_victim<10>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
+    case 11: hipLaunchKernelGGL(pk_victim<11>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
+    case 12: hipLaunchKernelGGL(pk_victim<12>, dim3(blocks), dim3(256), 0, st, out, iters, seed); break;
     default: return -1;
   }
   return (int)hipGetLastError();

@@ -40,7 +40,8 @@ NEIGH = {
     "library GEMM 128x64 (2560x768x3072)": lambda: [_lib.check(L.etp_gemm(ctypes.byref(d64), s_n.cuda_stream), "gemm") for _ in range(24)],
 }
 FORMS = ["v_pk_mul_f32 (plain)", "op_sel:[0,1]", "op_sel:[1,0]", "op_sel_hi:[1,0]", "op_sel_hi:[0,1]", "op_sel:[0,1] op_sel_hi:[0,1]",
-         "v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mul_f32 op_sel:[1,1]"]
+         "v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mul_f32 op_sel:[1,1]",
+         "v_pk_mov_b32 op_sel:[1,0]", "v_pk_mov_b32 op_sel:[0,1]", "v_pk_mov_b32 op_sel:[1,1]"]
 if os.environ.get("PK_FORMS"):
     KEEP = [int(x) for x in os.environ["PK_FORMS"].split(",")]
 else:
