@@ -150,6 +150,39 @@ def env_overrides():
     return out
 
 
+class LineWatchdog:
+    """`value` is measured when the timed region ends; what follows at N > 1 (the exposed-communication legs, the SECOND communicator of
+    the transport comparison, the teardown) is reported extras made of collectives -- and a first contact with RCCL on hardware the builder
+    never had.  A collective that does not return on some rank must not cost the job its ONE line: `timeout` seconds after
+    start() the rank that owns the line (fallback is not None) prints the fallback line unless the real one went out, and every rank leaves
+    with status 0 (os._exit: the main thread may sit inside a collective).  print_line() and the fallback exclude each other."""
+
+    def __init__(self, timeout, fallback):
+        import threading
+        self.timeout, self.fallback, self.partial = float(timeout), fallback, {}
+        self._lock, self._printed = threading.Lock(), False
+        self._timer = threading.Timer(self.timeout, self._bail)
+        self._timer.daemon = True
+
+    def start(self):
+        self._timer.start()
+
+    def print_line(self, line):
+        with self._lock:
+            print(line, flush=True)
+            self._printed = True
+
+    def _bail(self):
+        with self._lock:
+            if self.fallback is not None and not self._printed:
+                try:
+                    print(self.fallback(), flush=True)
+                except Exception as e:                               # noqa: BLE001
+                    print(f"[bench] watchdog could not build the line: {e}", file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +366,59 @@ def main():
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    def make_out(comm_info, roofline, optimizer, gemm_table):
+        """the ONE JSON line (rank 0); a function since round 6 so that the watchdog of the post-metric communication legs can print it too"""
+        fl = flops_per_step(w, cfg)
+        # whole-step roofline (SURVEY.md §8d): t_roof = sum over the step's kernels of max(flops/peak_mfma, bytes/peak_hbm),
+        # algorithmic work from the tensor shapes (etpnav_amd/roofline.py); achieved = t_roof / measured step time
+        from etpnav_amd.roofline import step_roofline
+        sr = step_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
+                           peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
+        from etpnav_amd.roofline import fused_plan_roofline
+        fp = fused_plan_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
+                                 peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
+        step_roof = {"t_roof_ms": round(sr["t_roof_ms"], 4), "measured_ms": round(ms_per_step, 4),
+                     "frac": round(sr["t_roof_ms"] / ms_per_step, 4), "alg_flops": sr["flops"], "alg_hbm_bytes": sr["hbm_bytes"],
+                     "mfma_bound_ms": round(sr["t_mfma_bound_ms"], 4), "hbm_bound_ms": round(sr["t_hbm_bound_ms"], 4),
+                     "peaks": {"bf16_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
+                     "fused_plan": {"t_roof_ms": round(fp["t_roof_ms"], 4), "frac": round(fp["t_roof_ms"] / ms_per_step, 4),
+                                    "alg_hbm_bytes": fp["hbm_bytes"],
+                                    "note": "SURVEY.md §8(d) byte model: bf16 activations saved once and read once, one fused "
+                                            "kernel per layer direction, weights 2 B (fwd) + 2 B (dgrad) + 4 B (wgrad) -- what a "
+                                            "fully fused implementation would move; `frac` above is against THIS implementation's "
+                                            "kernel decomposition (fp32 residual stream, separate LayerNorm passes)"},
+                     "note": "t_roof = sum_k max(flops_k/peak_mfma, bytes_k/peak_hbm) over the step's kernels as built, one read "
+                             "of every input and one write of every output per kernel (etpnav_amd/roofline.py)"}
+        return {
+            "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
+            "value": round(args.steps / elapsed * world, 3),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
+                                    if args.workload != "sap" else
+                                    f"pre-training SAP task (pretrain_cmt.py:223-283), T={w['T']} panoramas per episode: ")
+                                   + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
+                                   f"{w['task']} planner 9/2/4 layers, random-init weights",
+                       "global_batch": global_b, "parallelism": f"dp{world}",
+                       "ranks_seen": ranks_seen, "grad_comm": comm_kind,
+                       "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro,
+                       "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
+                                    "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
+                       "grad_comm_dtype": args.comm_dtype if world > 1 else None,
+                       "grad_comm_note": ("bf16 transport of the gradient buckets (reduction and the optimizer's input stay fp32); the "
+                                          "reference's DDP reduces fp32: --comm-dtype fp32") if (world > 1 and args.comm_dtype == "bf16") else None,
+                       "env_overrides": env_overrides()},
+            "comm": comm_info,
+            "loss": round(loss, 5),
+            "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
+            "model_flops_per_step": fl,
+            "roofline": roofline,
+            "roofline_step": step_roof,
+            "optimizer": optimizer,
+            "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
+        }
+
     # ---- communication leg (N > 1): what a scaling curve needs to be read.  Device-side stamps (etp_stamp: s_memrealtime on the
     # stream) around the part of the step that only waits for the reduction: `exposed` = from the moment the main stream has
     # finished the backward (every bucket announced) until reducer.finish() lets it continue.
@@ -363,6 +449,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return round(float(t.item()), 4)
 
+    # Watchdog of everything between the metric and the line (N > 1 only; class LineWatchdog above).
+    watchdog = None
+    if world > 1:
+        leg_timeout = float(os.environ.get("ETP_BENCH_LEG_TIMEOUT", "300"))
+
+        def fallback_line():
+            ci = dict(watchdog.partial.get("comm") or {},
+                      watchdog=f"a post-metric leg did not return within {leg_timeout:.0f} s on some rank; `value` / `ms_per_step` are "
+                               "the completed timed region")
+            o = make_out(ci, None, None, [])
+            o["cpu_baseline"] = None
+            return json.dumps(o)
+
+        watchdog = LineWatchdog(leg_timeout, fallback_line if rank == 0 else None)
+        watchdog.start()
+        if os.environ.get("ETP_BENCH_TEST_HANG") == str(rank):      # TEST ONLY: this rank never reaches the legs' collectives
+            time.sleep(10 * leg_timeout)
+
     if world > 1 and reducer is not None:
         esz = 2 if args.comm_dtype == "bf16" else 4
         dense = sum(e - s0 for s0, e in reducer.ranges)
@@ -374,6 +478,7 @@ def main():
                      "note": "exposed_ms = device-side time (etp_stamp) the main stream spends between the end of its backward and the "
                              "return of the gradient reduction, max over ranks, mean of 6 steps after the timed region; "
                              "bytes_per_step = payload one rank contributes per step (dense buckets + its row-sparse block x world)"}
+        watchdog.partial["comm"] = comm_info
         # both transports side by side, so that a scaling curve can be read on the reference's numerics (fp32, the
         # default and what `value` was timed with unless --comm-dtype says otherwise) AND on the half-width opt-in.  The second
         # communicator is created only after the first one is closed (never two RCCL communicators in flight).
@@ -559,61 +664,15 @@ def main():
                                                     "(weights move); the step runs with refresh_weights=False, zero_grads=False "
                                                     "because the optimizer kernel already wrote the shadows and zeroed the arena"}
     if rank == 0:
-        fl = flops_per_step(w, cfg)
-        # whole-step roofline: t_roof = sum over the step's kernels of max(flops/peak_mfma, bytes/peak_hbm),
-        # algorithmic work from the tensor shapes (etpnav_amd/roofline.py); achieved = t_roof / measured step time
-        from etpnav_amd.roofline import step_roofline
-        sr = step_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
-                           peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
-        from etpnav_amd.roofline import fused_plan_roofline
-        fp = fused_plan_roofline(cfg, w["B"], w["L"], w["V"], w["G"], Bp=w["B"] * w.get("T", 1),
-                                 peak_flops=(PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12, peak_bps=PEAK_HBM_GBS * 1e9)
-        step_roof = {"t_roof_ms": round(sr["t_roof_ms"], 4), "measured_ms": round(ms_per_step, 4),
-                     "frac": round(sr["t_roof_ms"] / ms_per_step, 4), "alg_flops": sr["flops"], "alg_hbm_bytes": sr["hbm_bytes"],
-                     "mfma_bound_ms": round(sr["t_mfma_bound_ms"], 4), "hbm_bound_ms": round(sr["t_hbm_bound_ms"], 4),
-                     "peaks": {"bf16_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
-                     "fused_plan": {"t_roof_ms": round(fp["t_roof_ms"], 4), "frac": round(fp["t_roof_ms"] / ms_per_step, 4),
-                                    "alg_hbm_bytes": fp["hbm_bytes"],
-                                    "note": "SURVEY.md §8(d) byte model: bf16 activations saved once and read once, one fused "
-                                            "kernel per layer direction, weights 2 B (fwd) + 2 B (dgrad) + 4 B (wgrad) -- what a "
-                                            "fully fused implementation would move; `frac` above is against THIS implementation's "
-                                            "kernel decomposition (fp32 residual stream, separate LayerNorm passes)"},
-                     "note": "t_roof = sum_k max(flops_k/peak_mfma, bytes_k/peak_hbm) over the step's kernels as built, one read "
-                             "of every input and one write of every output per kernel (etpnav_amd/roofline.py)"}
-        out = {
-            "metric": "planner fwd+bwd steps/sec at batch 32, 36-view x768 pano + 80-tok instr",
-            "value": round(args.steps / elapsed * world, 3),
-            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[{ {'c2': 1, 'c5': 4, 'c4': 3}[args.workload] }]: "
-                                    if args.workload != "sap" else
-                                    f"pre-training SAP task (pretrain_cmt.py:223-283), T={w['T']} panoramas per episode: ")
-                                   + f"B={w['B']}/GPU, L={w['L']}, V={w['V']}x{w['image_feat_size']}, G={w['G']}, "
-                                   f"{w['task']} planner 9/2/4 layers, random-init weights",
-                       "global_batch": global_b, "parallelism": f"dp{world}",
-                       "ranks_seen": ranks_seen, "grad_comm": comm_kind,
-                       "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro,
-                       "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
-                                    "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
-                       "grad_comm_dtype": args.comm_dtype if world > 1 else None,
-                       "grad_comm_note": ("bf16 transport of the gradient buckets (reduction and the optimizer's input stay fp32); the "
-                                          "reference's DDP reduces fp32: --comm-dtype fp32") if (world > 1 and args.comm_dtype == "bf16") else None,
-                       "env_overrides": env_overrides()},
-            "comm": comm_info,
-            "loss": round(loss, 5),
-            "model_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
-            "model_flops_per_step": fl,
-            "roofline": roofline,
-            "roofline_step": step_roof,
-            "optimizer": optimizer,
-            "gemm_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in gemm_table[:6]],
-        }
+        out = make_out(comm_info, roofline, optimizer, gemm_table)
         if world == 1 and not args.no_cpu_baseline and args.workload != "sap":
             out["cpu_baseline"] = cpu_baseline(w, dict(image_feat_size=w["image_feat_size"]), train=args.mode == "train")
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        if watchdog is not None:
+            watchdog.print_line(json.dumps(out))   # from here on the watchdog only ends the process (the teardown below is collective too)
+        else:
+            print(json.dumps(out), flush=True)
     step.close()
     if world > 1:
         dist.destroy_process_group()

@@ -159,3 +159,25 @@ def test_bench_cpu_baseline_leg_measures_the_full_batch_when_it_fits():
     assert "the full batch of 4 episodes (measured, not scaled)" in r["sample"] and r["kind"] == "port" and r["cores"] >= 1
     r = bench.cpu_baseline(w, dict(image_feat_size=768), budget_s=1e-3, train=False)
     assert not r["full_batch"] and r["mode"] == "eval" and "1 of the 4 episodes per step" in r["sample"] and r["value"] == r["eval_value"] > 0
+
+
+def test_bench_line_watchdog_prints_the_fallback_once_and_leaves_with_status_zero():
+    """bench.py LineWatchdog (N > 1): the metric is measured when the timed region ends; a collective of the reported legs behind it that
+    never returns on some rank must not cost the job its one JSON line.  (a) main thread stuck: the fallback line appears after the
+    timeout, exit status 0; (b) the real line went out first: the watchdog prints nothing more and only ends the process; (c) a rank that
+    does not own the line prints nothing."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = "import sys, time; sys.path.insert(0, %r); import bench; " % root
+    cases = [
+        ("w = bench.LineWatchdog(0.5, lambda: '{\"fallback\": 1}'); w.start(); time.sleep(60)", ['{"fallback": 1}']),
+        ("w = bench.LineWatchdog(0.5, lambda: '{\"fallback\": 1}'); w.start(); w.print_line('{\"real\": 1}'); time.sleep(60)", ['{"real": 1}']),
+        ("w = bench.LineWatchdog(0.5, None); w.start(); time.sleep(60)", []),
+    ]
+    for code, want in cases:
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        assert [l for l in r.stdout.splitlines() if l.startswith("{")] == want, (code, r.stdout)
+        assert time.time() - t0 < 45, "the watchdog did not end the process"
