@@ -181,3 +181,16 @@ def test_bench_line_watchdog_prints_the_fallback_once_and_leaves_with_status_zer
         assert r.returncode == 0, r.stderr[-1000:]
         assert [l for l in r.stdout.splitlines() if l.startswith("{")] == want, (code, r.stdout)
         assert time.time() - t0 < 45, "the watchdog did not end the process"
+
+
+def test_two_gpu_rccl_cases_are_the_last_file_of_the_suite():
+    """The driver runs `pytest -x`; the four cases of tests/test_zz_two_gpu.py would be RCCL's first contact with a second rank, so they
+    must come after every other GPU test (pytest collects files in name order) and nowhere else may a test skip on device_count() < 2."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(root, "test_*.py")))
+    assert files[-1] == "test_zz_two_gpu.py", files
+    for f in files[:-1]:
+        if f == os.path.basename(__file__):
+            continue
+        assert "device_count() < 2" not in open(os.path.join(root, f)).read(), f
