@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed clock-settle steps in front of the warm-up (default 30; the two-rank functional test passes 2: "
                          "every step there moves the whole gradient arena through gloo on the host)")
+    ap.add_argument("--chain-priority", default="default", choices=["default", "high"],
+                    help="stream the dependent chain is enqueued on: torch's default stream, or a stream of the highest priority the device "
+                         "offers (the side streams of PlannerStep are created at the lowest either way)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -259,6 +262,8 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.chain_priority == "high":
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.dist_backend, init_method="env://")
@@ -402,7 +407,7 @@ def main():
                                    f"{w['task']} planner 9/2/4 layers, random-init weights",
                        "global_batch": global_b, "parallelism": f"dp{world}",
                        "ranks_seen": ranks_seen, "grad_comm": comm_kind,
-                       "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro,
+                       "graph": use_graph, "mode": args.mode, "settle_steps": settle, "micro_batches": micro, "chain_priority": args.chain_priority,
                        "dropout": ({"hidden": cfg.hidden_dropout_prob, "attention_probs": cfg.attention_probs_dropout_prob,
                                     "sap_head": cfg.pred_head_dropout_prob} if args.mode == "train" else None),
                        "grad_comm_dtype": args.comm_dtype if world > 1 else None,
