@@ -261,11 +261,14 @@ def main():
                          f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if args.same_device:
         local_rank = 0
+    if world > 1:
+        # before the first HIP call of the process: the runtime reads it when it starts (the host driver only supports dmabuf IPC; without
+        # it RCCL fails with hipIpcGetMemHandle: invalid argument).  The image exports it already; this covers a stripped environment.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     if args.chain_priority == "high":
         torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.dist_backend, init_method="env://")
 
     from etpnav_amd.planner import GlocalTextPathNavCMT, default_config
