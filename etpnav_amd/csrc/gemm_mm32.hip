@@ -467,6 +467,33 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
           ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + rh) * CP + wc * WN + b * 32 + col] = acc[a][b][r];
   }
   __syncthreads();
+  // Round 6 (profiles/r06_epilogue_code.txt, calls r6c36-r6c39): the 128x128 / 128x64 epilogues were bound by their CODE, not by their stores (timing-only builds: no
+  // stores -0.5 .. -0.9 us, no read-back of the staged tile -0.3, no staging +0.8).  The generic form is eight (four) unrolled chunks, each carrying the whole bias /
+  // activation / dropout / residual / accumulate decision chain -- 43-KB kernels that execute a few hundred instructions of it and jump over the rest, an
+  // instruction-cache miss at every taken branch, once per launch and CU.  The input-gradient (NN) products take their variants as COMPILE-TIME specialisations
+  // instead (FIX parameter of gemm_epilogue_staged: straight-line code): FFN dgrad 21.4 -> 18.1 us (epilogue 9.5 -> 4.2), out-projection dgrad 9.8 -> 7.3 (4.0 -> 1.4),
+  // QKV dgrad 20.8 -> 19.3, FFN-up dgrad 25.2 -> 24.1; step 3.985 -> 3.925 ms (-1.5 %, six of six pairs).  The NT (forward) kernels keep the generic form: with
+  // their specialisations (GELU + saved derivative, bias + dropout + residual) the epilogues got 1.3 - 1.5 us shorter but the kernels' first slab arrived 0.6 us
+  // later and the loop ran slower -- +0.25 % in the step (r6c38).
+  if constexpr (KS == 1 && !TA && TB) {
+    const int key = epi_key(g);
+#define ETP_EPI_CASE(K) case (K): gemm_epilogue_staged<bf16_t, TC, BM, BN, NTH, KS, (K)>(smem, g, C, m0, n0, 0, tid, pre, zp); probe_end(probe, g, rec, nk); return;
+    if constexpr (sizeof(TC) == 2) {
+      switch (key) {
+        ETP_EPI_CASE(ETP_ACT_MUL_Z)                        // FFN dgrad: C = (dY W) * gelu'
+        ETP_EPI_CASE(ETP_ACT_MUL_Z | 0x400)                // the same in the panorama layers (dropout behind the activation)
+        ETP_EPI_CASE(ETP_ACT_NONE)                         // out-projection dgrad
+        default: break;
+      }
+    } else {
+      switch (key) {
+        ETP_EPI_CASE(ETP_ACT_NONE | 0x200)                 // FFN-up / QKV dgrad into the fp32 stream (+ the residual gradient)
+        ETP_EPI_CASE(ETP_ACT_NONE)
+        default: break;
+      }
+    }
+#undef ETP_EPI_CASE
+  }
   gemm_epilogue_staged<bf16_t, TC, BM, BN, NTH, KS>(smem, g, C, m0, n0, 0, tid, pre, zp);
   probe_end(probe, g, rec, nk);
 }

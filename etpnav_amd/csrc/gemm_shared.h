@@ -159,23 +159,32 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN, NTH>& pre, co
 // old C and stores them as 16-byte vectors.
 // NCT > 1: NCT such tiles lie behind one another ([NCT][BM][BN + 4]: the partial sums of an intra-workgroup split of the
 // reduction, gemm_mm32.hip KS = 2) and are added as they are read.
-template <typename T, typename TC, int BM, int BN, int NTH = 256, int NCT = 1>
+// FIX >= 0 (gemm_mm32.hip, ETP_EPI_SPECIAL): the epilogue's variant is a COMPILE-TIME constant -- activation code in bits 0-7, bias in bit 8, residual in
+// bit 9, dropout in bit 10, plain store (out_mode 0) -- so the eight unrolled chunks are straight-line code instead of eight copies of the whole
+// activation / dropout / residual / accumulate decision chain, most of it jumped over (epi_key() below computes the key of a launch).
+__host__ __device__ __forceinline__ int epi_key(const GemmArgs& g) {
+  if (g.out_mode != 0 || !g.vec_epilogue) return -1;
+  return g.act | (g.bias != nullptr ? 0x100 : 0) | (g.R != nullptr ? 0x200 : 0) | (g.drop.p > 0.f ? 0x400 : 0);
+}
+template <typename T, typename TC, int BM, int BN, int NTH = 256, int NCT = 1, int FIX = -1>
 __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs& g, TC* C, int m0, int n0, int ks, int tid,
                                                      const EpiPre<T, TC, BM, BN, NTH>& pre, const ZPre<BM * (BN / 8) / NTH> zp) {
+  const int ACT = FIX < 0 ? g.act : (FIX & 0xff);
   constexpr int CP = BN + 4;
   float* ct = reinterpret_cast<float*>(smem);
   const T* R = reinterpret_cast<const T*>(g.R);   // residual has the OUTPUT type when TC != T (see launch checks)
   T* Z = reinterpret_cast<T*>(g.Z);
   constexpr int CPRW = BN / 8;                     // 8-column chunks per tile row
   constexpr int NCHUNK = BM * CPRW / NTH;
-  if (g.vec_epilogue) {
+  if (FIX >= 0 || g.vec_epilogue) {
     // Phase A: issue every global read of the epilogue (residual / activation operand / old C) up front from
     // clamped in-bounds addresses -- no per-element branches, so the loads overlap instead of serialising.
     constexpr int VPC = 8 * (int)sizeof(TC) / 16;  // 16-byte vectors per 8-element chunk of the C type (1 or 2)
     constexpr int VPT = 8 * (int)sizeof(T) / 16;   // 16-byte vectors per 8-element chunk of T (bf16: 1, fp32: 2)
-    const bool has_r = g.R != nullptr, has_zr = act_reads_z(g.act),
-               has_c = (g.out_mode == 1);
-    const bool has_bias = (g.bias != nullptr && ks == 0);
+    const bool has_r = FIX < 0 ? g.R != nullptr : (FIX & 0x200) != 0, has_zr = act_reads_z(ACT),
+               has_c = FIX < 0 && (g.out_mode == 1);
+    const bool has_bias = FIX < 0 ? (g.bias != nullptr && ks == 0) : (FIX & 0x100) != 0;
+    const bool has_drop = FIX < 0 ? g.drop.p > 0.f : (FIX & 0x400) != 0;
     // chunks per pass: all global reads of a pass are issued together (ONE memory round trip per pass; round 2 made four
     // dependent round trips on a 128x128 tile), at most 4 chunks per pass to bound the live epilogue registers
     constexpr int HC = NCHUNK >= 4 ? 4 : NCHUNK;
@@ -256,26 +265,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
       }
-      if (g.act == ETP_ACT_GELU) {
+      if (ACT == ETP_ACT_GELU) {
         if (ok) store8(Z + (long)row * g.ldz + col, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-      } else if (g.act == ETP_ACT_GELU_SAVEGRAD) {
+      } else if (ACT == ETP_ACT_GELU_SAVEGRAD) {
         float dv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) gelu_erf_both(v[e], v[e], dv[e]);
         if (ok) store8_grad(Z + (long)row * g.ldz + col, dv);
-      } else if (g.act == ETP_ACT_RELU) {
+      } else if (ACT == ETP_ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (has_zr) {
         float zf[8];
-        if (g.act == ETP_ACT_MUL_Z) unpack8_grad<T>(zz[jj], zf);
+        if (ACT == ETP_ACT_MUL_Z) unpack8_grad<T>(zz[jj], zf);
         else unpack8<T>(zz[jj], zf);
-        if (g.act == ETP_ACT_GELU_BWD) {
+        if (ACT == ETP_ACT_GELU_BWD) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(zf[e]);
-        } else if (g.act == ETP_ACT_MUL_Z) {
+        } else if (ACT == ETP_ACT_MUL_Z) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= zf[e];
         } else {
@@ -283,7 +292,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
           for (int e = 0; e < 8; ++e) v[e] = zf[e] > 0.f ? v[e] : 0.f;
         }
       }
-      if (g.drop.p > 0.f) {
+      if (has_drop) {
         const uint32_t e0 = (uint32_t)row * (uint32_t)g.N + (uint32_t)col;
         float dm[8];
         drop_mult_run<8>(g.drop.seed, e0, g.drop.p, g.drop.inv_keep, dm);
@@ -297,7 +306,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(char* smem, const GemmArgs&
         for (int e = 0; e < 8; ++e) v[e] += rf[e];
       }
       TC* dst = C + (long)row * g.ldc + col;
-      if (g.out_mode == 2) {
+      if (FIX < 0 && g.out_mode == 2) {
         if constexpr (sizeof(TC) == 4) {
           if (ok) {
 #pragma unroll
