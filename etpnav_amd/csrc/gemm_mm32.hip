@@ -475,6 +475,15 @@ __device__ __forceinline__ void tile(const GemmArgs& g, const bf16_t* A, const b
   // QKV dgrad 20.8 -> 19.3, FFN-up dgrad 25.2 -> 24.1; step 3.985 -> 3.925 ms (-1.5 %, six of six pairs).  The NT (forward) kernels keep the generic form: with
   // their specialisations (GELU + saved derivative, bias + dropout + residual) the epilogues got 1.3 - 1.5 us shorter but the kernels' first slab arrived 0.6 us
   // later and the loop ran slower -- +0.25 % in the step (r6c38).
+  // ... and the weight-gradient products (TN, fp32 C) in overwrite mode -- a plain store, the bias gradient rides as column sums: grouped kernel's epilogue 7.1 -> 3.3 us,
+  // the 128x64 TN class 5.1 -> 1.1; step 3.911 -> 3.876 ms (-0.9 %, six of six pairs, r6c41).  The accumulate mode (out_mode 1) keeps the generic form.
+  if constexpr (KS == 1 && TA && sizeof(TC) == 4) {
+    if (epi_key(g) == ETP_ACT_NONE) {
+      gemm_epilogue_staged<bf16_t, TC, BM, BN, NTH, KS, ETP_ACT_NONE>(smem, g, C, m0, n0, 0, tid, pre, zp);
+      probe_end(probe, g, rec, nk);
+      return;
+    }
+  }
   if constexpr (KS == 1 && !TA && TB) {
     const int key = epi_key(g);
 #define ETP_EPI_CASE(K) case (K): gemm_epilogue_staged<bf16_t, TC, BM, BN, NTH, KS, (K)>(smem, g, C, m0, n0, 0, tid, pre, zp); probe_end(probe, g, rec, nk); return;
