@@ -159,7 +159,7 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, TC, BM, BN, NTH>& pre, co
 // old C and stores them as 16-byte vectors.
 // NCT > 1: NCT such tiles lie behind one another ([NCT][BM][BN + 4]: the partial sums of an intra-workgroup split of the
 // reduction, gemm_mm32.hip KS = 2) and are added as they are read.
-// FIX >= 0 (gemm_mm32.hip, ETP_EPI_SPECIAL): the epilogue's variant is a COMPILE-TIME constant -- activation code in bits 0-7, bias in bit 8, residual in
+// FIX >= 0 (gemm_mm32.hip mm32::tile): the epilogue's variant is a COMPILE-TIME constant -- activation code in bits 0-7, bias in bit 8, residual in
 // bit 9, dropout in bit 10, plain store (out_mode 0) -- so the eight unrolled chunks are straight-line code instead of eight copies of the whole
 // activation / dropout / residual / accumulate decision chain, most of it jumped over (epi_key() below computes the key of a launch).
 __host__ __device__ __forceinline__ int epi_key(const GemmArgs& g) {
